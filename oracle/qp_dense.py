@@ -1,0 +1,233 @@
+"""Dense float64 QP solver used ONLY as test infrastructure (oracle side).
+
+    minimise   1/2 x'Px + q'x    subject to   Gx <= h,   Ax = b
+
+The reference hands its two QPs to ``cvxopt.solvers.qp`` (reference
+planner/path_planning.py:211-214 and planner/planning_utils.py:353).  cvxopt is a
+third-party dependency that is neither vendored in the reference nor installable in
+this image, and the reference pins no version of it, so the solver arithmetic itself
+is *unpinned*.  What is pinned is the formulation (P, q, G, h, A, b) produced by the
+reference's own matrix-building code; both QPs have a unique minimiser (SURVEY.md
+section 8c), so any solver that returns a KKT-certified point returns the point cvxopt
+converges toward.  This module is that independent solver:
+
+  * ``presolve``   turns ``lb == ub`` inequality pairs (how the reference pins the
+                    start and end state, path_planning.py:145-166) into equalities,
+                    because they leave the feasible set without a strict interior;
+  * ``solve_qp``   Mehrotra predictor-corrector interior point on dense matrices;
+  * ``polish``     identifies the active set and re-solves the equality-constrained
+                    QP so the answer is exact to round-off (not to an IPM tolerance);
+  * ``kkt_certificate``  solver-independent optimality check (NNLS multipliers).
+
+Nothing under ``emplanner_carla_amd/`` imports this file.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import nnls
+
+
+class QPResult(dict):
+    """dict with attribute access; mimics the fields the reference reads (res['x'])."""
+
+    __getattr__ = dict.__getitem__
+
+
+def presolve(G, h, A, b, tol=0.0):
+    """Split inequality rows into (kept inequalities, implied equalities).
+
+    Only singleton rows (one non-zero) are inspected: a variable whose tightest upper
+    bound equals its tightest lower bound is fixed, and all singleton rows on it are
+    dropped.  Returns (G2, h2, A2, b2, info).
+    """
+    G = np.asarray(G, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64).reshape(-1)
+    nvar = G.shape[1]
+    A = np.zeros((0, nvar)) if A is None else np.asarray(A, dtype=np.float64)
+    b = np.zeros(0) if b is None else np.asarray(b, dtype=np.float64).reshape(-1)
+
+    nnz = (G != 0.0).sum(axis=1)
+    single = np.nonzero(nnz == 1)[0]
+    ub = np.full(nvar, np.inf)
+    lb = np.full(nvar, -np.inf)
+    var_of = {}
+    for r in single:
+        j = int(np.nonzero(G[r])[0][0])
+        var_of[r] = j
+        bound = h[r] / G[r, j]
+        if G[r, j] > 0:
+            ub[j] = min(ub[j], bound)
+        else:
+            lb[j] = max(lb[j], bound)
+    fixed = np.nonzero(np.abs(ub - lb) <= tol)[0]
+    fixed_set = set(int(j) for j in fixed)
+    drop = [r for r in single if var_of[r] in fixed_set]
+    keep = np.setdiff1d(np.arange(G.shape[0]), np.asarray(drop, dtype=np.int64))
+    rows = np.zeros((len(fixed), nvar))
+    vals = np.zeros(len(fixed))
+    for k, j in enumerate(fixed):
+        rows[k, j] = 1.0
+        vals[k] = ub[j]
+    A2 = np.vstack([A, rows])
+    b2 = np.concatenate([b, vals])
+    return G[keep], h[keep], A2, b2, {"fixed": fixed, "kept_rows": keep}
+
+
+def _kkt_solve(P, G, A, w, r1, r2):
+    """Solve [[P + G'diag(w)G, A'],[A, 0]] [dx, dy] = [r1, r2]."""
+    n = P.shape[0]
+    p = A.shape[0]
+    K = np.zeros((n + p, n + p))
+    K[:n, :n] = P + (G.T * w) @ G
+    K[:n, n:] = A.T
+    K[n:, :n] = A
+    sol = np.linalg.solve(K, np.concatenate([r1, r2]))
+    return sol[:n], sol[n:]
+
+
+def _ipm(P, q, G, h, A, b, max_iter=200, tol=1e-11):
+    n = P.shape[0]
+    m = G.shape[0]
+    p = A.shape[0]
+    scale = max(1.0, np.abs(q).max(initial=0.0), np.abs(h).max(initial=0.0))
+    # initial point: equality-feasible least-squares-ish x, slacks pushed positive
+    x, y = _kkt_solve(P, G, A, np.ones(m), -q + G.T @ h, b)
+    s = h - G @ x
+    shift = max(0.0, -s.min(initial=0.0)) + 1.0 if (m and s.min() <= 1e-3) else 0.0
+    s = s + shift
+    z = np.ones(m)
+    it = 0
+    for it in range(max_iter):
+        rx = P @ x + q + G.T @ z + A.T @ y
+        rp = G @ x + s - h
+        re = A @ x - b
+        mu = float(s @ z) / max(m, 1)
+        res = max(np.abs(rx).max(initial=0.0), np.abs(rp).max(initial=0.0),
+                  np.abs(re).max(initial=0.0))
+        if res <= tol * scale and mu <= tol * 1e-2 * scale:
+            break
+        w = z / s
+
+        def newton(rc):
+            # rc: target for s*dz + z*ds = -rc
+            r1 = -rx - G.T @ ((z * rp - rc) / s)
+            dx, dy = _kkt_solve(P, G, A, w, r1, -re)
+            ds = -rp - G @ dx
+            dz = -(rc + z * ds) / s
+            return dx, dy, ds, dz
+
+        def max_step(v, dv):
+            neg = dv < 0
+            return float((-v[neg] / dv[neg]).min()) if neg.any() else np.inf
+
+        dxa, dya, dsa, dza = newton(s * z)
+        ap = min(1.0, max_step(s, dsa))
+        ad = min(1.0, max_step(z, dza))
+        mu_aff = float((s + ap * dsa) @ (z + ad * dza)) / max(m, 1)
+        sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
+        dx, dy, ds, dz = newton(s * z + dsa * dza - sigma * mu)
+        eta = max(0.99, 1.0 - mu) if mu < 1.0 else 0.99
+        ap = min(1.0, eta * max_step(s, ds))
+        ad = min(1.0, eta * max_step(z, dz))
+        x = x + ap * dx
+        s = s + ap * ds
+        y = y + ad * dy
+        z = z + ad * dz
+    return x, s, y, z, it + 1
+
+
+def polish(P, q, G, h, A, b, x, z, act_tol=1e-7, max_rounds=8):
+    """Active-set polish: solve the equality-constrained QP on the identified active set.
+
+    Returns (x, z, y, ok).  If sign/feasibility checks fail after a few add/drop rounds the
+    IPM point is returned unchanged with ok=False.
+    """
+    m = G.shape[0]
+    n = P.shape[0]
+    slack = h - G @ x
+    active = (slack < act_tol * (1.0 + np.abs(h))) & (z > slack)
+    for _ in range(max_rounds):
+        idx = np.nonzero(active)[0]
+        Aa = np.vstack([A, G[idx]])
+        ba = np.concatenate([b, h[idx]])
+        K = np.zeros((n + len(ba), n + len(ba)))
+        K[:n, :n] = P
+        K[:n, n:] = Aa.T
+        K[n:, :n] = Aa
+        try:
+            sol = np.linalg.lstsq(K, np.concatenate([-q, ba]), rcond=None)[0]
+        except np.linalg.LinAlgError:
+            return x, z, None, False
+        xn = sol[:n]
+        mult = sol[n:]
+        y = mult[:A.shape[0]]
+        za = mult[A.shape[0]:]
+        sl = h - G @ xn
+        bad_mult = idx[za < -1e-9 * (1.0 + np.abs(za).max(initial=0.0))]
+        bad_feas = np.nonzero((sl < -1e-9 * (1.0 + np.abs(h))) & ~active)[0]
+        if len(bad_mult) == 0 and len(bad_feas) == 0:
+            zn = np.zeros(m)
+            zn[idx] = np.maximum(za, 0.0)
+            return xn, zn, y, True
+        active[bad_mult] = False
+        active[bad_feas] = True
+    return x, z, None, False
+
+
+def kkt_certificate(P, q, G, h, A, b, x, act_tol=1e-7):
+    """Solver-independent optimality certificate.
+
+    Finds multipliers z >= 0 on the near-active inequality rows and free y on the equality
+    rows minimising |Px + q + G'z + A'y| (NNLS), and reports primal violations.  All
+    numbers are scaled by max(1, |q|_inf).
+    """
+    P = np.asarray(P, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64).reshape(-1)
+    G = np.asarray(G, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64).reshape(-1)
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    nvar = P.shape[0]
+    A = np.zeros((0, nvar)) if A is None else np.asarray(A, dtype=np.float64)
+    b = np.zeros(0) if b is None else np.asarray(b, dtype=np.float64).reshape(-1)
+    g = P @ x + q
+    slack = h - G @ x
+    act = np.nonzero(slack <= act_tol * (1.0 + np.abs(h)))[0]
+    # columns: active inequality normals (z >= 0), +A', -A' (free y split)
+    M = np.hstack([G[act].T, A.T, -A.T])
+    if M.shape[1]:
+        coef, rnorm = nnls(M, -g, maxiter=50 * max(M.shape[1], 10))
+        stat = np.abs(M @ coef + g).max()
+    else:
+        stat = np.abs(g).max(initial=0.0)
+    scale = max(1.0, np.abs(q).max(initial=0.0))
+    return {
+        "stationarity": float(stat / scale),
+        "ineq_violation": float(max(0.0, -slack.min(initial=0.0))),
+        "eq_violation": float(np.abs(A @ x - b).max(initial=0.0)),
+        "n_active": int(len(act)),
+    }
+
+
+def solve_qp(P, q, G=None, h=None, A=None, b=None, do_polish=True):
+    """Solve the QP; arguments are dense array-likes with cvxopt.solvers.qp's meaning."""
+    P = np.asarray(P, dtype=np.float64)
+    q = np.asarray(q, dtype=np.float64).reshape(-1)
+    n = P.shape[0]
+    G = np.zeros((0, n)) if G is None else np.asarray(G, dtype=np.float64)
+    h = np.zeros(0) if h is None else np.asarray(h, dtype=np.float64).reshape(-1)
+    G2, h2, A2, b2, info = presolve(G, h, A, b)
+    # equality rows may be rank-deficient only if the caller's A is; the reference's is not.
+    with np.errstate(all="ignore"):      # infeasible problems diverge; status reports it
+        x, s, y, z, iters = _ipm(P, q, G2, h2, A2, b2)
+    polished = False
+    if do_polish:
+        x, z, y2, polished = polish(P, q, G2, h2, A2, b2, x, z)
+        if polished:
+            y = y2
+    rx = P @ x + q + G2.T @ z + A2.T @ y
+    viol = max(0.0, float((G2 @ x - h2).max(initial=0.0)))
+    scale = max(1.0, np.abs(q).max(initial=0.0))
+    status = "optimal" if (np.abs(rx).max(initial=0.0) / scale < 1e-8 and viol < 1e-8) else "unknown"
+    return QPResult(x=x, z=z, y=y, status=status, iterations=iters, polished=polished,
+                    stationarity=float(np.abs(rx).max(initial=0.0) / scale),
+                    violation=viol, eq_violation=float(np.abs(A2 @ x - b2).max(initial=0.0)))

@@ -1,0 +1,113 @@
+"""Import the *actual reference* (read-only tree at /root/reference) in this container.
+
+Used only by ``make_golden.py`` (fixture generation) and by the optional live
+cross-check test that is skipped when /root/reference is absent (it never exists on the
+GPU box).  Nothing here is copied from the reference: we only register two stub modules
+so that its ``import carla`` / ``import cvxopt`` lines succeed:
+
+  * ``carla``   - the reference evaluates annotations such as ``loc_1: carla.Location``
+                   at def time (reference planner/planning_utils.py:14), so the stub
+                   carries dummy attributes of those names;
+  * ``cvxopt``  - ``solvers.qp`` RECORDS the dense (P, q, G, h, A, b) the reference built
+                   (pinning the QP *formulation*) and returns the KKT-certified solution
+                   of ``oracle.qp_dense`` (the QP *arithmetic* is unpinned: cvxopt is not
+                   vendored, not version-pinned and not installable here).
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REFERENCE_ROOT = "/root/reference"
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+#: every call of the stub ``cvxopt.solvers.qp`` appends a dict here
+QP_LOG: list = []
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "planner", "path_planning.py"))
+
+
+class _Matrix:
+    """Minimal stand-in for cvxopt.matrix: dense column-major semantics are not needed
+    because the reference only converts numpy arrays and indexes the 1-D solution."""
+
+    def __init__(self, a):
+        self.a = np.array(a, dtype=np.float64)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.a if dtype is None else self.a.astype(dtype)
+
+
+class _Solution:
+    """``res['x']`` in the reference is sliced ([0::3]), indexed ([i]) and len()-ed."""
+
+    def __init__(self, x):
+        self._x = [float(v) for v in np.asarray(x).reshape(-1)]
+
+    def __getitem__(self, k):
+        return self._x[k]
+
+    def __len__(self):
+        return len(self._x)
+
+    def __iter__(self):
+        return iter(self._x)
+
+
+def _install_stubs():
+    if REPO_ROOT not in sys.path:
+        sys.path.insert(0, REPO_ROOT)
+    from oracle import qp_dense
+
+    carla = types.ModuleType("carla")
+    for name in ("Location", "Waypoint", "Vehicle", "Map", "World", "Transform", "Rotation",
+                 "Vector3D", "VehicleControl", "Client", "Color", "Actor"):
+        setattr(carla, name, type(name, (), {}))
+
+    cvxopt = types.ModuleType("cvxopt")
+    solvers = types.ModuleType("cvxopt.solvers")
+    solvers.options = {}
+
+    def qp(P, q, G=None, h=None, A=None, b=None, **_kw):
+        arr = lambda m: None if m is None else np.asarray(m, dtype=np.float64)
+        rec = {"P": arr(P), "q": arr(q), "G": arr(G), "h": arr(h), "A": arr(A), "b": arr(b)}
+        res = qp_dense.solve_qp(rec["P"], rec["q"], rec["G"], rec["h"], rec["A"], rec["b"])
+        rec["x"] = res.x.copy()
+        rec["status"] = res.status
+        rec["stationarity"] = res.stationarity
+        rec["violation"] = res.violation
+        rec["polished"] = res.polished
+        QP_LOG.append(rec)
+        return {"x": _Solution(res.x), "status": res.status}
+
+    solvers.qp = qp
+    cvxopt.matrix = _Matrix
+    cvxopt.solvers = solvers
+    sys.modules["carla"] = carla
+    sys.modules["cvxopt"] = cvxopt
+    sys.modules["cvxopt.solvers"] = solvers
+
+
+def load_reference():
+    """Return (path_planning, planning_utils) modules of the reference."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+    sys.dont_write_bytecode = True  # the tree is read-only; never leave .pyc behind
+    _install_stubs()
+    # The reference's package is called ``planner``; keep it off sys.path except while importing
+    # so that it cannot shadow anything of ours.
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        for name in ("planner", "planner.planning_utils", "planner.path_planning"):
+            sys.modules.pop(name, None)
+        pu = importlib.import_module("planner.planning_utils")
+        pp = importlib.import_module("planner.path_planning")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+    return pp, pu
