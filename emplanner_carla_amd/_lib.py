@@ -1,0 +1,118 @@
+"""ctypes binding of include/emplanner.h (the C-ABI shared library built by build.py).
+
+There is NO fallback: if ``libemplanner.so`` is missing or cannot be loaded, importing a
+planner function raises ``RuntimeError``; if no gfx950 GPU is visible, creating a context
+raises ``EmpError``.  Nothing in this package computes planner results on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libemplanner.so")
+
+EMP_HOST, EMP_DEVICE = 0, 1
+EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1
+EMP_DP_FUSED, EMP_DP_TWO_KERNEL = 0, 1
+
+ST_DP_INFEASIBLE = 1
+ST_S_OUT_OF_RANGE = 2
+ST_BOUND_INDEX = 4
+ST_QP_FAILED = 8
+ST_SMOOTH_FAILED = 16
+ST_TRUNCATED = 32
+
+
+class EmpError(RuntimeError):
+    """A C-ABI call returned a negative emp_error."""
+
+
+class DpParams(C.Structure):
+    _fields_ = [("row", C.c_int32), ("col", C.c_int32), ("sample_s", C.c_double), ("sample_l", C.c_double),
+                ("sampling_res", C.c_double), ("w_collision", C.c_double), ("w_smooth", C.c_double * 3),
+                ("w_ref", C.c_double)]
+
+
+class QpParams(C.Structure):
+    _fields_ = [("ds", C.c_double), ("w_l", C.c_double), ("w_dl", C.c_double), ("w_ddl", C.c_double),
+                ("w_dddl", C.c_double), ("w_centre", C.c_double), ("w_end_l", C.c_double),
+                ("w_end_dl", C.c_double), ("w_end_ddl", C.c_double), ("host_d1", C.c_double),
+                ("host_d2", C.c_double), ("host_w", C.c_double), ("obs_length", C.c_double),
+                ("obs_width", C.c_double), ("decimate", C.c_int32), ("midpoint", C.c_int32),
+                ("use_qp", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SmoothParams(C.Structure):
+    _fields_ = [("w_smooth", C.c_double), ("w_length", C.c_double), ("w_ref", C.c_double),
+                ("x_thre", C.c_double), ("y_thre", C.c_double)]
+
+
+_vp, _i32, _f64, _u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
+
+
+class CycleIO(C.Structure):
+    _fields_ = [(n, _vp) for n in (
+        "ref_line", "n_ref", "origin_xy", "start_xy", "start_v", "start_a", "obs_xy", "n_obs",
+        "dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status")]
+
+
+# name -> (restype, argtypes); data pointers are void* so numpy arrays and raw device addresses both fit
+PROTOTYPES = {
+    "emp_abi_version": (C.c_int, []),
+    "emp_dp_params_default": (None, [C.POINTER(DpParams)]),
+    "emp_qp_params_default": (None, [C.POINTER(QpParams)]),
+    "emp_smooth_params_default": (None, [C.POINTER(SmoothParams)]),
+    "emp_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "emp_destroy": (None, [_vp]),
+    "emp_last_error": (C.c_char_p, [_vp]),
+    "emp_synchronize": (C.c_int, [_vp]),
+    "emp_stream": (_vp, [_vp]),
+    "emp_device_alloc": (C.c_int, [_vp, _u64, C.POINTER(_vp)]),
+    "emp_device_free": (C.c_int, [_vp, _vp]),
+    "emp_copy_to_device": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "emp_copy_to_host": (C.c_int, [_vp, _vp, _vp, _u64]),
+    "emp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
+    "emp_edge_tensor_elems": (_u64, [C.POINTER(DpParams), _i32, C.c_int]),
+    "emp_dp_edge_costs": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                    C.c_int]),
+    "emp_dp_plan": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _i32, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp,
+                              C.c_int]),
+    "emp_dp_sweep": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_dp_enrich": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_frenet_project": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 13 + [C.c_int]),
+    "emp_match_projection": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 6 + [C.c_int]),
+    "emp_find_match_points": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int]),
+    "emp_heading_kappa": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_lmin_lmax": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 6 + [_f64, _f64, _vp, _vp, _vp, C.c_int]),
+    "emp_path_qp": (C.c_int, [_vp, C.POINTER(QpParams), _i32, _i32] + [_vp] * 9 + [C.c_int]),
+    "emp_smooth_line": (C.c_int, [_vp, C.POINTER(SmoothParams), _i32, _i32] + [_vp] * 5 + [C.c_int]),
+    "emp_frenet_path_to_xy": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 10 + [C.c_int]),
+    "emp_plan_cycle": (C.c_int, [_vp, C.POINTER(DpParams), C.POINTER(QpParams), C.POINTER(SmoothParams), _i32, _i32,
+                                 _i32, _i32, C.c_int, C.POINTER(CycleIO), C.c_int]),
+    "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
+    "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m emplanner_carla_amd.build` "
+            "(hipcc, gfx950).  This package has no CPU implementation to fall back to.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.emp_abi_version() != 1:
+        raise RuntimeError("libemplanner.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,405 @@
+// emp_api.hip - C-ABI of the MI355X EM-Planner hot path (see include/emplanner.h).
+// One translation unit: kernels are header-only templates, this file owns launches and staging.
+#include "emp_context.h"
+#include "emp_dp_kernels.h"
+
+namespace emp {
+thread_local std::string g_create_error;
+
+static int make_dp_dev(emp_ctx* ctx, const emp_dp_params* p, int B, int max_obs, DpDev* d) {
+    EMP_REQUIRE(ctx, p != nullptr, "dp params are NULL");
+    EMP_REQUIRE(ctx, p->row >= 1 && p->row <= 32, "row must be in [1, 32]");
+    EMP_REQUIRE(ctx, p->col >= 1 && p->col <= 255 * 16, "col must be in [1, 4080]");
+    EMP_REQUIRE(ctx, B >= 0, "negative batch");
+    EMP_REQUIRE(ctx, max_obs >= 0 && max_obs <= 256, "max_obs must be in [0, 256]");
+    EMP_REQUIRE(ctx, p->sample_s > 0 && p->sample_l > 0 && p->sampling_res > 0, "sample_s, sample_l, sampling_res must be > 0");
+    d->row = p->row;
+    d->col = p->col;
+    d->S = 64 / p->row;
+    d->tiles = (B + d->S - 1) / d->S;
+    d->B = B;
+    d->max_obs = max_obs > 0 ? max_obs : 1;
+    d->sample_s = p->sample_s;
+    d->sample_l = p->sample_l;
+    d->res = p->sampling_res;
+    d->w_coll = p->w_collision;
+    d->w0 = p->w_smooth[0];
+    d->w1 = p->w_smooth[1];
+    d->w2 = p->w_smooth[2];
+    d->w_ref = p->w_ref;
+    return EMP_OK;
+}
+
+static size_t tiled_elems(const DpDev& d) { return (size_t)d.tiles * (size_t)(d.col - 1) * d.row * 64; }
+
+// ---- device-level stage launchers (all pointers are device memory; nothing synchronises) -----
+static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
+                       const double* start, double* start_cost, double* edge, bool tiled) {
+    if (d.B == 0) return EMP_OK;
+    const size_t lds = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples) * sizeof(double);
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
+    int ncol = d.col - 1;
+    int chunks = 1;
+    if (ncol > 0) {
+        chunks = (2048 + d.tiles - 1) / d.tiles;
+        if (chunks > ncol) chunks = ncol;
+        if (chunks < 1) chunks = 1;
+    }
+    const int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
+    chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
+    dim3 grid(d.tiles, chunks), block(256);
+    auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
+    if (lds > 48 * 1024)
+        EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer t(ctx, "dp_edge");
+    hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, obs_s, obs_l, n_obs, start, start_cost, edge,
+                       cols_per_chunk);
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, const double* edge,
+                        const int* n_obs, double* rows, double* min_cost, int* status) {
+    if (d.B == 0) return EMP_OK;
+    dim3 grid((d.tiles + 3) / 4), block(256);
+    const size_t lds = (size_t)4 * d.col * 64;
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the predecessor table in LDS");
+    KernelTimer t(ctx, "dp_sweep");
+#define EMP_SWEEP(R, PD)                                                                                   \
+    do {                                                                                                   \
+        if (lds > 48 * 1024)                                                                               \
+            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD>,                          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        hipLaunchKernelGGL((dp_sweep_kernel<R, PD>), grid, block, lds, ctx->stream, d, start_cost, edge,   \
+                           n_obs, rows, min_cost, status);                                                 \
+    } while (0)
+    switch (d.row) {
+        case 5: EMP_SWEEP(5, 4); break;
+        case 9: EMP_SWEEP(9, 4); break;
+        case 12: EMP_SWEEP(12, 3); break;
+        case 21: EMP_SWEEP(21, 2); break;
+        default: EMP_SWEEP(0, 1); break;
+    }
+#undef EMP_SWEEP
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const double* start, int max_pts,
+                         double* path_s, double* path_l, int* path_len, int* status, int or_status) {
+    if (d.B == 0) return EMP_OK;
+    KernelTimer t(ctx, "dp_enrich");
+    hipLaunchKernelGGL(dp_enrich_kernel, dim3((d.B + 63) / 64), dim3(64), 0, ctx->stream, d, rows, start, max_pts,
+                       path_s, path_l, path_len, status, or_status);
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+// DP_algorithm up to the backtrack.  `edge_scratch` may be NULL: taken from the named scratch.
+static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
+                       const double* start, emp_dp_mode mode, double* rows, double* min_cost, int* status) {
+    (void)mode;  // EMP_DP_FUSED currently shares the two-kernel path
+    if (d.B == 0) return EMP_OK;
+    const size_t need = (tiled_elems(d) + (size_t)d.B * d.row) * sizeof(double);
+    emp_ctx::Buf& sc = ctx->named["dp_edge_tensor"];
+    if (sc.bytes < need) {
+        if (sc.p) EMP_HIP(ctx, hipFree(sc.p));
+        sc.p = nullptr;
+        sc.bytes = 0;
+        EMP_HIP(ctx, hipMalloc(&sc.p, need));
+        sc.bytes = need;
+    }
+    double* edge = (double*)sc.p;
+    double* start_cost = edge + tiled_elems(d);
+    int rc = dev_dp_edge(ctx, d, obs_s, obs_l, n_obs, start, start_cost, edge, true);
+    if (rc) return rc;
+    return dev_dp_sweep(ctx, d, start_cost, edge, n_obs, rows, min_cost, status);
+}
+
+}  // namespace emp
+
+using namespace emp;
+
+extern "C" {
+
+int emp_abi_version(void) { return EMP_ABI_VERSION; }
+
+void emp_dp_params_default(emp_dp_params* p) {
+    // ref: path_planning.py:276-279
+    p->row = 12;
+    p->col = 6;
+    p->sample_s = 15.0;
+    p->sample_l = 1.5;
+    p->sampling_res = 2.0;
+    p->w_collision = 1e12;
+    p->w_smooth[0] = 300.0;
+    p->w_smooth[1] = 1000.0;
+    p->w_smooth[2] = 5000.0;
+    p->w_ref = 20.0;
+}
+
+void emp_qp_params_default(emp_qp_params* q) {
+    // ref: path_planning.py:78-81, test_9.py:187-192
+    q->ds = 2.0;
+    q->w_l = 1000.0;
+    q->w_dl = 10000.0;
+    q->w_ddl = 3000.0;
+    q->w_dddl = 150.0;
+    q->w_centre = 250.0;
+    q->w_end_l = q->w_end_dl = q->w_end_ddl = 40.0;
+    q->host_d1 = q->host_d2 = q->host_w = 3.0;
+    q->obs_length = q->obs_width = 5.0;
+    q->decimate = 2;
+    q->midpoint = 1;
+    q->use_qp = 1;
+    q->reserved = 0;
+}
+
+void emp_smooth_params_default(emp_smooth_params* s) {
+    // ref: planning_utils.py:262-264
+    s->w_smooth = 0.4;
+    s->w_length = 0.3;
+    s->w_ref = 0.3;
+    s->x_thre = 0.2;
+    s->y_thre = 0.2;
+}
+
+int emp_create(int device_id, emp_ctx** out) {
+    if (!out) return fail(nullptr, EMP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, EMP_ERR_NO_DEVICE,
+                    std::string("no HIP device visible: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, EMP_ERR_INVALID, "device_id out of range");
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, EMP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, EMP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, EMP_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    emp_ctx* c = new emp_ctx();
+    c->device = device_id;
+    c->cu_count = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, EMP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return EMP_OK;
+}
+
+void emp_destroy(emp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->pool)
+        if (b.p) (void)hipFree(b.p);
+    for (auto& kv : ctx->named)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->events) {
+        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+        if (kv.second.b) (void)hipEventDestroy(kv.second.b);
+    }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* emp_last_error(const emp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int emp_synchronize(emp_ctx* ctx) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return EMP_OK;
+}
+
+void* emp_stream(emp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
+    EMP_REQUIRE(ctx, ctx && out, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    EMP_HIP(ctx, hipMalloc(out, bytes ? bytes : 8));
+    return EMP_OK;
+}
+int emp_device_free(emp_ctx* ctx, void* ptr) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EMP_HIP(ctx, hipFree(ptr));
+    return EMP_OK;
+}
+int emp_copy_to_device(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return EMP_OK;
+}
+int emp_copy_to_host(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return EMP_OK;
+}
+
+int emp_set_timing(emp_ctx* ctx, int enabled) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    if (!ctx->timing)
+        for (auto& kv : ctx->events) kv.second.valid = false;
+    return EMP_OK;
+}
+
+double emp_kernel_ms(emp_ctx* ctx, const char* kernel) {
+    if (!ctx || !kernel) return -1.0;
+    auto it = ctx->events.find(kernel);
+    if (it == ctx->events.end() || !it->second.valid) return -1.0;
+    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+// ---- DP ----------------------------------------------------------------------------------
+uint64_t emp_edge_tensor_elems(const emp_dp_params* p, int32_t B, emp_edge_layout layout) {
+    if (!p || p->row < 1 || p->row > 64 || p->col < 1 || B < 0) return 0;
+    if (layout == EMP_EDGE_CANONICAL) return (uint64_t)B * (p->col - 1) * p->row * p->row;
+    const int S = 64 / p->row;
+    const uint64_t tiles = ((uint64_t)B + S - 1) / S;
+    return tiles * (uint64_t)(p->col - 1) * p->row * 64;
+}
+
+int emp_dp_edge_costs(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t max_obs, const double* obs_s,
+                      const double* obs_l, const int32_t* n_obs, const double* start, double* start_cost,
+                      double* edge, emp_edge_layout layout, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    DpDev d;
+    int rc = make_dp_dev(ctx, p, B, max_obs, &d);
+    if (rc) return rc;
+    EMP_REQUIRE(ctx, n_obs && start && edge, "n_obs, start and edge are required");
+    EMP_REQUIRE(ctx, max_obs == 0 || (obs_s && obs_l), "obs_s / obs_l are required when max_obs > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    const double *d_os, *d_ol, *d_start;
+    const int* d_n;
+    double *d_c0, *d_e;
+    if ((rc = st.in(obs_s, (size_t)B * max_obs, &d_os))) return rc;
+    if ((rc = st.in(obs_l, (size_t)B * max_obs, &d_ol))) return rc;
+    if ((rc = st.in(n_obs, (size_t)B, &d_n))) return rc;
+    if ((rc = st.in(start, (size_t)B * 4, &d_start))) return rc;
+    if ((rc = st.out(start_cost, (size_t)B * d.row, &d_c0))) return rc;
+    if ((rc = st.out(edge, (size_t)emp_edge_tensor_elems(p, B, layout), &d_e, layout == EMP_EDGE_TILED))) return rc;
+    if (max_obs == 0) {  // kernels index [b * max_obs + m] only for m < n_obs == 0
+        double* dummy;
+        if ((rc = st.tmp(1, &dummy))) return rc;
+        d_os = d_ol = dummy;
+    }
+    if ((rc = dev_dp_edge(ctx, d, d_os, d_ol, d_n, d_start, d_c0, d_e, layout == EMP_EDGE_TILED))) return rc;
+    return st.finish();
+}
+
+int emp_dp_sweep(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double* start_cost, const double* edge,
+                 double* rows, double* min_cost, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    DpDev d;
+    int rc = make_dp_dev(ctx, p, B, 0, &d);
+    if (rc) return rc;
+    EMP_REQUIRE(ctx, start_cost && edge && rows && status, "start_cost, edge, rows and status are required");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    const double *d_c0, *d_e;
+    double *d_rows, *d_min;
+    int* d_st;
+    if ((rc = st.in(start_cost, (size_t)B * d.row, &d_c0))) return rc;
+    if ((rc = st.in(edge, tiled_elems(d), &d_e))) return rc;
+    if ((rc = st.out(rows, (size_t)B * d.col, &d_rows))) return rc;
+    if ((rc = st.out(min_cost, (size_t)B, &d_min))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if ((rc = dev_dp_sweep(ctx, d, d_c0, d_e, nullptr, d_rows, d_min, d_st))) return rc;
+    return st.finish();
+}
+
+int emp_dp_plan(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t max_obs, const double* obs_s,
+                const double* obs_l, const int32_t* n_obs, const double* start, emp_dp_mode mode, double* rows,
+                double* min_cost, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    DpDev d;
+    int rc = make_dp_dev(ctx, p, B, max_obs, &d);
+    if (rc) return rc;
+    EMP_REQUIRE(ctx, n_obs && start && rows && status, "n_obs, start, rows and status are required");
+    EMP_REQUIRE(ctx, max_obs == 0 || (obs_s && obs_l), "obs_s / obs_l are required when max_obs > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    const double *d_os, *d_ol, *d_start;
+    const int* d_n;
+    double *d_rows, *d_min;
+    int* d_st;
+    if ((rc = st.in(obs_s, (size_t)B * max_obs, &d_os))) return rc;
+    if ((rc = st.in(obs_l, (size_t)B * max_obs, &d_ol))) return rc;
+    if ((rc = st.in(n_obs, (size_t)B, &d_n))) return rc;
+    if ((rc = st.in(start, (size_t)B * 4, &d_start))) return rc;
+    if ((rc = st.out(rows, (size_t)B * d.col, &d_rows))) return rc;
+    if ((rc = st.out(min_cost, (size_t)B, &d_min))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (max_obs == 0) {
+        double* dummy;
+        if ((rc = st.tmp(1, &dummy))) return rc;
+        d_os = d_ol = dummy;
+    }
+    if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_n, d_start, mode, d_rows, d_min, d_st))) return rc;
+    return st.finish();
+}
+
+int emp_dp_enrich(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double* rows, const double* start,
+                  int32_t max_pts, double* path_s, double* path_l, int32_t* path_len, int32_t* status,
+                  emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    DpDev d;
+    int rc = make_dp_dev(ctx, p, B, 0, &d);
+    if (rc) return rc;
+    EMP_REQUIRE(ctx, rows && start && path_s && path_l && path_len && status, "NULL argument");
+    EMP_REQUIRE(ctx, max_pts >= 1, "max_pts must be >= 1");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    const double *d_rows, *d_start;
+    double *d_ps, *d_pl;
+    int *d_len, *d_st;
+    if ((rc = st.in(rows, (size_t)B * d.col, &d_rows))) return rc;
+    if ((rc = st.in(start, (size_t)B * 4, &d_start))) return rc;
+    if ((rc = st.out(path_s, (size_t)B * max_pts, &d_ps))) return rc;
+    if ((rc = st.out(path_l, (size_t)B * max_pts, &d_pl))) return rc;
+    if ((rc = st.out(path_len, (size_t)B, &d_len))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_ps, d_pl, d_len, d_st, 0))) return rc;
+    return st.finish();
+}
+
+}  // extern "C"
+
+// ---- entry points still to be filled in (kept so that the exported symbol set matches the header) ----
+#define EMP_TODO(ctx) return emp::fail((ctx), EMP_ERR_INVALID, std::string(__func__) + ": not implemented yet")
+extern "C" {
+int emp_frenet_project(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
+                       const double*, const double*, const double*, const double*, const int32_t*, double*, double*,
+                       double*, double*, double*, emp_mem) { EMP_TODO(ctx); }
+int emp_match_projection(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
+                         const int32_t*, int32_t*, double*, emp_mem) { EMP_TODO(ctx); }
+int emp_find_match_points(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
+                          const int32_t*, const int32_t*, const int32_t*, int32_t*, double*, emp_mem) { EMP_TODO(ctx); }
+int emp_heading_kappa(emp_ctx* ctx, int32_t, int32_t, const double*, const int32_t*, double*, double*, emp_mem) { EMP_TODO(ctx); }
+int emp_lmin_lmax(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const double*, const int32_t*, const double*,
+                  const double*, const int32_t*, double, double, double*, double*, int32_t*, emp_mem) { EMP_TODO(ctx); }
+int emp_path_qp(emp_ctx* ctx, const emp_qp_params*, int32_t, int32_t, const double*, const double*, const int32_t*,
+                const double*, double*, double*, double*, int32_t*, int32_t*, emp_mem) { EMP_TODO(ctx); }
+int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params*, int32_t, int32_t, const double*, const int32_t*, double*,
+                    int32_t*, int32_t*, emp_mem) { EMP_TODO(ctx); }
+int emp_frenet_path_to_xy(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const double*, const int32_t*,
+                          const double*, const double*, const double*, const int32_t*, double*, int32_t*, int32_t*,
+                          emp_mem) { EMP_TODO(ctx); }
+int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params*, const emp_qp_params*, const emp_smooth_params*, int32_t, int32_t,
+                   int32_t, int32_t, emp_dp_mode, const emp_cycle_io*, emp_mem) { EMP_TODO(ctx); }
+int emp_quintic_coefficients(emp_ctx* ctx, int32_t, const double*, double*, emp_mem) { EMP_TODO(ctx); }
+int emp_obs_cost(emp_ctx* ctx, int32_t, double, double, double, const double*, double*, emp_mem) { EMP_TODO(ctx); }
+}

@@ -1,0 +1,168 @@
+// emp_context.h - context object behind the C-ABI: device, stream, scratch pool, host staging, timing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/emplanner.h"
+
+struct emp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only pool of device buffers, handed out in call order and recycled by the next call
+    struct Buf {
+        void* p = nullptr;
+        size_t bytes = 0;
+    };
+    std::vector<Buf> pool;
+    size_t cursor = 0;
+    // persistent named scratch (survives across the staged buffers of one call)
+    std::map<std::string, Buf> named;
+    // per-kernel timing
+    bool timing = false;
+    struct Ev {
+        hipEvent_t a = nullptr, b = nullptr;
+        bool valid = false;
+    };
+    std::map<std::string, Ev> events;
+    int cu_count = 0;
+};
+
+namespace emp {
+
+extern thread_local std::string g_create_error;
+
+inline int fail(emp_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define EMP_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return emp::fail((ctx), EMP_ERR_HIP,                                                   \
+                             std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+#define EMP_REQUIRE(ctx, cond, msg)                                                               \
+    do {                                                                                           \
+        if (!(cond)) return emp::fail((ctx), EMP_ERR_INVALID, std::string(msg));                   \
+    } while (0)
+
+// device scratch from the per-call pool
+inline int pool_get(emp_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 8;
+    if (ctx->cursor == ctx->pool.size()) ctx->pool.push_back({});
+    emp_ctx::Buf& b = ctx->pool[ctx->cursor++];
+    if (b.bytes < bytes) {
+        if (b.p) EMP_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+        size_t want = bytes + bytes / 4;
+        EMP_HIP(ctx, hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return EMP_OK;
+}
+
+// Staging of one call's arguments.  For EMP_DEVICE pointers pass through; for EMP_HOST inputs are copied
+// to pool buffers and outputs are copied back in finish().
+class Stage {
+  public:
+    Stage(emp_ctx* c, emp_mem where) : ctx_(c), dev_(where == EMP_DEVICE) { c->cursor = 0; }
+
+    template <typename T>
+    int in(const T* host, size_t n, const T** out) {
+        if (host == nullptr) { *out = nullptr; return EMP_OK; }
+        if (dev_) { *out = host; return EMP_OK; }
+        void* d = nullptr;
+        int rc = pool_get(ctx_, n * sizeof(T), &d);
+        if (rc) return rc;
+        if (n) EMP_HIP(ctx_, hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream));
+        *out = (const T*)d;
+        return EMP_OK;
+    }
+    template <typename T>
+    int out(T* host, size_t n, T** outp, bool zero = false) {
+        if (host == nullptr) { *outp = nullptr; return EMP_OK; }
+        T* d = host;
+        if (!dev_) {
+            void* v = nullptr;
+            int rc = pool_get(ctx_, n * sizeof(T), &v);
+            if (rc) return rc;
+            d = (T*)v;
+            backs_.push_back({host, d, n * sizeof(T)});
+        }
+        if (zero && n) EMP_HIP(ctx_, hipMemsetAsync(d, 0, n * sizeof(T), ctx_->stream));
+        *outp = d;
+        return EMP_OK;
+    }
+    // device-only temporary
+    template <typename T>
+    int tmp(size_t n, T** outp, bool zero = false) {
+        void* v = nullptr;
+        int rc = pool_get(ctx_, n * sizeof(T), &v);
+        if (rc) return rc;
+        if (zero && n) EMP_HIP(ctx_, hipMemsetAsync(v, 0, n * sizeof(T), ctx_->stream));
+        *outp = (T*)v;
+        return EMP_OK;
+    }
+    int finish() {
+        for (auto& b : backs_)
+            if (b.bytes) EMP_HIP(ctx_, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx_->stream));
+        if (!dev_) EMP_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        return EMP_OK;
+    }
+    bool on_device() const { return dev_; }
+
+  private:
+    struct Back {
+        void* host;
+        void* dev;
+        size_t bytes;
+    };
+    emp_ctx* ctx_;
+    bool dev_;
+    std::vector<Back> backs_;
+};
+
+// RAII-ish kernel timer: records events around a launch when ctx->timing is on
+struct KernelTimer {
+    emp_ctx* ctx;
+    emp_ctx::Ev* ev = nullptr;
+    KernelTimer(emp_ctx* c, const char* name) : ctx(c) {
+        if (!c->timing) return;
+        emp_ctx::Ev& e = c->events[name];
+        if (!e.a) {
+            (void)hipEventCreate(&e.a);
+            (void)hipEventCreate(&e.b);
+        }
+        ev = &e;
+        (void)hipEventRecord(e.a, c->stream);
+    }
+    ~KernelTimer() {
+        if (ev) {
+            (void)hipEventRecord(ev->b, ctx->stream);
+            ev->valid = true;
+        }
+    }
+};
+
+#define EMP_LAUNCH_CHECK(ctx)                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess)                                                                      \
+            return emp::fail((ctx), EMP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace emp

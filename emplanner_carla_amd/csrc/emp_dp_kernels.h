@@ -1,0 +1,337 @@
+// emp_dp_kernels.h - HIP kernels of the S-L lattice DP for gfx950 (wave64).
+//
+// Scene tiling.  A lattice column has `row` nodes; S = 64 / row scenes are packed side by side
+// in one wavefront (lane = s * row + i, i = destination row), so every lane of the min-plus sweep
+// does useful work and every load of the edge tensor is one fully coalesced 512-byte row:
+//
+//     edge_tiled[tile][j-1][k][lane]      tile = scene / S, lane = (scene % S) * row + i,  64 lanes
+//
+// (k = source row in column j-1, j = 1..col-1).  Lanes >= S*row are padding.
+//
+// Kernels
+//   dp_edge_kernel     edge costs (ref: cal_start_cost / cal_neighbor_cost, path_planning.py:435-585),
+//                      FP64 VALU bound; writes the tiled (or canonical) tensor, 8 B per lane coalesced.
+//   dp_sweep_kernel    min-plus sweep + argmin + backtrack (ref: path_planning.py:301-361), HBM bound:
+//                      streams the tiled tensor once with a register double buffer of PD columns.
+//   dp_enrich_kernel   row indices -> densified (s, l) path (ref: path_planning.py:364-432).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "emp_core.h"
+
+namespace emp {
+
+struct DpDev {
+    int row, col;
+    int S;       // scenes per wavefront tile = 64 / row
+    int tiles;   // ceil(B / S)
+    int B;
+    int max_obs;
+    double sample_s, sample_l, res;
+    double w_coll, w0, w1, w2, w_ref;
+};
+
+constexpr int kTableFields = kSamples + 7;  // l samples, a3, a4, a5, base smooth, ref cost, l_lo, l_hi
+
+// ---------------------------------------------------------------------------------------------
+// edge costs
+// ---------------------------------------------------------------------------------------------
+// grid = (tiles, column chunks), block = 256.  Dynamic LDS: pair table [kTableFields][row*row] doubles
+// followed by the tile's obstacles [S][max_obs] x2 doubles.
+template <bool TILED>
+__global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __restrict__ obs_s,
+                                                      const double* __restrict__ obs_l,
+                                                      const int* __restrict__ n_obs,
+                                                      const double* __restrict__ start,
+                                                      double* __restrict__ start_cost,
+                                                      double* __restrict__ edge, int cols_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int row = P.row, rr = P.row * P.row;
+    double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
+    double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
+    double* t_obs_l = t_obs_s + P.S * P.max_obs;
+    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples] sample offsets t_n (one division each)
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    // ---- per-pair table: everything of a neighbour edge that does not depend on scene or column.
+    // (dl0 = ddl0 = 0, T = sample_s; the lateral samples, sum l^2, sum dl^2, sum ddl^2 are shared by all
+    // columns and scenes; only the quirked jerk term and the obstacles see the absolute s.)
+    for (int p = tid; p < rr; p += blockDim.x) {
+        const int k = p / row, i = p - k * row;
+        const double l_pre = lattice_l(row, k, P.sample_l);
+        const double l_cur = lattice_l(row, i, P.sample_l);
+        const Quintic q = quintic_shifted(l_pre, 0.0, 0.0, l_cur, P.sample_s);
+        double S_l = 0.0, S_dl = 0.0, S_ddl = 0.0;
+        for (int n = 0; n < kSamples; ++n) {
+            const double t = sample_t(n, P.sample_s);
+            const double l = quintic_l(q, t);
+            const double dl = quintic_dl(q, t);
+            const double ddl = quintic_ddl(q, t);
+            tab[n * rr + p] = l;
+            S_l = S_l + l * l;
+            S_dl = S_dl + dl * dl;
+            S_ddl = S_ddl + ddl * ddl;
+        }
+        tab[(kSamples + 0) * rr + p] = q.a3;
+        tab[(kSamples + 1) * rr + p] = q.a4;
+        tab[(kSamples + 2) * rr + p] = q.a5;
+        tab[(kSamples + 3) * rr + p] = P.w0 * S_dl + P.w1 * S_ddl;
+        tab[(kSamples + 4) * rr + p] = P.w_ref * S_l;
+        tab[(kSamples + 5) * rr + p] = fmin(l_pre, l_cur);
+        tab[(kSamples + 6) * rr + p] = fmax(l_pre, l_cur);
+    }
+    if (tid < kSamples) t_smp[tid] = sample_t(tid, P.sample_s);
+    for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
+        const int s = x / P.max_obs, m = x - s * P.max_obs;
+        const int b = tile * P.S + s;
+        t_obs_s[x] = (b < P.B) ? obs_s[(size_t)b * P.max_obs + m] : 0.0;
+        t_obs_l[x] = (b < P.B) ? obs_l[(size_t)b * P.max_obs + m] : 0.0;
+    }
+    __syncthreads();
+
+    const int lanes_used = P.S * row;
+    const double t_last = t_smp[kSamples - 1];
+
+    // ---- start edges (column 0): generic form, one thread per (scene, row); only chunk 0 does them
+    if (blockIdx.y == 0 && start_cost != nullptr && tid < lanes_used) {
+        const int s = tid / row, i = tid - s * row;
+        const int b = tile * P.S + s;
+        if (b < P.B) {
+            const double ps = start[b * 4 + 0], pl = start[b * 4 + 1], pdl = start[b * 4 + 2],
+                         pddl = start[b * 4 + 3];
+            const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, i, P.sample_l), P.sample_s);
+            start_cost[(size_t)b * row + i] =
+                segment_cost(q, ps, P.sample_s, t_obs_s + s * P.max_obs, t_obs_l + s * P.max_obs, n_obs[b],
+                             P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+        }
+    }
+
+    // ---- neighbour edges of this block's column chunk.  A thread keeps its lane (scene, row i) and walks
+    // over (column, source row k) items; consecutive lanes store consecutive doubles of the tiled tensor.
+    const int j_begin = 1 + blockIdx.y * cols_per_chunk;
+    const int j_end = min(P.col, j_begin + cols_per_chunk);
+    const int n_jk = (j_end - j_begin) * row;
+    const int lane = tid & 63;
+    const int s = lane / row, i = lane - s * row;
+    const int b = tile * P.S + s;
+    if (lane >= lanes_used || b >= P.B) return;
+    const double ps = start[b * 4 + 0];
+    const int nob = n_obs[b];
+    for (int jk = tid >> 6; jk < n_jk; jk += (int)(blockDim.x >> 6)) {
+        const int jj = jk / row, k = jk - jj * row;
+        const int j = j_begin + jj;
+        const int p = k * row + i;
+        const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
+        Quintic q;
+        q.a3 = tab[(kSamples + 0) * rr + p];
+        q.a4 = tab[(kSamples + 1) * rr + p];
+        q.a5 = tab[(kSamples + 2) * rr + p];
+        const JerkQuirk jq = jerk_quirk(q, s0);
+        double S_d3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < kSamples; ++n) {
+            const double d3 = jerk_quirk_at(jq, s0 + t_smp[n]);
+            S_d3 = S_d3 + d3 * d3;
+        }
+        const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
+        const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
+        double coll = 0.0;
+        for (int m = 0; m < nob; ++m) {
+            const double os = t_obs_s[s * P.max_obs + m], ol = t_obs_l[s * P.max_obs + m];
+            if (!obstacle_in_reach(os, ol, s0, s0 + t_last, l_lo, l_hi)) continue;   // contributes exactly 0
+            double c = 0.0;
+            for (int n = 0; n < kSamples; ++n) {
+                const double sn = s0 + t_smp[n];
+                const double d_lon = os - sn;
+                const double d_lat = ol - tab[n * rr + p];
+                const double d2 = d_lon * d_lon + d_lat * d_lat;
+                if (d2 <= kDanger2) {
+                    c = c + P.w_coll;
+                    break;
+                } else if (d2 < kSafe2) {
+                    c = c + kSoftGain / d2;
+                }
+            }
+            coll = coll + c;
+        }
+        const double cost = (smooth + coll) + tab[(kSamples + 4) * rr + p];
+        if (TILED) {
+            edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
+        } else {
+            edge[(size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + i * row + k] = cost;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// min-plus sweep + backtrack
+// ---------------------------------------------------------------------------------------------
+// One wavefront per tile of S scenes; block = 4 wavefronts.  LDS: predecessor bytes [wave][col][64].
+// ROW > 0: compile-time row count, register double buffer of PD columns (loads for the next group are
+// in flight while the current group is reduced).  ROW == 0: generic fallback with a runtime row count.
+template <int ROW, int PD>
+__global__ __launch_bounds__(256) void dp_sweep_kernel(DpDev P, const double* __restrict__ start_cost,
+                                                       const double* __restrict__ edge,
+                                                       const int* __restrict__ n_obs,
+                                                       double* __restrict__ rows_out,
+                                                       double* __restrict__ min_cost_out,
+                                                       int* __restrict__ status_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];
+    const int row = ROW > 0 ? ROW : P.row;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= P.tiles) return;                         // whole wavefront exits together
+    unsigned char* pre = pre_lds + (size_t)wave * P.col * 64;
+    const int s = lane / row, i = lane - s * row;
+    const int b = tile * P.S + s;
+    const bool live = (lane < P.S * row) && (b < P.B);
+    const int base = s * row;
+    const bool left = i < (row >> 1);                    // ref :317 / :341 lane penalty rows
+    const double INF = __builtin_inf();
+
+    double cost = INF;
+    if (live) {
+        cost = start_cost[(size_t)b * row + i];
+        if (left) cost = cost + kLanePenalty;            // ref :318
+    }
+    const double* tile_edge = edge + (size_t)tile * (P.col - 1) * row * 64 + lane;
+
+    auto relax_one = [&](double e, int k, double& best, int& arg) {
+        const double ck = __shfl(cost, base + k, 64);
+        double cand = ck + e;                             // ref :340
+        if (left) cand = cand + kLanePenalty;             // ref :342
+        if (cand < best) {                                // strict, k ascending: lowest k wins ties (:344)
+            best = cand;
+            arg = k;
+        }
+    };
+
+    if constexpr (ROW > 0) {
+        double bufA[PD][ROW], bufB[PD][ROW];
+        auto load_group = [&](double (&buf)[PD][ROW], int j0) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int j = j0 + d;
+#pragma unroll
+                for (int k = 0; k < ROW; ++k)
+                    buf[d][k] = (j < P.col) ? tile_edge[((size_t)(j - 1) * ROW + k) * 64] : 0.0;
+            }
+        };
+        auto relax_group = [&](double (&buf)[PD][ROW], int j0) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                if (j0 + d < P.col) {
+                    double best = INF;
+                    int arg = 1;                          // ref :304 pre_node_index initialised to ones
+#pragma unroll
+                    for (int k = 0; k < ROW; ++k) relax_one(buf[d][k], k, best, arg);
+                    cost = best;
+                    pre[(j0 + d) * 64 + lane] = (unsigned char)arg;
+                }
+            }
+        };
+        load_group(bufA, 1);
+        for (int j0 = 1; j0 < P.col; j0 += 2 * PD) {
+            load_group(bufB, j0 + PD);
+            relax_group(bufA, j0);
+            load_group(bufA, j0 + 2 * PD);
+            relax_group(bufB, j0 + PD);
+        }
+    } else {
+        for (int j = 1; j < P.col; ++j) {
+            double best = INF;
+            int arg = 1;
+            for (int k = 0; k < row; ++k) relax_one(tile_edge[((size_t)(j - 1) * row + k) * 64], k, best, arg);
+            cost = best;
+            pre[j * 64 + lane] = (unsigned char)arg;
+        }
+    }
+
+    // ---- terminal argmin (first minimum, ref :349) - every lane of a scene computes the same answer
+    double best = INF;
+    int arg = 0;
+    bool first = true;
+    for (int k = 0; k < row; ++k) {
+        const double ck = __shfl(cost, base + k, 64);
+        if (first || ck < best) {
+            best = ck;
+            arg = k;
+            first = false;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                      // pre[] bytes of all lanes are written
+    if (live && i == 0) {
+        const bool bypass = (n_obs != nullptr) && (n_obs[b] == 0);
+        double* out = rows_out + (size_t)b * P.col;
+        if (bypass) {                                     // ref :362-363 no obstacles: centre row, DP skipped
+            const double centre = (double)(row + 1) / 2.0 - 1.0;
+            for (int j = 0; j < P.col; ++j) out[j] = centre;
+            if (min_cost_out) min_cost_out[b] = INF;
+            status_out[b] = 0;
+        } else {
+            int idx = arg;
+            out[P.col - 1] = (double)idx;
+            for (int j = P.col - 1; j >= 1; --j) {        // ref :355-359
+                idx = pre[j * 64 + base + idx];
+                out[j - 1] = (double)idx;
+            }
+            if (min_cost_out) min_cost_out[b] = best;
+            status_out[b] = (best > P.w_coll) ? 1 : 0;    // ref :351 (EMP_ST_DP_INFEASIBLE)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// densification (ref: path_planning.py:364-432)
+// ---------------------------------------------------------------------------------------------
+__global__ void dp_enrich_kernel(DpDev P, const double* __restrict__ rows, const double* __restrict__ start,
+                                 int max_pts, double* __restrict__ path_s, double* __restrict__ path_l,
+                                 int* __restrict__ path_len, int* __restrict__ status, int or_status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const double ps = start[b * 4 + 0];
+    double s0 = ps, l0 = start[b * 4 + 1], dl0 = start[b * 4 + 2], ddl0 = start[b * 4 + 3];
+    double* os = path_s + (size_t)b * max_pts;
+    double* ol = path_l + (size_t)b * max_pts;
+    int n = 0;
+    bool trunc = false;
+    double end_s = ps, end_l = l0;
+    for (int c = 0; c < P.col; ++c) {
+        end_s = ps + (double)(c + 1) * P.sample_s;                       // ref :369
+        end_l = lattice_l_f(P.row, rows[(size_t)b * P.col + c], P.sample_l);   // ref :370
+        const double span = end_s - s0;
+        const int cnt = arange_count(span, P.res);                       // ref :405 / :423
+        const Quintic q = quintic_shifted(l0, dl0, ddl0, end_l, span);
+        for (int k = 0; k < cnt; ++k) {
+            const double t = (double)k * P.res;
+            if (n < max_pts) {
+                os[n] = s0 + t;
+                ol[n] = quintic_l(q, t);
+                ++n;
+            } else {
+                trunc = true;
+            }
+        }
+        s0 = end_s;
+        l0 = end_l;
+        dl0 = 0.0;
+        ddl0 = 0.0;
+    }
+    if (n < max_pts) {                                                   // ref :429-430
+        os[n] = end_s;
+        ol[n] = end_l;
+        ++n;
+    } else {
+        trunc = true;
+    }
+    path_len[b] = n;
+    if (or_status) {
+        if (trunc) status[b] |= 32;                                      // EMP_ST_TRUNCATED
+    } else {
+        status[b] = trunc ? 32 : 0;
+    }
+}
+
+}  // namespace emp

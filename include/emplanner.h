@@ -1,0 +1,247 @@
+/*
+ * emplanner.h - C-ABI of the MI355X-native EM-Planner path-planning hot path.
+ *
+ * The reference (6Lackiu/EMplanner_Carla) is pure Python: its "plugin interface" for this
+ * path is the module-level function surface of planner/path_planning.py and
+ * planner/planning_utils.py.  Each entry point below is the batched, device-resident form of
+ * one (or a chain) of those functions; the Python package `emplanner_carla_amd.planner` binds
+ * them with ctypes and re-exposes the reference's names and signatures.
+ * "ref:" comments cite the reference function an entry point replaces (paths relative to the
+ * reference tree).
+ *
+ * Conventions
+ *   - plain C, POD only; all floating point is IEEE-754 binary64, all indices int32.
+ *   - every array is batch-major and padded: [B][max_x]... with a per-scene length array.
+ *   - `where` tells whether the DATA pointers of the call are host (EMP_HOST: the library
+ *     stages them through its own device buffers) or device (EMP_DEVICE: used in place; e.g.
+ *     torch tensors' data_ptr()).  Parameter structs are always host memory.
+ *   - functions return EMP_OK or a negative emp_error; emp_last_error() gives the text.
+ *     Per-scene problems never fail a call: they are reported in `status[b]` (bit mask).
+ *   - a context owns one device, one HIP stream and its scratch buffers; calls on one
+ *     context are serialised by the caller.  HIP is initialised lazily in emp_create(), so a
+ *     forked planning process (ref: test_9.py:225-227 runs the planner in a child process)
+ *     must create its context after the fork.
+ */
+#ifndef EMPLANNER_H
+#define EMPLANNER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMP_ABI_VERSION 1
+
+typedef struct emp_ctx emp_ctx;
+
+typedef enum emp_error {
+    EMP_OK = 0,
+    EMP_ERR_INVALID = -1,   /* bad argument (null pointer, size out of supported range) */
+    EMP_ERR_HIP = -2,       /* a HIP runtime call failed; see emp_last_error */
+    EMP_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
+    EMP_ERR_NOMEM = -4
+} emp_error;
+
+typedef enum emp_mem { EMP_HOST = 0, EMP_DEVICE = 1 } emp_mem;
+
+/* per-scene status bits */
+enum {
+    EMP_ST_DP_INFEASIBLE = 1,  /* min terminal cost > w_collision: ref prints its banner, path_planning.py:351 */
+    EMP_ST_S_OUT_OF_RANGE = 2, /* cal_proj_point walked past the s_map: ref raises IndexError, path_planning.py:63 */
+    EMP_ST_BOUND_INDEX = 4,    /* cal_lmin_lmax index >= n: ref raises IndexError, path_planning.py:267/272 */
+    EMP_ST_QP_FAILED = 8,      /* path QP infeasible / not converged (ref ignores cvxopt's status, :211-218) */
+    EMP_ST_SMOOTH_FAILED = 16, /* smoothing QP not converged */
+    EMP_ST_TRUNCATED = 32      /* an output did not fit the caller's max_* capacity */
+};
+
+/* ref: keyword arguments of DP_algorithm, path_planning.py:276-279 (defaults in emp_dp_params_default) */
+typedef struct emp_dp_params {
+    int32_t row;            /* lateral samples  (ref default 12) */
+    int32_t col;            /* longitudinal stations (ref default 6) */
+    double sample_s;        /* 15  */
+    double sample_l;        /* 1.5 */
+    double sampling_res;    /* 2: densification step of enrich_DP_s_l */
+    double w_collision;     /* 1e12 */
+    double w_smooth[3];     /* 300, 1000, 5000 */
+    double w_ref;           /* 20 */
+} emp_dp_params;
+
+/* ref: keyword arguments of Quadratic_planning, path_planning.py:78-81, and of cal_lmin_lmax :222 */
+typedef struct emp_qp_params {
+    double ds;              /* dp_sampling_res = 2 (the QP's fixed station spacing, :108) */
+    double w_l, w_dl, w_ddl, w_dddl, w_centre;          /* 1000, 10000 (unused by the ref, :193), 3000, 150, 250 */
+    double w_end_l, w_end_dl, w_end_ddl;                /* 40, 40, 40 */
+    double host_d1, host_d2, host_w;                    /* 3, 3, 3 */
+    double obs_length, obs_width;                       /* 5, 5 (ref: test_9.py:192) */
+    int32_t decimate;       /* 2 (test_9.py:187) or 1 (test_7.py) */
+    int32_t midpoint;       /* 1: re-interleave midpoints (test_9.py:204-210); 0: none (test_7.py) */
+    int32_t use_qp;         /* 1; 0 skips the QP (test_5.py / test_6.py form) */
+    int32_t reserved;
+} emp_qp_params;
+
+/* ref: keyword arguments of smooth_reference_line, planning_utils.py:262-264 */
+typedef struct emp_smooth_params {
+    double w_smooth, w_length, w_ref;                   /* 0.4, 0.3, 0.3 */
+    double x_thre, y_thre;                              /* 0.2, 0.2 */
+} emp_smooth_params;
+
+void emp_dp_params_default(emp_dp_params* p);
+void emp_qp_params_default(emp_qp_params* p);
+void emp_smooth_params_default(emp_smooth_params* p);
+
+/* ---- context ------------------------------------------------------------------------- */
+int emp_abi_version(void);
+int emp_create(int device_id, emp_ctx** out);
+void emp_destroy(emp_ctx* ctx);
+const char* emp_last_error(const emp_ctx* ctx); /* ctx may be NULL: error of the last failed emp_create */
+int emp_synchronize(emp_ctx* ctx);
+/* the context's HIP stream (hipStream_t) so callers can order their own work after ours */
+void* emp_stream(emp_ctx* ctx);
+/* device memory helpers for callers without a HIP binding (ctypes hosts) */
+int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
+int emp_device_free(emp_ctx* ctx, void* ptr);
+int emp_copy_to_device(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int emp_copy_to_host(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+/* timing of the last launch of a named kernel on this context, measured with HIP events on the
+ * context's stream ("dp_edge", "dp_sweep", "dp_fused", "project", "path_qp", "to_cartesian");
+ * returns milliseconds, or a negative value when that kernel has not run with timing enabled */
+int emp_set_timing(emp_ctx* ctx, int enabled);
+double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
+
+/* ---- S-L lattice DP ------------------------------------------------------------------ */
+/* Layout of the materialised edge-cost tensor (two-kernel DP mode):
+ *   EMP_EDGE_CANONICAL  edge[b][j-1][i][k]  k fastest: cost of row k (column j-1) -> row i (column j)
+ *   EMP_EDGE_TILED      the layout the sweep kernel streams: scenes are grouped in tiles of
+ *                       S = 64 / row scenes and stored [tile][j-1][k][s][i] so that one wavefront
+ *                       reads 64 consecutive doubles per source row k         */
+typedef enum emp_edge_layout { EMP_EDGE_CANONICAL = 0, EMP_EDGE_TILED = 1 } emp_edge_layout;
+uint64_t emp_edge_tensor_elems(const emp_dp_params* p, int32_t B, emp_edge_layout layout);
+
+/* ref: cal_start_cost (path_planning.py:435-514) for every row and cal_neighbor_cost (:517-585)
+ * for every (column, row, row) of every scene.
+ *   obs_s, obs_l [B][max_obs], n_obs [B], start [B][4] = plan_start s, l, dl, ddl
+ *   start_cost [B][row]   (without the +10000 lane penalty, like the ref's function)
+ *   edge       emp_edge_tensor_elems(p, B, layout) doubles                                  */
+int emp_dp_edge_costs(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t max_obs,
+                      const double* obs_s, const double* obs_l, const int32_t* n_obs, const double* start,
+                      double* start_cost, double* edge, emp_edge_layout layout, emp_mem where);
+
+typedef enum emp_dp_mode {
+    EMP_DP_FUSED = 0,      /* one kernel: edge costs staged in LDS, swept in place, no HBM edge tensor */
+    EMP_DP_TWO_KERNEL = 1  /* edge-cost kernel writes the tiled tensor to HBM, sweep kernel streams it */
+} emp_dp_mode;
+
+/* ref: DP_algorithm (path_planning.py:276-375) up to and including the backtrack, batched.
+ *   rows   [B][col] float64: chosen lattice row per column (float because the ref's no-obstacle
+ *          bypass yields (row+1)/2-1, which is x.5 for even `row`, :363)
+ *   min_cost [B] (may be NULL): minimum of the last cost column (+inf in the bypass)
+ *   status [B]: EMP_ST_DP_INFEASIBLE or 0                                                    */
+int emp_dp_plan(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t max_obs,
+                const double* obs_s, const double* obs_l, const int32_t* n_obs, const double* start,
+                emp_dp_mode mode, double* rows, double* min_cost, int32_t* status, emp_mem where);
+
+/* min-plus sweep + backtrack on caller-provided costs (ref: path_planning.py:301-361), for tests
+ * and for the HBM-roofline measurement.  start_cost [B][row], edge in EMP_EDGE_TILED layout. */
+int emp_dp_sweep(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double* start_cost, const double* edge,
+                 double* rows, double* min_cost, int32_t* status, emp_mem where);
+
+/* ref: enrich_DP_s_l (path_planning.py:378-432) after the row->(s,l) mapping of :366-370.
+ *   rows [B][col] -> path_s, path_l [B][max_pts], path_len [B]; status gets EMP_ST_TRUNCATED  */
+int emp_dp_enrich(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double* rows, const double* start,
+                  int32_t max_pts, double* path_s, double* path_l, int32_t* path_len, int32_t* status,
+                  emp_mem where);
+
+/* ---- Cartesian <-> Frenet ------------------------------------------------------------ */
+/* ref: cal_s_map_fun (planning_utils.py:448-472), cal_s_l_fun (:475-509) for the obstacles and the
+ * planning start, cal_s_l_deri_fun (:512-588) for the planning start - the front half of one
+ * motion_planning cycle (test_9.py:113-177).
+ *   ref_line [B][max_ref][4] x,y,theta,kappa; n_ref [B]
+ *   origin_xy, start_xy, start_v, start_a [B][2]; obs_xy [B][max_obs][2]; n_obs [B]
+ *   s_map [B][max_ref]; obs_s, obs_l [B][max_obs]; begin_sl [B][2] = s,l of start_xy;
+ *   start [B][4] = s, l, dl/ds, d2l/ds2 (the DP's plan_start_*)                               */
+int emp_frenet_project(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_obs,
+                       const double* ref_line, const int32_t* n_ref,
+                       const double* origin_xy, const double* start_xy, const double* start_v,
+                       const double* start_a, const double* obs_xy, const int32_t* n_obs,
+                       double* s_map, double* obs_s, double* obs_l, double* begin_sl, double* start,
+                       emp_mem where);
+
+/* ref: match_projection_points (planning_utils.py:364-426): [B][max_pts] points against one line per scene */
+int emp_match_projection(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts,
+                         const double* ref_line, const int32_t* n_ref, const double* xy, const int32_t* n_pts,
+                         int32_t* match_index, double* proj, emp_mem where);
+
+/* ref: find_match_points (planning_utils.py:49-182) */
+int emp_find_match_points(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts,
+                          const double* ref_line, const int32_t* n_ref, const double* xy, const int32_t* n_pts,
+                          const int32_t* is_first_run, const int32_t* pre_match_index,
+                          int32_t* match_index, double* proj, emp_mem where);
+
+/* ref: cal_heading_kappa (planning_utils.py:185-228): xy [B][max_pts][2] -> theta, kappa [B][max_pts] */
+int emp_heading_kappa(emp_ctx* ctx, int32_t B, int32_t max_pts, const double* xy, const int32_t* n_pts,
+                      double* theta, double* kappa, emp_mem where);
+
+/* ---- QP stages ----------------------------------------------------------------------- */
+/* ref: cal_lmin_lmax (path_planning.py:222-273): station bounds from the (decimated) DP path */
+int emp_lmin_lmax(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_t max_obs,
+                  const double* dp_s, const double* dp_l, const int32_t* n_pts,
+                  const double* obs_s, const double* obs_l, const int32_t* n_obs,
+                  double obs_length, double obs_width, double* l_min, double* l_max, int32_t* status,
+                  emp_mem where);
+
+/* ref: Quadratic_planning (path_planning.py:78-219).  l_min, l_max [B][max_pts], n_pts [B],
+ * start_l3 [B][3] = plan_start l, dl, ddl -> qp_l, qp_dl, qp_ddl [B][max_pts]; status EMP_ST_QP_FAILED */
+int emp_path_qp(emp_ctx* ctx, const emp_qp_params* q, int32_t B, int32_t max_pts,
+                const double* l_min, const double* l_max, const int32_t* n_pts, const double* start_l3,
+                double* qp_l, double* qp_dl, double* qp_ddl, int32_t* iters, int32_t* status, emp_mem where);
+
+/* ref: smooth_reference_line (planning_utils.py:262-361): box-QP smoothing + heading/kappa.
+ * xy [B][max_pts][2] -> out [B][max_pts][4] = x, y, theta, kappa */
+int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_t max_pts,
+                    const double* xy, const int32_t* n_pts, double* out, int32_t* iters, int32_t* status,
+                    emp_mem where);
+
+/* ref: cal_proj_point (path_planning.py:52-75) chained over a path as frenet_2_x_y_theta_kappa does
+ * (:29-46), WITHOUT the smoothing: target_xy [B][max_pts+1][2] (first = the planning start), n_out [B] */
+int emp_frenet_path_to_xy(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts,
+                          const double* ref_line, const double* s_map, const int32_t* n_ref,
+                          const double* begin_sl, const double* path_s, const double* path_l,
+                          const int32_t* n_pts, double* target_xy, int32_t* n_out, int32_t* status,
+                          emp_mem where);
+
+/* ---- one whole planning cycle -------------------------------------------------------- */
+/* ref: the body of motion_planning, test_9.py:113-218 (reference line already smoothed):
+ * projection -> DP -> decimate -> bounds -> path QP -> midpoints -> Frenet->Cartesian -> smoothing
+ * -> heading/kappa.  Inputs as emp_frenet_project.  Outputs (any may be NULL except traj/traj_len/status):
+ *   dp_rows [B][col]; dp_s, dp_l [B][max_pts], dp_len [B]      (DP_algorithm's return)
+ *   path_s, path_l [B][max_pts], path_len [B]                   (what test_9.py:220 sends back)
+ *   traj [B][max_pts+1][4] x,y,theta,kappa, traj_len [B]        (the controller's input)
+ *   status [B] bit mask                                                                       */
+typedef struct emp_cycle_io {
+    /* inputs */
+    const double* ref_line; const int32_t* n_ref;
+    const double* origin_xy; const double* start_xy; const double* start_v; const double* start_a;
+    const double* obs_xy; const int32_t* n_obs;
+    /* outputs */
+    double* dp_rows; double* dp_s; double* dp_l; int32_t* dp_len;
+    double* path_s; double* path_l; int32_t* path_len;
+    double* traj; int32_t* traj_len;
+    int32_t* status;
+} emp_cycle_io;
+
+int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q, const emp_smooth_params* sp,
+                   int32_t B, int32_t max_ref, int32_t max_obs, int32_t max_pts, emp_dp_mode mode,
+                   const emp_cycle_io* io, emp_mem where);
+
+/* ---- scalar utilities of the reference that sit beside the path ----------------------- */
+/* ref: cal_quintic_coefficient (planning_utils.py:671-703): bc [n][8] -> coeff [n][6] (absolute-s basis) */
+int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* coeff, emp_mem where);
+/* ref: cal_obs_cost (path_planning.py:588-609): square_d [n][10] -> cost [n] */
+int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis,
+                 const double* square_d, double* cost, emp_mem where);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMPLANNER_H */

@@ -1,0 +1,171 @@
+"""GPU parity: S-L lattice DP kernels (edge costs, sweep, backtrack, densification) through the C-ABI.
+
+Bars: bit-exact against ``oracle.exact`` (same operation order, no FMA contraction), index-exact
+and 1e-6 relative against the golden vectors of the imported reference.
+"""
+import numpy as np
+import pytest
+
+from emplanner_carla_amd import scenes as S
+from oracle import exact as ex
+from tests.conftest import assert_rel, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+GOLD = [(S.CFG1, "cycle_cfg1_20x5_0obs.npz"), (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz"),
+        (S.CFG2, "cycle_cfg2_40x9_8obs.npz")]
+
+
+@pytest.fixture(scope="module")
+def planner():
+    from emplanner_carla_amd.api import Planner
+    p = Planner(0)
+    yield p
+    p.close()
+
+
+def _params(cfg):
+    from emplanner_carla_amd.api import dp_params_from_cfg
+    return dp_params_from_cfg(cfg)
+
+
+def _golden_inputs(g):
+    return (np.nan_to_num(g["obs_s"]), np.nan_to_num(g["obs_l"]), g["in_n_obs"].astype(np.int32), g["start"].copy())
+
+
+@pytest.mark.parametrize("cfg,fname", GOLD[1:], ids=[c[0].name for c in GOLD[1:]])
+def test_edge_costs_bit_exact_vs_exact_oracle(planner, cfg, fname):
+    obs_s, obs_l, n_obs, start = _golden_inputs(load_golden(fname))
+    p = _params(cfg)
+    c0, e = planner.dp_edge_costs(p, obs_s, obs_l, n_obs, start)
+    rc0, re = ex.edge_costs(obs_s, obs_l, n_obs, start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l)
+    assert np.array_equal(c0, rc0), f"start edges differ: max rel {np.abs(c0 - rc0).max()}"
+    assert np.array_equal(e, re), f"{(e != re).sum()} of {e.size} neighbour edges differ"
+
+
+def test_edge_costs_vs_reference_golden(planner):
+    """GPU edge tensor against the reference's own cal_start_cost / cal_neighbor_cost values."""
+    ed = load_golden("edges.npz")
+    for cfg, fname, seeds in ((S.CFG_DEFAULT, GOLD[1][1], (0, 1, 2)), (S.CFG2, GOLD[2][1], (0, 9))):
+        obs_s, obs_l, n_obs, start = _golden_inputs(load_golden(fname))
+        c0, e = planner.dp_edge_costs(_params(cfg), obs_s, obs_l, n_obs, start)
+        for sd in seeds:
+            assert_rel(c0[sd], ed[f"{cfg.name}__{sd}__c0"], RTOL, 1.0, "start edges")
+            s0 = start[sd, 0] + np.arange(1, cfg.col) * cfg.sample_s
+            near = s0 <= 90.0      # beyond, the reference's own noise exceeds 1e-6 (tests/test_oracle_golden.py)
+            red = ed[f"{cfg.name}__{sd}__e"]
+            assert_rel(e[sd][near], red[near], RTOL, 1.0, "neighbour edges")
+            if (~near).any():
+                assert_rel(e[sd][~near], red[~near], 4 * RTOL, 1.0, "neighbour edges beyond 90 m")
+
+
+def test_tiled_layout_matches_canonical(planner):
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd.api import tile_edges
+    cfg = S.CFG2
+    obs_s, obs_l, n_obs, start = _golden_inputs(load_golden(GOLD[2][1]))
+    obs_s, obs_l, n_obs, start = obs_s[:17], obs_l[:17], n_obs[:17], start[:17]     # ragged last tile
+    p = _params(cfg)
+    _, e = planner.dp_edge_costs(p, obs_s, obs_l, n_obs, start)
+    _, t = planner.dp_edge_costs(p, obs_s, obs_l, n_obs, start, layout=L.EMP_EDGE_TILED)
+    want = tile_edges(e, cfg.row).reshape(-1, 64)
+    got = t.reshape(-1, 64)
+    Sn = 64 // cfg.row
+    live = np.zeros((want.shape[0], 64), dtype=bool)
+    rows_per_tile = (cfg.col - 1) * cfg.row
+    for b in range(17):
+        tl, s = divmod(b, Sn)
+        live[tl * rows_per_tile:(tl + 1) * rows_per_tile, s * cfg.row:(s + 1) * cfg.row] = True
+    assert np.array_equal(got[live], want[live])
+
+
+@pytest.mark.parametrize("cfg,fname", GOLD, ids=[c[0].name for c in GOLD])
+@pytest.mark.parametrize("mode", [0, 1], ids=["fused", "two_kernel"])
+def test_dp_rows_index_exact_vs_reference(planner, cfg, fname, mode):
+    g = load_golden(fname)
+    obs_s, obs_l, n_obs, start = _golden_inputs(g)
+    p = _params(cfg)
+    rows, min_cost, status = planner.dp_plan(p, obs_s, obs_l, n_obs, start, mode=mode)
+    xrows, xfeas, xpaths = ex.dp_plan(obs_s, obs_l, n_obs, start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l,
+                                      cfg.sampling_res)
+    assert np.array_equal(rows, xrows), "DP rows differ from the exact oracle"
+    assert np.array_equal((status & 1) == 1, ~xfeas)
+    assert np.array_equal((status & 1) == 1, g["dp_infeasible_banner"] == 1), "infeasible banner vs reference"
+    # densified path against the reference's DP_algorithm output
+    from emplanner_carla_amd.api import max_path_points
+    mp = max_path_points(p)
+    ps, pl, ln, st = planner.dp_enrich(p, rows, start, mp)
+    assert (st == 0).all()
+    for b in range(len(start)):
+        n = int(g["dp_len"][b])
+        assert ln[b] == n, "point count (int() truncation rule)"
+        assert np.array_equal(ps[b, :n], g["dp_s"][b, :n]), "station s must be bit-exact with the reference"
+        assert_rel(pl[b, :n], g["dp_l"][b, :n], RTOL, 1.0, "dp_l vs reference")
+        xs, xl = xpaths[b]
+        assert np.array_equal(pl[b, :n], np.asarray(xl)), "dp_l must be bit-exact with the exact oracle"
+
+
+def test_dp_sweep_on_handmade_costs(planner):
+    """Sweep semantics on synthetic tensors: ties -> lowest k, untouched predecessor stays 1, +10000 rows."""
+    from emplanner_carla_amd.api import dp_params, tile_edges
+    rng = np.random.default_rng(5)
+    for row, col in ((9, 40), (12, 6), (5, 20), (7, 11), (21, 13), (3, 2), (1, 5)):
+        B = 2 * (64 // row) + 3
+        p = dp_params(row=row, col=col)
+        # integers in a small range create many exact ties
+        c0 = rng.integers(0, 4, size=(B, row)).astype(np.float64)
+        e = rng.integers(0, 3, size=(B, col - 1, row, row)).astype(np.float64)
+        if row >= 2:
+            e[0] = np.inf                                # a scene where nothing is ever relaxed
+        rows, min_cost, status = planner.dp_sweep(p, c0, tile_edges(e, row))
+        cost, pre = ex.dp_sweep(c0, e, row)
+        xrows, feas = ex.dp_backtrack(cost, pre)
+        assert np.array_equal(rows, xrows.astype(np.float64)), (row, col)
+        assert np.array_equal(min_cost, cost[:, :, -1].min(axis=1))
+        assert np.array_equal(status == 1, ~feas)
+
+
+def test_enrich_truncation_rule_and_capacity(planner):
+    """int(end_s - start_s) decides the sample count (ref path_planning.py:405); integer sample_s flips it."""
+    g = load_golden("functions.npz")
+    from emplanner_carla_amd.api import dp_params
+    DP_l = np.array([0.0, 1.5, 1.5, -3.0, 0.0, 0.0])
+    rows = ((12 + 1) / 2 - 1 - DP_l / 1.5)[None, :]
+    for rec in g["enrich"]:
+        ps, res, n = rec[0], rec[1], int(rec[2])
+        p = dp_params(row=12, col=6, sample_s=15, sample_l=1.5, sampling_res=res)
+        start = np.array([[ps, 0.2, 0.01, -0.003]])
+        s, l, ln, st = planner.dp_enrich(p, rows, start, 200)
+        assert ln[0] == n and st[0] == 0
+        assert np.array_equal(s[0, :n], rec[3:3 + n])
+        assert_rel(l[0, :n], rec[203:203 + n], RTOL, 1.0, "enrich l")
+        s, l, ln, st = planner.dp_enrich(p, rows, start, 10)      # too small: flagged, no overflow
+        assert ln[0] == 10 and st[0] == 32
+
+
+def test_dp_large_batch_matches_exact_oracle(planner):
+    """BASELINE configs[2] shape (40x9, 8 obstacles) on 1024 scenes incl. walls and dodges."""
+    cfg = S.CFG2
+    b = S.make_batch(range(1000, 2024), cfg)
+    p = _params(cfg)
+    rows, mc, st = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    xrows, xfeas, _ = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s,
+                                 cfg.sample_l, cfg.sampling_res)
+    assert np.array_equal(rows, xrows)
+    assert np.array_equal(st == 1, ~xfeas)
+    assert 0 < (st == 1).sum() < 400           # the generator's walls show up, most scenes are drivable
+
+
+def test_empty_and_bypass_batches(planner):
+    from emplanner_carla_amd.api import dp_params
+    p = dp_params(row=12, col=6)
+    rows, mc, st = planner.dp_plan(p, np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros((0, 4)))
+    assert rows.shape == (0, 6)
+    # no obstacles -> centre row 5.5 on an even lattice (ref path_planning.py:363), +inf min cost
+    start = np.array([[0.0, 0.1, 0.0, 0.0], [3.0, -0.2, 0.01, 0.0]])
+    rows, mc, st = planner.dp_plan(p, np.zeros((2, 3)), np.zeros((2, 3)), np.zeros(2, np.int32), start)
+    assert np.array_equal(rows, np.full((2, 6), 5.5)) and np.isinf(mc).all() and (st == 0).all()
+    # max_obs == 0 arrays
+    rows, mc, st = planner.dp_plan(p, np.zeros((2, 0)), np.zeros((2, 0)), np.zeros(2, np.int32), start)
+    assert np.array_equal(rows, np.full((2, 6), 5.5))
