@@ -150,18 +150,40 @@ def polish(P, q, G, h, A, b, x, z, act_tol=1e-7, max_rounds=8):
         idx = np.nonzero(active)[0]
         Aa = np.vstack([A, G[idx]])
         ba = np.concatenate([b, h[idx]])
-        K = np.zeros((n + len(ba), n + len(ba)))
-        K[:n, :n] = P
-        K[:n, n:] = Aa.T
-        K[n:, :n] = Aa
+        # null-space method (accurate to round-off even when active rows are linearly dependent):
+        # x = xp + Z y with Aa xp = ba (minimum norm) and Z an orthonormal basis of null(Aa)
         try:
-            sol = np.linalg.lstsq(K, np.concatenate([-q, ba]), rcond=None)[0]
+            Ua, sv, Vt = np.linalg.svd(Aa, full_matrices=True)
         except np.linalg.LinAlgError:
             return x, z, None, False
-        xn = sol[:n]
-        mult = sol[n:]
-        y = mult[:A.shape[0]]
-        za = mult[A.shape[0]:]
+        rank = int((sv > 1e-11 * max(sv.max(initial=0.0), 1.0)).sum())
+        xp = Vt[:rank].T @ ((Ua[:, :rank].T @ ba) / sv[:rank])
+        if np.abs(Aa @ xp - ba).max(initial=0.0) > 1e-8 * (1.0 + np.abs(ba).max(initial=0.0)):
+            return x, z, None, False                       # inconsistent active set
+        Z = Vt[rank:].T
+        if Z.shape[1]:
+            Hr = Z.T @ P @ Z
+            y_red = np.linalg.solve(Hr, -Z.T @ (q + P @ xp))
+            xn = xp + Z @ y_red
+        else:
+            xn = xp
+        # multipliers: non-negative on the active inequality rows, free on the equality rows (NNLS copes
+        # with linearly dependent active rows, where plain least squares may return spurious negatives)
+        grad = P @ xn + q
+        Mt = np.hstack([G[idx].T, A.T, -A.T])
+        if Mt.shape[1]:
+            coef, _ = nnls(Mt, -grad, maxiter=50 * max(Mt.shape[1], 10))
+            resid = np.abs(Mt @ coef + grad).max()
+        else:
+            coef, resid = np.zeros(0), np.abs(grad).max(initial=0.0)
+        na = len(idx)
+        if resid <= 1e-9 * max(1.0, np.abs(q).max(initial=0.0)):
+            za = coef[:na]
+            y = coef[na:na + A.shape[0]] - coef[na + A.shape[0]:]
+        else:
+            mult = np.linalg.lstsq(Aa.T, -grad, rcond=None)[0]
+            y = mult[:A.shape[0]]
+            za = mult[A.shape[0]:]
         sl = h - G @ xn
         bad_mult = idx[za < -1e-9 * (1.0 + np.abs(za).max(initial=0.0))]
         bad_feas = np.nonzero((sl < -1e-9 * (1.0 + np.abs(h))) & ~active)[0]

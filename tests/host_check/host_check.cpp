@@ -1,0 +1,46 @@
+// host_check.cpp - runs the scalar building blocks of csrc/*.h on the CPU for the `-m "not gpu"` suite.
+// TEST TOOL ONLY: compiled with g++ into tests/host_check/_build/, loaded by tests/test_host_logic.py,
+// never by the package.  It lets kernel *logic* (banded QP, Frenet helpers, edge arithmetic) be checked
+// against the oracle without a GPU; GPU parity proper is tests/test_gpu_*.py through the C-ABI.
+#include "../../emplanner_carla_amd/csrc/emp_core.h"
+#include "../../emplanner_carla_amd/csrc/emp_frenet_core.h"
+#include "../../emplanner_carla_amd/csrc/emp_qp_core.h"
+
+using namespace emp;
+
+extern "C" {
+
+double hc_segment_cost(double l0, double dl0, double ddl0, double l1, double s0, double sample_s, const double* obs_s,
+                       const double* obs_l, int n_obs, double w_coll, double w0, double w1, double w2, double w_ref) {
+    const Quintic q = quintic_shifted(l0, dl0, ddl0, l1, sample_s);
+    return segment_cost(q, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w0, w1, w2, w_ref);
+}
+
+int hc_path_qp(int n, const double* l_min, const double* l_max, double l0, double dl0, double ddl0, const double* prm8,
+               double* out_l, double* out_dl, double* out_ddl, int* iters) {
+    static PathQp<128> qp;
+    PathQpParams p{prm8[0], prm8[1], prm8[2], prm8[3], prm8[4], prm8[5], prm8[6], prm8[7]};
+    const int rc = qp.solve(l_min, l_max, n, l0, dl0, ddl0, p, out_l, out_dl, out_ddl);
+    *iters = qp.iters;
+    return rc;
+}
+
+int hc_box_qp(int m, const double* ref, int stride, double w_smooth, double w_length, double w_ref, double thr,
+              double* out, int* iters) {
+    static BoxQp<256> qp;
+    SmoothQpParams p{w_smooth, w_length, w_ref, thr};
+    const int rc = qp.solve(ref, stride, m, p);
+    for (int i = 0; i < m && i < 256; ++i) out[i] = qp.x[i];
+    *iters = qp.iters;
+    return rc;
+}
+
+void hc_heading_kappa(const double* xy, int m, double* theta, double* kappa) { heading_kappa(xy, 2, m, theta, 1, kappa, 1); }
+
+void hc_s_map(const double* line, int n_ref, double ox, double oy, double* s_map) { s_map_build(line, n_ref, ox, oy, s_map); }
+
+int hc_match(const double* line, int n_ref, double x, double y, int first, int step, int limit) {
+    return match_scan(line, n_ref, x, y, first, step, limit);
+}
+
+}  // extern "C"

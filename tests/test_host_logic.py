@@ -1,0 +1,178 @@
+"""CPU checks of the kernels' scalar building blocks (csrc/emp_core.h, emp_qp_core.h, emp_frenet_core.h).
+
+The headers are plain C++ that hipcc compiles into the kernels; here g++ compiles the same text
+into a test-only library (tests/host_check) so the *logic* - the B-spline reformulation of the path
+QP, the banded interior point, the Frenet helpers, the edge arithmetic - is compared with the oracle
+without a GPU.  This is host-logic coverage, not the GPU parity proof (tests/test_gpu_*.py).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from emplanner_carla_amd import scenes as S
+from oracle import exact as ex
+from oracle import qp_dense
+from oracle import ref_port as op
+from tests import host_check
+from tests.conftest import assert_rel, load_golden
+
+QP_PRM = np.array([2.0, 1000.0, 3000.0, 150.0, 250.0, 3.0, 3.0, 3.0])   # ds, w_l, w_ddl, w_dddl, w_centre, d1, d2, w
+
+
+@pytest.fixture(scope="module")
+def hc():
+    return host_check.load()
+
+
+def _path_qp(hc, l_min, l_max, start3, prm=QP_PRM):
+    n = len(l_min)
+    l_min = np.ascontiguousarray(l_min, dtype=np.float64)
+    l_max = np.ascontiguousarray(l_max, dtype=np.float64)
+    prm = np.ascontiguousarray(prm, dtype=np.float64)
+    out = [np.zeros(n) for _ in range(3)]
+    it = C.c_int(0)
+    rc = hc.hc_path_qp(n, l_min.ctypes.data, l_max.ctypes.data, *[float(v) for v in start3], prm.ctypes.data,
+                       out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(it))
+    return rc, out, it.value
+
+
+@pytest.mark.parametrize("fname", ["cycle_cfg2_40x9_8obs.npz", "cycle_default_6x12_3obs.npz",
+                                   "cycle_cfg1_20x5_0obs.npz", "cycle_default_6x12_3obs_t7.npz"])
+def test_bspline_path_qp_matches_reference_formulation(hc, fname):
+    """Banded B-spline IPM == dense solve of the reference's own (H, f, G, h, Aeq, beq)."""
+    g = load_golden(fname)
+    n_ok = 0
+    for i in range(len(g["seeds"])):
+        if np.isnan(g["l_min"][i, 0]):
+            continue
+        nq = int(g["n_qp"][i])
+        rc, (l, dl, ddl), iters = _path_qp(hc, g["l_min"][i, :nq], g["l_max"][i, :nq], g["start"][i, 1:])
+        if g["status"][i] == 4:
+            assert rc != 0, "oracle says infeasible, banded solver must not claim success"
+            continue
+        assert rc == 0 and iters <= 40
+        assert_rel(l, g["qp_l"][i, :nq], 1e-8, 1.0, "qp_l")
+        assert_rel(dl, g["qp_dl"][i, :nq], 1e-8, 1.0, "qp_dl")
+        assert_rel(ddl, g["qp_ddl"][i, :nq], 1e-8, 1.0, "qp_ddl")
+        n_ok += 1
+    assert n_ok >= 6
+
+
+def test_path_qp_kkt_certificate_on_random_corridors(hc):
+    """Certificate against the reference's dense formulation on corridors the goldens do not hold."""
+    rng = np.random.default_rng(11)
+    checked = 0
+    for trial in range(40):
+        n = int(rng.integers(8, 60))
+        l_min = -10.0 * np.ones(n)
+        l_max = 10.0 * np.ones(n)
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(4, max(5, n - 6)))
+            w = int(rng.integers(1, 4))
+            if rng.random() < 0.5:
+                l_max[a:a + w] = rng.uniform(0.5, 4.0)
+            else:
+                l_min[a:a + w] = rng.uniform(-4.0, -0.5)
+        start3 = (rng.uniform(-0.4, 0.4), rng.uniform(-0.05, 0.05), rng.uniform(-0.01, 0.01))
+        rc, (l, dl, ddl), iters = _path_qp(hc, l_min, l_max, start3)
+        H, f, G, h, A, b = op.path_qp_matrices(l_min, l_max, *start3)
+        ref = qp_dense.solve_qp(H, f, G, h, A, b)
+        if ref.status != "optimal":
+            assert rc != 0
+            continue
+        assert rc == 0
+        x = np.stack([l, dl, ddl], axis=1).reshape(-1)
+        cert = qp_dense.kkt_certificate(H, f, G, h, A, b, x)
+        assert cert["stationarity"] < 1e-7 and cert["ineq_violation"] < 1e-9 and cert["eq_violation"] < 1e-9
+        assert_rel(x, ref.x, 1e-7, 1.0, "x vs dense oracle")
+        checked += 1
+    assert checked >= 20
+
+
+def test_path_qp_rejects_infeasible_and_tiny(hc):
+    n = 12
+    rc, _, _ = _path_qp(hc, 2.0 * np.ones(n), -2.0 * np.ones(n), (0, 0, 0))       # empty corridor
+    assert rc == 1
+    rc, _, _ = _path_qp(hc, -10 * np.ones(n), 10 * np.ones(n), (9.5, 0.0, 0.0))   # pinned start outside
+    assert rc == 1
+    lmax = 10 * np.ones(n)
+    lmax[n - 1] = -5.0                               # pinned end (l = 0) above the last stations' upper bound
+    rc, _, _ = _path_qp(hc, -10 * np.ones(n), lmax, (0, 0, 0))
+    assert rc == 1
+    rc, _, _ = _path_qp(hc, -10 * np.ones(3), 10 * np.ones(3), (0, 0, 0))         # n < 4: start/end overlap
+    assert rc == 2
+    rc, (l, dl, ddl), _ = _path_qp(hc, -10 * np.ones(4), 10 * np.ones(4), (0.3, 0.01, 0.0))   # n = 4: no freedom
+    assert rc == 0 and abs(l[0] - 0.3) < 1e-15 and l[3] == 0.0
+
+
+def _box_qp(hc, ref, thr=0.2, w=(0.4, 0.3, 0.3)):
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    out = np.zeros(len(ref))
+    it = C.c_int(0)
+    rc = hc.hc_box_qp(len(ref), ref.ctypes.data, 1, w[0], w[1], w[2], thr, out.ctypes.data, C.byref(it))
+    return rc, out, it.value
+
+
+def test_box_qp_matches_reference_smoothing(hc):
+    """x and y solved separately == the reference's joint 2m-variable QP (unique minimiser)."""
+    rng = np.random.default_rng(3)
+    for m in (2, 3, 5, 23, 51, 130):
+        pts = np.cumsum(rng.normal(0, 1.2, (m, 2)), axis=0) + rng.uniform(-300, 300, 2)
+        H, f, G, h = op.smooth_qp_matrices([tuple(p) for p in pts])
+        ref = qp_dense.solve_qp(H, f, G, h)
+        assert ref.status == "optimal"
+        for c in range(2):
+            rc, x, iters = _box_qp(hc, pts[:, c])
+            assert rc == 0 and iters <= 40
+            assert_rel(x, ref.x[c::2], 1e-9, 1.0, f"coordinate {c}, m={m}")
+    # golden: the smoothed trajectory of the reference cycle (x, y columns)
+    g = load_golden("cycle_cfg2_40x9_8obs.npz")
+    f0 = load_golden("qp_formulation.npz")
+    tgt = (-f0["smooth_q"].reshape(-1) / 0.6)          # f = -2 * 0.3 * x_ref
+    for c in range(2):
+        rc, x, _ = _box_qp(hc, tgt[c::2])
+        m = int(g["traj_len"][0])
+        assert rc == 0
+        assert_rel(x, g["traj"][0, :m, c], 1e-9, 1.0, "golden trajectory")
+
+
+def test_heading_kappa_and_s_map(hc):
+    g = load_golden("functions.npz")
+    xy = np.ascontiguousarray(g["hk_xy"])
+    th = np.zeros(len(xy))
+    kp = np.zeros(len(xy))
+    hc.hc_heading_kappa(xy.ctypes.data, len(xy), th.ctypes.data, kp.ctypes.data)
+    assert_rel(th, g["hk_theta"], 1e-12, 1.0, "theta")
+    assert_rel(kp, g["hk_kappa"], 1e-9, 1.0, "kappa")
+    line = np.ascontiguousarray(g["mp_path"][:80])
+    sm = np.zeros(80)
+    hc.hc_s_map(line.ctypes.data, 80, 7.3, 2.0, sm.ctypes.data)
+    assert_rel(sm, g["sm_out"], 1e-12, 1.0, "s_map")
+    # matching with both early exits (50 on a first run, 5 in windowed mode)
+    full = np.ascontiguousarray(g["mp_path"])
+    for (x, y), want in zip(g["mp_pts"], g["mp_index"]):
+        assert hc.hc_match(full.ctypes.data, len(full), x, y, 0, 1, 50) == want
+
+
+def test_segment_cost_bit_exact_with_exact_oracle(hc):
+    g = load_golden("cycle_default_6x12_3obs.npz")
+    cfg = S.CFG_DEFAULT
+    for sd in range(4):
+        k = int(g["in_n_obs"][sd])
+        obs_s = np.ascontiguousarray(g["obs_s"][sd, :k])
+        obs_l = np.ascontiguousarray(g["obs_l"][sd, :k])
+        c0, e = ex.edge_costs(obs_s[None], obs_l[None], np.array([k]), g["start"][sd:sd + 1], cfg.row, cfg.col,
+                              cfg.sample_s, cfg.sample_l)
+        ps, pl, pdl, pddl = g["start"][sd]
+        for i in range(cfg.row):
+            l1 = ((cfg.row + 1) / 2 - 1 - i) * cfg.sample_l
+            v = hc.hc_segment_cost(pl, pdl, pddl, l1, ps, cfg.sample_s, obs_s.ctypes.data, obs_l.ctypes.data, k,
+                                   1e12, 300.0, 1000.0, 5000.0, 20.0)
+            assert v == c0[0, i]
+        for (j, i, kk) in ((1, 0, 0), (3, 11, 2), (5, 4, 9)):
+            l0 = ((cfg.row + 1) / 2 - 1 - kk) * cfg.sample_l
+            l1 = ((cfg.row + 1) / 2 - 1 - i) * cfg.sample_l
+            v = hc.hc_segment_cost(l0, 0.0, 0.0, l1, ps + j * cfg.sample_s, cfg.sample_s, obs_s.ctypes.data,
+                                   obs_l.ctypes.data, k, 1e12, 300.0, 1000.0, 5000.0, 20.0)
+            assert v == e[0, j - 1, i, kk]
