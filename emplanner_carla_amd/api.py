@@ -214,6 +214,159 @@ class Planner:
             int(max_pts), psp, plp, lnp, sp, a.where))
         return ps, pl, ln, st
 
+    # ---- Cartesian <-> Frenet -------------------------------------------------------------
+    def frenet_project(self, ref_line, n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs):
+        """ref cal_s_map_fun + cal_s_l_fun (obstacles, start) + cal_s_l_deri_fun (start): test_9.py:113-177.
+        returns s_map (B,P), obs_s (B,mo), obs_l (B,mo), begin_sl (B,2), start (B,4)."""
+        a = _Args(ref_line, origin_xy)
+        B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
+        mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
+        sm, smp = a.out((B, P), np.float64)
+        os_, osp = a.out((B, mo), np.float64)
+        ol_, olp = a.out((B, mo), np.float64)
+        bsl, bslp = a.out((B, 2), np.float64)
+        st, stp = a.out((B, 4), np.float64)
+        self._check(self._lib.emp_frenet_project(
+            self._h, B, P, mo, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(n_ref, np.int32, (B,)),
+            a.inp(origin_xy, np.float64, (B, 2)), a.inp(start_xy, np.float64, (B, 2)),
+            a.inp(start_v, np.float64, (B, 2)), a.inp(start_a, np.float64, (B, 2)),
+            a.inp(obs_xy, np.float64, (B, mo, 2)) if mo else None, a.inp(n_obs, np.int32, (B,)) if mo else None,
+            smp, osp if mo else None, olp if mo else None, bslp, stp, a.where))
+        return sm, os_, ol_, bsl, st
+
+    def match_projection(self, ref_line, n_ref, xy, n_pts):
+        """ref match_projection_points: returns match_index (B,K) int32, proj (B,K,4)."""
+        a = _Args(ref_line, xy)
+        B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
+        mi, mip = a.out((B, K), np.int32)
+        pr, prp = a.out((B, K, 4), np.float64)
+        self._check(self._lib.emp_match_projection(
+            self._h, B, P, K, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(n_ref, np.int32, (B,)),
+            a.inp(xy, np.float64, (B, K, 2)), a.inp(n_pts, np.int32, (B,)), mip, prp, a.where))
+        return mi, pr
+
+    def find_match_points(self, ref_line, n_ref, xy, n_pts, is_first_run, pre_match_index):
+        """ref find_match_points: returns match_index (B,K) int32, proj (B,K,4)."""
+        a = _Args(ref_line, xy)
+        B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
+        mi, mip = a.out((B, K), np.int32)
+        pr, prp = a.out((B, K, 4), np.float64)
+        self._check(self._lib.emp_find_match_points(
+            self._h, B, P, K, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(n_ref, np.int32, (B,)),
+            a.inp(xy, np.float64, (B, K, 2)), a.inp(n_pts, np.int32, (B,)), a.inp(is_first_run, np.int32, (B,)),
+            a.inp(pre_match_index, np.int32, (B,)), mip, prp, a.where))
+        return mi, pr
+
+    def heading_kappa(self, xy, n_pts):
+        """ref cal_heading_kappa: xy (B,M,2) -> theta, kappa (B,M)."""
+        a = _Args(xy)
+        B, M = int(xy.shape[0]), int(xy.shape[1])
+        th, thp = a.out((B, M), np.float64)
+        kp, kpp = a.out((B, M), np.float64)
+        self._check(self._lib.emp_heading_kappa(self._h, B, M, a.inp(xy, np.float64, (B, M, 2)),
+                                                a.inp(n_pts, np.int32, (B,)), thp, kpp, a.where))
+        return th, kp
+
+    # ---- QP stages ------------------------------------------------------------------------
+    def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):
+        """ref cal_lmin_lmax: returns l_min, l_max (B,M), status (B,)."""
+        a = _Args(dp_s, obs_s)
+        B, M = int(dp_s.shape[0]), int(dp_s.shape[1])
+        mo = int(obs_s.shape[1])
+        lo, lop = a.out((B, M), np.float64)
+        hi, hip = a.out((B, M), np.float64)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_lmin_lmax(
+            self._h, B, M, mo, a.inp(dp_s, np.float64, (B, M)), a.inp(dp_l, np.float64, (B, M)),
+            a.inp(n_pts, np.int32, (B,)), a.inp(obs_s, np.float64, (B, mo)), a.inp(obs_l, np.float64, (B, mo)),
+            a.inp(n_obs, np.int32, (B,)), float(obs_length), float(obs_width), lop, hip, stp, a.where))
+        return lo, hi, st
+
+    def path_qp(self, q: QpParams, l_min, l_max, n_pts, start_l3):
+        """ref Quadratic_planning: returns qp_l, qp_dl, qp_ddl (B,M), iters (B,), status (B,)."""
+        a = _Args(l_min, l_max, start_l3)
+        B, M = int(l_min.shape[0]), int(l_min.shape[1])
+        outs = [a.out((B, M), np.float64) for _ in range(3)]
+        it, itp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_path_qp(
+            self._h, C.byref(q), B, M, a.inp(l_min, np.float64, (B, M)), a.inp(l_max, np.float64, (B, M)),
+            a.inp(n_pts, np.int32, (B,)), a.inp(start_l3, np.float64, (B, 3)), outs[0][1], outs[1][1], outs[2][1],
+            itp, stp, a.where))
+        return outs[0][0], outs[1][0], outs[2][0], it, st
+
+    def smooth_line(self, sp: SmoothParams, xy, n_pts):
+        """ref smooth_reference_line: xy (B,M,2) -> out (B,M,4) x,y,theta,kappa; iters, status."""
+        a = _Args(xy)
+        B, M = int(xy.shape[0]), int(xy.shape[1])
+        out, outp = a.out((B, M, 4), np.float64)
+        it, itp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_smooth_line(self._h, C.byref(sp), B, M, a.inp(xy, np.float64, (B, M, 2)),
+                                              a.inp(n_pts, np.int32, (B,)), outp, itp, stp, a.where))
+        return out, it, st
+
+    def frenet_path_to_xy(self, ref_line, s_map, n_ref, begin_sl, path_s, path_l, n_pts):
+        """ref frenet_2_x_y_theta_kappa before its smoothing call: returns target_xy (B,M+1,2), n_out, status."""
+        a = _Args(ref_line, path_s)
+        B, P, M = int(ref_line.shape[0]), int(ref_line.shape[1]), int(path_s.shape[1])
+        t, tp = a.out((B, M + 1, 2), np.float64)
+        no, nop = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_frenet_path_to_xy(
+            self._h, B, P, M, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(s_map, np.float64, (B, P)),
+            a.inp(n_ref, np.int32, (B,)), a.inp(begin_sl, np.float64, (B, 2)), a.inp(path_s, np.float64, (B, M)),
+            a.inp(path_l, np.float64, (B, M)), a.inp(n_pts, np.int32, (B,)), tp, nop, stp, a.where))
+        return t, no, st
+
+    # ---- whole cycle ------------------------------------------------------------------------
+    def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
+                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_FUSED) -> CycleResult:
+        """ref motion_planning body, test_9.py:113-218, for a batch of scenes."""
+        a = _Args(ref_line, origin_xy)
+        B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
+        mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
+        M = int(max_pts) if max_pts else max_path_points(p)
+        io = L.CycleIO()
+        io.ref_line = a.inp(ref_line, np.float64, (B, P, 4))
+        io.n_ref = a.inp(n_ref, np.int32, (B,))
+        io.origin_xy = a.inp(origin_xy, np.float64, (B, 2))
+        io.start_xy = a.inp(start_xy, np.float64, (B, 2))
+        io.start_v = a.inp(start_v, np.float64, (B, 2))
+        io.start_a = a.inp(start_a, np.float64, (B, 2))
+        io.obs_xy = a.inp(obs_xy, np.float64, (B, mo, 2)) if mo else None
+        io.n_obs = a.inp(n_obs, np.int32, (B,)) if mo else None
+        res = {}
+        for name, shape, dt in (("dp_rows", (B, p.col), np.float64), ("dp_s", (B, M), np.float64),
+                                ("dp_l", (B, M), np.float64), ("dp_len", (B,), np.int32),
+                                ("path_s", (B, M), np.float64), ("path_l", (B, M), np.float64),
+                                ("path_len", (B,), np.int32), ("traj", (B, M + 1, 4), np.float64),
+                                ("traj_len", (B,), np.int32), ("status", (B,), np.int32)):
+            arr, ptr = a.out(shape, dt)
+            res[name] = arr
+            setattr(io, name, ptr)
+        self._check(self._lib.emp_plan_cycle(self._h, C.byref(p), C.byref(q), C.byref(sp), B, P, mo, M, int(mode),
+                                             C.byref(io), a.where))
+        return CycleResult(**res)
+
+    # ---- scalar utilities -------------------------------------------------------------------
+    def quintic_coefficients(self, bc):
+        """ref cal_quintic_coefficient: bc (n,8) -> coeff (n,6) in the absolute-s basis."""
+        a = _Args(bc)
+        n = int(bc.shape[0])
+        c, cp = a.out((n, 6), np.float64)
+        self._check(self._lib.emp_quintic_coefficients(self._h, n, a.inp(bc, np.float64, (n, 8)), cp, a.where))
+        return c
+
+    def obs_cost(self, square_d, w_collision, danger_dis=4, safe_dis=6):
+        """ref cal_obs_cost: square_d (n,10) -> cost (n,)."""
+        a = _Args(square_d)
+        n = int(square_d.shape[0])
+        c, cp = a.out((n,), np.float64)
+        self._check(self._lib.emp_obs_cost(self._h, n, float(w_collision), float(danger_dis), float(safe_dis),
+                                           a.inp(square_d, np.float64, (n, 10)), cp, a.where))
+        return c
+
 
 def max_path_points(p: DpParams) -> int:
     """Upper bound of len(enrich_DP_s_l output): col * ceil(int(sample_s + 1) / res) + 1."""

@@ -2,6 +2,7 @@
 // One translation unit: kernels are header-only templates, this file owns launches and staging.
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
+#include "emp_tail_kernels.h"
 
 namespace emp {
 thread_local std::string g_create_error;
@@ -378,28 +379,436 @@ int emp_dp_enrich(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double*
 
 }  // extern "C"
 
-// ---- entry points still to be filled in (kept so that the exported symbol set matches the header) ----
-#define EMP_TODO(ctx) return emp::fail((ctx), EMP_ERR_INVALID, std::string(__func__) + ": not implemented yet")
-extern "C" {
-int emp_frenet_project(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
-                       const double*, const double*, const double*, const double*, const int32_t*, double*, double*,
-                       double*, double*, double*, emp_mem) { EMP_TODO(ctx); }
-int emp_match_projection(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
-                         const int32_t*, int32_t*, double*, emp_mem) { EMP_TODO(ctx); }
-int emp_find_match_points(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const int32_t*, const double*,
-                          const int32_t*, const int32_t*, const int32_t*, int32_t*, double*, emp_mem) { EMP_TODO(ctx); }
-int emp_heading_kappa(emp_ctx* ctx, int32_t, int32_t, const double*, const int32_t*, double*, double*, emp_mem) { EMP_TODO(ctx); }
-int emp_lmin_lmax(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const double*, const int32_t*, const double*,
-                  const double*, const int32_t*, double, double, double*, double*, int32_t*, emp_mem) { EMP_TODO(ctx); }
-int emp_path_qp(emp_ctx* ctx, const emp_qp_params*, int32_t, int32_t, const double*, const double*, const int32_t*,
-                const double*, double*, double*, double*, int32_t*, int32_t*, emp_mem) { EMP_TODO(ctx); }
-int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params*, int32_t, int32_t, const double*, const int32_t*, double*,
-                    int32_t*, int32_t*, emp_mem) { EMP_TODO(ctx); }
-int emp_frenet_path_to_xy(emp_ctx* ctx, int32_t, int32_t, int32_t, const double*, const double*, const int32_t*,
-                          const double*, const double*, const double*, const int32_t*, double*, int32_t*, int32_t*,
-                          emp_mem) { EMP_TODO(ctx); }
-int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params*, const emp_qp_params*, const emp_smooth_params*, int32_t, int32_t,
-                   int32_t, int32_t, emp_dp_mode, const emp_cycle_io*, emp_mem) { EMP_TODO(ctx); }
-int emp_quintic_coefficients(emp_ctx* ctx, int32_t, const double*, double*, emp_mem) { EMP_TODO(ctx); }
-int emp_obs_cost(emp_ctx* ctx, int32_t, double, double, double, const double*, double*, emp_mem) { EMP_TODO(ctx); }
+
+// =============================================================================================
+// Frenet / QP stages and the whole cycle
+// =============================================================================================
+namespace emp {
+
+static QpDev make_qp_dev(const emp_qp_params* q) {
+    QpDev d;
+    d.qp = PathQpParams{q->ds, q->w_l, q->w_ddl, q->w_dddl, q->w_centre, q->host_d1, q->host_d2, q->host_w};
+    d.obs_length = q->obs_length;
+    d.obs_width = q->obs_width;
+    d.decimate = q->decimate > 0 ? q->decimate : 1;
+    d.midpoint = q->midpoint;
+    d.use_qp = q->use_qp;
+    return d;
 }
+
+static inline dim3 grid1(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const double* ref_line, const int* n_ref,
+                       const double* origin_xy, const double* start_xy, const double* start_v, const double* start_a,
+                       const double* obs_xy, const int* n_obs, double* s_map, double* obs_s, double* obs_l,
+                       double* begin_sl, double* start) {
+    if (B == 0) return EMP_OK;
+    KernelTimer t(ctx, "project");
+    hipLaunchKernelGGL(frenet_project_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_obs, ref_line,
+                       n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs, s_map, obs_s, obs_l, begin_sl, start);
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+#define EMP_DISPATCH_N(need, CALL)              \
+    do {                                        \
+        if ((need) <= 32) { CALL(32); }         \
+        else if ((need) <= 64) { CALL(64); }    \
+        else if ((need) <= 128) { CALL(128); }  \
+        else { CALL(256); }                     \
+    } while (0)
+
+static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpDev& Q, const double* dp_s,
+                        const double* dp_l, const int* dp_len, const double* obs_s, const double* obs_l,
+                        const int* n_obs, const double* start, double* path_s, double* path_l, int* path_len,
+                        int* status) {
+    if (B == 0) return EMP_OK;
+    const int need = (max_pts + Q.decimate - 1) / Q.decimate;
+    EMP_REQUIRE(ctx, need <= 256, "more than 256 QP stations are not supported");
+    KernelTimer t(ctx, "path_qp");
+#define CALL(N)                                                                                                    \
+    hipLaunchKernelGGL((cycle_qp_kernel<N>), grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, max_obs, Q, dp_s,   \
+                       dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status)
+    EMP_DISPATCH_N(need, CALL);
+#undef CALL
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, const emp_smooth_params* sp,
+                               const double* ref_line, const double* s_map, const int* n_ref, const double* begin_sl,
+                               const double* path_s, const double* path_l, const int* path_len, double* traj,
+                               int* traj_len, int* status) {
+    if (B == 0) return EMP_OK;
+    const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
+    const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
+    const int need = max_pts + 1;
+    EMP_REQUIRE(ctx, need <= 256, "more than 255 path points are not supported");
+    {
+        KernelTimer t(ctx, "to_cartesian");
+#define CALL(N)                                                                                                      \
+    hipLaunchKernelGGL((cycle_cartesian_kernel<N>), grid1(2 * B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts,   \
+                       sx, sy, ref_line, s_map, n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status)
+        EMP_DISPATCH_N(need, CALL);
+#undef CALL
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    KernelTimer t2(ctx, "heading");
+    hipLaunchKernelGGL(cycle_heading_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, traj_len, traj, status);
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+}  // namespace emp
+
+extern "C" {
+
+int emp_frenet_project(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_obs, const double* ref_line,
+                       const int32_t* n_ref, const double* origin_xy, const double* start_xy, const double* start_v,
+                       const double* start_a, const double* obs_xy, const int32_t* n_obs, double* s_map, double* obs_s,
+                       double* obs_l, double* begin_sl, double* start, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 2 && max_obs >= 0, "bad sizes");
+    EMP_REQUIRE(ctx, ref_line && n_ref && origin_xy && start_xy && start_v && start_a && s_map && start, "NULL argument");
+    EMP_REQUIRE(ctx, max_obs == 0 || (obs_xy && n_obs && obs_s && obs_l), "obstacle arrays required when max_obs > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
+    const int *d_nr, *d_no;
+    double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(origin_xy, (size_t)B * 2, &d_o))) return rc;
+    if ((rc = st.in(start_xy, (size_t)B * 2, &d_sxy))) return rc;
+    if ((rc = st.in(start_v, (size_t)B * 2, &d_v))) return rc;
+    if ((rc = st.in(start_a, (size_t)B * 2, &d_a))) return rc;
+    if ((rc = st.in(obs_xy, (size_t)B * max_obs * 2, &d_oxy))) return rc;
+    if ((rc = st.in(max_obs ? n_obs : nullptr, (size_t)B, &d_no))) return rc;
+    if ((rc = st.out(s_map, (size_t)B * max_ref, &d_sm))) return rc;
+    if ((rc = st.out(obs_s, (size_t)B * max_obs, &d_os))) return rc;
+    if ((rc = st.out(obs_l, (size_t)B * max_obs, &d_ol))) return rc;
+    if ((rc = st.out(begin_sl, (size_t)B * 2, &d_bsl))) return rc;
+    if ((rc = st.out(start, (size_t)B * 4, &d_start))) return rc;
+    if ((rc = dev_project(ctx, B, max_ref, max_obs, d_ref, d_nr, d_o, d_sxy, d_v, d_a, d_oxy, d_no, d_sm, d_os, d_ol,
+                          d_bsl, d_start)))
+        return rc;
+    return st.finish();
+}
+
+static int match_common(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                        const int32_t* n_ref, const double* xy, const int32_t* n_pts, const int32_t* is_first_run,
+                        const int32_t* pre_match_index, int32_t* match_index, double* proj, emp_mem where, int windowed) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 1 && max_pts >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, ref_line && n_ref && xy && n_pts && match_index && proj, "NULL argument");
+    EMP_REQUIRE(ctx, !windowed || (is_first_run && pre_match_index), "is_first_run / pre_match_index required");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_xy;
+    const int *d_nr, *d_np, *d_first, *d_pre;
+    int* d_mi;
+    double* d_pr;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(xy, (size_t)B * max_pts * 2, &d_xy))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(is_first_run, (size_t)B, &d_first))) return rc;
+    if ((rc = st.in(pre_match_index, (size_t)B, &d_pre))) return rc;
+    if ((rc = st.out(match_index, (size_t)B * max_pts, &d_mi))) return rc;
+    if ((rc = st.out(proj, (size_t)B * max_pts * 4, &d_pr))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "match");
+        hipLaunchKernelGGL(match_points_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts, d_ref, d_nr,
+                           d_xy, d_np, d_first, d_pre, d_mi, d_pr, windowed);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_match_projection(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                         const int32_t* n_ref, const double* xy, const int32_t* n_pts, int32_t* match_index,
+                         double* proj, emp_mem where) {
+    return match_common(ctx, B, max_ref, max_pts, ref_line, n_ref, xy, n_pts, nullptr, nullptr, match_index, proj, where, 0);
+}
+
+int emp_find_match_points(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                          const int32_t* n_ref, const double* xy, const int32_t* n_pts, const int32_t* is_first_run,
+                          const int32_t* pre_match_index, int32_t* match_index, double* proj, emp_mem where) {
+    return match_common(ctx, B, max_ref, max_pts, ref_line, n_ref, xy, n_pts, is_first_run, pre_match_index,
+                        match_index, proj, where, 1);
+}
+
+int emp_heading_kappa(emp_ctx* ctx, int32_t B, int32_t max_pts, const double* xy, const int32_t* n_pts, double* theta,
+                      double* kappa, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_pts >= 2 && xy && n_pts && theta && kappa, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double* d_xy;
+    const int* d_np;
+    double *d_t, *d_k;
+    if ((rc = st.in(xy, (size_t)B * max_pts * 2, &d_xy))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.out(theta, (size_t)B * max_pts, &d_t))) return rc;
+    if ((rc = st.out(kappa, (size_t)B * max_pts, &d_k))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "heading");
+        hipLaunchKernelGGL(heading_kappa_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, d_xy, d_np, d_t, d_k);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_lmin_lmax(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_t max_obs, const double* dp_s, const double* dp_l,
+                  const int32_t* n_pts, const double* obs_s, const double* obs_l, const int32_t* n_obs,
+                  double obs_length, double obs_width, double* l_min, double* l_max, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_pts >= 1 && max_obs >= 0, "bad sizes");
+    EMP_REQUIRE(ctx, dp_s && dp_l && n_pts && n_obs && l_min && l_max && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_s, *d_l, *d_os, *d_ol;
+    const int *d_np, *d_no;
+    double *d_lo, *d_hi;
+    int* d_st;
+    if ((rc = st.in(dp_s, (size_t)B * max_pts, &d_s))) return rc;
+    if ((rc = st.in(dp_l, (size_t)B * max_pts, &d_l))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(obs_s, (size_t)B * max_obs, &d_os))) return rc;
+    if ((rc = st.in(obs_l, (size_t)B * max_obs, &d_ol))) return rc;
+    if ((rc = st.in(n_obs, (size_t)B, &d_no))) return rc;
+    if ((rc = st.out(l_min, (size_t)B * max_pts, &d_lo))) return rc;
+    if ((rc = st.out(l_max, (size_t)B * max_pts, &d_hi))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "lmin_lmax");
+        hipLaunchKernelGGL(lmin_lmax_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, max_obs, d_s, d_l, d_np,
+                           d_os, d_ol, d_no, obs_length, obs_width, d_lo, d_hi, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_path_qp(emp_ctx* ctx, const emp_qp_params* q, int32_t B, int32_t max_pts, const double* l_min,
+                const double* l_max, const int32_t* n_pts, const double* start_l3, double* qp_l, double* qp_dl,
+                double* qp_ddl, int32_t* iters, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, q && B >= 0 && max_pts >= 1 && max_pts <= 256, "bad sizes (max_pts must be in [1, 256])");
+    EMP_REQUIRE(ctx, l_min && l_max && n_pts && start_l3 && qp_l && qp_dl && qp_ddl && status, "NULL argument");
+    EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_lo, *d_hi, *d_s3;
+    const int* d_np;
+    double *d_l, *d_dl, *d_ddl;
+    int *d_it, *d_st;
+    if ((rc = st.in(l_min, (size_t)B * max_pts, &d_lo))) return rc;
+    if ((rc = st.in(l_max, (size_t)B * max_pts, &d_hi))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(start_l3, (size_t)B * 3, &d_s3))) return rc;
+    if ((rc = st.out(qp_l, (size_t)B * max_pts, &d_l))) return rc;
+    if ((rc = st.out(qp_dl, (size_t)B * max_pts, &d_dl))) return rc;
+    if ((rc = st.out(qp_ddl, (size_t)B * max_pts, &d_ddl))) return rc;
+    if ((rc = st.out(iters, (size_t)B, &d_it))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        const QpDev Q = make_qp_dev(q);
+        KernelTimer t(ctx, "path_qp");
+#define CALL(N)                                                                                                  \
+    hipLaunchKernelGGL((path_qp_kernel<N>), grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, Q, d_lo, d_hi, d_np, \
+                       d_s3, d_l, d_dl, d_ddl, d_it, d_st)
+        EMP_DISPATCH_N(max_pts, CALL);
+#undef CALL
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_t max_pts, const double* xy,
+                    const int32_t* n_pts, double* out, int32_t* iters, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, sp && B >= 0 && max_pts >= 2 && max_pts <= 256, "bad sizes (max_pts must be in [2, 256])");
+    EMP_REQUIRE(ctx, xy && n_pts && out && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double* d_xy;
+    const int* d_np;
+    double* d_out;
+    int *d_it, *d_st;
+    if ((rc = st.in(xy, (size_t)B * max_pts * 2, &d_xy))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.out(out, (size_t)B * max_pts * 4, &d_out))) return rc;
+    if ((rc = st.out(iters, (size_t)B, &d_it))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        EMP_HIP(ctx, hipMemsetAsync(d_st, 0, (size_t)B * sizeof(int), ctx->stream));
+        const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
+        const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
+        {
+            KernelTimer t(ctx, "smooth");
+#define CALL(N)                                                                                                    \
+    hipLaunchKernelGGL((smooth_kernel<N>), grid1(2 * B, 64), dim3(64), 0, ctx->stream, B, max_pts, sx, sy, d_xy, d_np, \
+                       d_out, d_it, d_st)
+            EMP_DISPATCH_N(max_pts, CALL);
+#undef CALL
+            EMP_LAUNCH_CHECK(ctx);
+        }
+        KernelTimer t2(ctx, "heading");
+        hipLaunchKernelGGL(traj_heading_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, d_np, d_out, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_frenet_path_to_xy(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                          const double* s_map, const int32_t* n_ref, const double* begin_sl, const double* path_s,
+                          const double* path_l, const int32_t* n_pts, double* target_xy, int32_t* n_out,
+                          int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 2 && max_pts >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, ref_line && s_map && n_ref && begin_sl && path_s && path_l && n_pts && target_xy && n_out && status,
+                "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_sm, *d_b, *d_ps, *d_pl;
+    const int *d_nr, *d_np;
+    double* d_t;
+    int *d_no, *d_st;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(s_map, (size_t)B * max_ref, &d_sm))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(begin_sl, (size_t)B * 2, &d_b))) return rc;
+    if ((rc = st.in(path_s, (size_t)B * max_pts, &d_ps))) return rc;
+    if ((rc = st.in(path_l, (size_t)B * max_pts, &d_pl))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.out(target_xy, (size_t)B * (max_pts + 1) * 2, &d_t))) return rc;
+    if ((rc = st.out(n_out, (size_t)B, &d_no))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "path_to_xy");
+        hipLaunchKernelGGL(path_to_xy_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts, d_ref, d_sm,
+                           d_nr, d_b, d_ps, d_pl, d_np, d_t, d_no, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q, const emp_smooth_params* sp, int32_t B,
+                   int32_t max_ref, int32_t max_obs, int32_t max_pts, emp_dp_mode mode, const emp_cycle_io* io,
+                   emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p && q && sp && io, "NULL parameter struct");
+    DpDev d;
+    int rc = make_dp_dev(ctx, p, B, max_obs, &d);
+    if (rc) return rc;
+    EMP_REQUIRE(ctx, max_ref >= 2 && max_pts >= 2 && max_pts <= 255, "max_ref >= 2 and 2 <= max_pts <= 255 required");
+    EMP_REQUIRE(ctx, io->ref_line && io->n_ref && io->origin_xy && io->start_xy && io->start_v && io->start_a,
+                "cycle inputs missing");
+    EMP_REQUIRE(ctx, max_obs == 0 || (io->obs_xy && io->n_obs), "obstacle inputs missing");
+    EMP_REQUIRE(ctx, io->traj && io->traj_len && io->status, "traj, traj_len and status are required outputs");
+    EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
+    const int *d_nr, *d_no;
+    if ((rc = st.in(io->ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(io->n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(io->origin_xy, (size_t)B * 2, &d_o))) return rc;
+    if ((rc = st.in(io->start_xy, (size_t)B * 2, &d_sxy))) return rc;
+    if ((rc = st.in(io->start_v, (size_t)B * 2, &d_v))) return rc;
+    if ((rc = st.in(io->start_a, (size_t)B * 2, &d_a))) return rc;
+    if ((rc = st.in(io->obs_xy, (size_t)B * max_obs * 2, &d_oxy))) return rc;
+    if ((rc = st.in(io->n_obs, (size_t)B, &d_no))) return rc;
+    // outputs (optional ones fall back to device temporaries)
+    double *d_rows, *d_dps, *d_dpl, *d_ps, *d_pl, *d_traj;
+    int *d_dplen, *d_plen, *d_tlen, *d_st;
+    if ((rc = st.out(io->dp_rows, (size_t)B * d.col, &d_rows))) return rc;
+    if (!d_rows && (rc = st.tmp((size_t)B * d.col, &d_rows))) return rc;
+    if ((rc = st.out(io->dp_s, (size_t)B * max_pts, &d_dps))) return rc;
+    if (!d_dps && (rc = st.tmp((size_t)B * max_pts, &d_dps))) return rc;
+    if ((rc = st.out(io->dp_l, (size_t)B * max_pts, &d_dpl))) return rc;
+    if (!d_dpl && (rc = st.tmp((size_t)B * max_pts, &d_dpl))) return rc;
+    if ((rc = st.out(io->dp_len, (size_t)B, &d_dplen))) return rc;
+    if (!d_dplen && (rc = st.tmp((size_t)B, &d_dplen))) return rc;
+    if ((rc = st.out(io->path_s, (size_t)B * max_pts, &d_ps))) return rc;
+    if (!d_ps && (rc = st.tmp((size_t)B * max_pts, &d_ps))) return rc;
+    if ((rc = st.out(io->path_l, (size_t)B * max_pts, &d_pl))) return rc;
+    if (!d_pl && (rc = st.tmp((size_t)B * max_pts, &d_pl))) return rc;
+    if ((rc = st.out(io->path_len, (size_t)B, &d_plen))) return rc;
+    if (!d_plen && (rc = st.tmp((size_t)B, &d_plen))) return rc;
+    if ((rc = st.out(io->traj, (size_t)B * (max_pts + 1) * 4, &d_traj))) return rc;
+    if ((rc = st.out(io->traj_len, (size_t)B, &d_tlen))) return rc;
+    if ((rc = st.out(io->status, (size_t)B, &d_st))) return rc;
+    // intermediates
+    double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
+    const int mo = max_obs > 0 ? max_obs : 1;
+    if ((rc = st.tmp((size_t)B * max_ref, &d_sm))) return rc;
+    if ((rc = st.tmp((size_t)B * mo, &d_os))) return rc;
+    if ((rc = st.tmp((size_t)B * mo, &d_ol))) return rc;
+    if ((rc = st.tmp((size_t)B * 2, &d_bsl))) return rc;
+    if ((rc = st.tmp((size_t)B * 4, &d_start))) return rc;
+    int* d_zero_nobs = nullptr;
+    if (max_obs == 0) {
+        if ((rc = st.tmp((size_t)B, &d_zero_nobs, true))) return rc;
+        d_no = d_zero_nobs;
+    }
+    if (B == 0) return st.finish();
+    if ((rc = dev_project(ctx, B, max_ref, max_obs, d_ref, d_nr, d_o, d_sxy, d_v, d_a, d_oxy, d_no, d_sm, d_os, d_ol,
+                          d_bsl, d_start)))
+        return rc;
+    if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
+    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
+    const QpDev Q = make_qp_dev(q);
+    if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
+                           d_st)))
+        return rc;
+    if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen, d_traj,
+                                  d_tlen, d_st)))
+        return rc;
+    return st.finish();
+}
+
+int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* coeff, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && bc && coeff, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double* d_bc;
+    double* d_c;
+    if ((rc = st.in(bc, (size_t)n * 8, &d_bc))) return rc;
+    if ((rc = st.out(coeff, (size_t)n * 6, &d_c))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(quintic_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, d_bc, d_c);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis, const double* square_d,
+                 double* cost, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && square_d && cost, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double* d_sq;
+    double* d_c;
+    if ((rc = st.in(square_d, (size_t)n * 10, &d_sq))) return rc;
+    if ((rc = st.out(cost, (size_t)n, &d_c))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(obs_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, w_collision, danger_dis, safe_dis,
+                           d_sq, d_c);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""GPU parity: Cartesian<->Frenet, QP stages and the whole planning cycle through the C-ABI.
+
+Reference side = golden vectors of the imported reference (tests/golden), tolerance 1e-6 relative with
+the magnitude floors written at each check (the north-star tolerance).  QP outputs are additionally
+certified against the reference's own dense formulation (KKT certificate of oracle/qp_dense.py),
+because the reference's solver (cvxopt) is absent and unpinned.
+"""
+import numpy as np
+import pytest
+
+from emplanner_carla_amd import scenes as S
+from oracle import qp_dense
+from oracle import ref_port as op
+from tests.conftest import assert_rel, load_golden
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+GOLD = {"cfg1": (S.CFG1, "cycle_cfg1_20x5_0obs.npz", {}),
+        "default": (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz", {}),
+        "cfg2": (S.CFG2, "cycle_cfg2_40x9_8obs.npz", {}),
+        "default_t7": (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t7.npz", dict(decimate=1, midpoint=0)),
+        "default_t6": (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t6.npz", dict(decimate=1, midpoint=0, use_qp=0))}
+
+
+@pytest.fixture(scope="module")
+def planner():
+    from emplanner_carla_amd.api import Planner
+    p = Planner(0)
+    yield p
+    p.close()
+
+
+def _inputs(g):
+    B, P = g["in_ref"].shape[:2]
+    return dict(ref_line=g["in_ref"], n_ref=np.full(B, P, np.int32), origin_xy=g["in_origin_xy"],
+                start_xy=g["in_start_xy"], start_v=g["in_start_v"], start_a=g["in_start_a"],
+                obs_xy=g["in_obs_xy"], n_obs=g["in_n_obs"].astype(np.int32))
+
+
+@pytest.mark.parametrize("key", ["cfg1", "default", "cfg2"])
+def test_frenet_project_vs_reference(planner, key):
+    cfg, fname, _ = GOLD[key]
+    g = load_golden(fname)
+    i = _inputs(g)
+    sm, os_, ol_, bsl, start = planner.frenet_project(**i)
+    assert_rel(sm, g["s_map"], RTOL, 1.0, "s_map")
+    for b in range(len(sm)):
+        k = int(i["n_obs"][b])
+        assert_rel(os_[b, :k], g["obs_s"][b, :k], RTOL, 1.0, "obs_s")
+        assert_rel(ol_[b, :k], g["obs_l"][b, :k], RTOL, 1.0, "obs_l")
+    assert_rel(bsl, g["begin"], RTOL, 1.0, "begin s,l")
+    assert_rel(start[:, :2], g["start"][:, :2], RTOL, 1.0, "start s,l")
+    assert_rel(start[:, 2], g["start"][:, 2], RTOL, 1e-1, "start dl/ds")        # |dl| <= 0.05: floor 0.1
+    assert_rel(start[:, 3], g["start"][:, 3], RTOL, 1e-1, "start d2l/ds2")
+
+
+def test_match_and_heading_functions(planner):
+    g = load_golden("functions.npz")
+    path = g["mp_path"][None]
+    n_ref = np.array([path.shape[1]], np.int32)
+    pts = g["mp_pts"][None]
+    mi, pr = planner.match_projection(path, n_ref, pts, np.array([pts.shape[1]], np.int32))
+    assert np.array_equal(mi[0], g["mp_index"])
+    assert_rel(pr[0], g["mp_proj"], RTOL, 1.0, "projection")
+    for mode, out in zip(g["fm_modes"], g["fm_out"]):
+        mi, pr = planner.find_match_points(path, n_ref, pts[:, :3], np.array([3], np.int32),
+                                           np.array([int(mode[0])], np.int32), np.array([int(mode[1])], np.int32))
+        assert np.array_equal(mi[0].astype(np.float64), out[:3])
+        assert_rel(pr[0].reshape(-1), out[3:], RTOL, 1.0, "find_match_points projection")
+    th, kp = planner.heading_kappa(g["hk_xy"][None], np.array([len(g["hk_xy"])], np.int32))
+    assert_rel(th[0], g["hk_theta"], RTOL, 1.0, "theta")
+    assert_rel(kp[0], g["hk_kappa"], RTOL, 1.0, "kappa")
+    # ragged batch: two polylines of different length in one call
+    xy = np.zeros((2, 40, 2))
+    xy[0, :37] = g["hk_xy"]
+    xy[1, :20] = g["hk_xy"][:20]
+    th, kp = planner.heading_kappa(xy, np.array([37, 20], np.int32))
+    t20, k20 = op.cal_heading_kappa([tuple(p) for p in g["hk_xy"][:20]])
+    assert_rel(th[0, :37], g["hk_theta"], RTOL, 1.0)
+    assert_rel(th[1, :20], t20, RTOL, 1.0)
+    assert_rel(kp[1, :20], k20, RTOL, 1.0)
+
+
+def test_scalar_utilities(planner):
+    g = load_golden("functions.npz")
+    c = planner.quintic_coefficients(g["quintic_bc"])
+    for b, coef, v in zip(g["quintic_bc"], c, g["quintic_vals"]):
+        ts = np.linspace(b[6], b[7], 11)
+        # compare the polynomial on its segment: the reference's raw coefficients are the
+        # ill-conditioned part of its route (they cancel to ~1e-7 absolute in the evaluation)
+        got = sum(coef[k] * ts ** k for k in range(6))
+        assert_rel(got, v, RTOL, 1.0, "quintic on segment")
+    assert np.array_equal(planner.obs_cost(g["obs_sq"], 1e12), g["obs_cost"])
+    assert np.array_equal(planner.obs_cost(g["obs_sq"], 7.5, danger_dis=3, safe_dis=5), g["obs_cost_w3"])
+
+
+def test_lmin_lmax_and_index_error(planner):
+    cfg, fname, _ = GOLD["cfg2"]
+    g = load_golden(fname)
+    B = len(g["seeds"])
+    nq = g["n_qp"].astype(np.int32)
+    M = 24
+    dps = np.zeros((B, M))
+    dpl = np.zeros((B, M))
+    for b in range(B):
+        n = int(g["dp_len"][b])
+        dps[b, :nq[b]] = g["dp_s"][b, :n][::2]
+        dpl[b, :nq[b]] = g["dp_l"][b, :n][::2]
+    lo, hi, st = planner.lmin_lmax(dps, dpl, nq, np.nan_to_num(g["obs_s"]), np.nan_to_num(g["obs_l"]),
+                                   g["in_n_obs"].astype(np.int32), 5, 5)
+    for b in range(B):
+        assert st[b] == 0
+        assert np.array_equal(lo[b, :nq[b]], g["l_min"][b, :nq[b]])
+        assert np.array_equal(hi[b, :nq[b]], g["l_max"][b, :nq[b]])
+    # an obstacle mapped within two stations of the path end: the reference raises IndexError (:267/:272)
+    obs_s = np.array([[dps[0, nq[0] - 1] - 1.0]])
+    with pytest.raises(IndexError):
+        op.cal_lmin_lmax(list(dps[0, :nq[0]]), list(dpl[0, :nq[0]]), [obs_s[0, 0]], [3.0], 5, 5)
+    lo, hi, st = planner.lmin_lmax(dps[:1], dpl[:1], nq[:1], obs_s, np.array([[3.0]]), np.array([1], np.int32), 5, 5)
+    assert st[0] == 4
+
+
+@pytest.mark.parametrize("key", ["cfg2", "default", "default_t7"])
+def test_path_qp_vs_reference_formulation(planner, key):
+    from emplanner_carla_amd.api import qp_params
+    cfg, fname, mode = GOLD[key]
+    g = load_golden(fname)
+    B = len(g["seeds"])
+    ok = ~np.isnan(g["l_min"][:, 0])
+    nq = g["n_qp"].astype(np.int32)
+    M = int(nq.max())
+    lo = np.nan_to_num(g["l_min"][:, :M])
+    hi = np.nan_to_num(g["l_max"][:, :M])
+    l, dl, ddl, iters, st = planner.path_qp(qp_params(), lo, hi, nq, g["start"][:, 1:].copy())
+    n_checked = 0
+    for b in np.nonzero(ok)[0]:
+        n = nq[b]
+        if g["status"][b] == 4:
+            assert st[b] == 8, "reference formulation infeasible -> EMP_ST_QP_FAILED"
+            continue
+        assert st[b] == 0 and iters[b] <= 40
+        assert_rel(l[b, :n], g["qp_l"][b, :n], RTOL, 1.0, "qp_l")
+        assert_rel(dl[b, :n], g["qp_dl"][b, :n], RTOL, 1.0, "qp_dl")
+        assert_rel(ddl[b, :n], g["qp_ddl"][b, :n], RTOL, 1.0, "qp_ddl")
+        if n_checked < 4:      # solver-independent certificate against the reference's dense matrices
+            H, f, G, h, A, bb = op.path_qp_matrices(lo[b, :n], hi[b, :n], *g["start"][b, 1:])
+            x = np.stack([l[b, :n], dl[b, :n], ddl[b, :n]], axis=1).reshape(-1)
+            cert = qp_dense.kkt_certificate(H, f, G, h, A, bb, x)
+            assert cert["stationarity"] < 1e-7 and cert["ineq_violation"] < 1e-9 and cert["eq_violation"] < 1e-9
+        n_checked += 1
+    assert n_checked >= 5
+
+
+def test_smooth_line_reference_line_size(planner):
+    """smooth_reference_line on 51-point lines (the size motion_planning smooths, test_9.py:110)."""
+    from emplanner_carla_amd.api import smooth_params
+    rng = np.random.default_rng(21)
+    B, m = 6, 51
+    xy = np.zeros((B, 64, 2))
+    n_pts = np.array([51, 51, 30, 2, 51, 17], np.int32)
+    want = []
+    for b in range(B):
+        t = np.arange(n_pts[b]) * 2.0
+        pts = np.stack([t * np.cos(0.3 * b) + rng.normal(0, 0.15, n_pts[b]),
+                        t * np.sin(0.3 * b) + 15 * np.sin(t / 40.0) + rng.normal(0, 0.15, n_pts[b])], axis=1)
+        xy[b, :n_pts[b]] = pts
+        want.append(np.asarray(op.smooth_reference_line([tuple(p) for p in pts]), dtype=np.float64))
+    out, iters, st = planner.smooth_line(smooth_params(), xy, n_pts)
+    assert (st == 0).all()
+    for b in range(B):
+        n = n_pts[b]
+        assert_rel(out[b, :n, :2], want[b][:, :2], RTOL, 1.0, "smoothed xy")
+        assert_rel(out[b, :n, 2], want[b][:, 2], RTOL, 1.0, "theta")
+        assert_rel(out[b, :n, 3], want[b][:, 3], RTOL, 1e-2, "kappa")
+
+
+@pytest.mark.parametrize("key", list(GOLD))
+def test_full_cycle_vs_reference(planner, key):
+    """emp_plan_cycle == reference motion_planning body (test_9 / test_7 / test_6 driver forms)."""
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg, fname, mode = GOLD[key]
+    g = load_golden(fname)
+    q = qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width, **mode)
+    r = planner.plan_cycle(dp_params_from_cfg(cfg), q, smooth_params(), **_inputs(g))
+    B = len(g["seeds"])
+    n_traj = 0
+    for b in range(B):
+        n = int(g["dp_len"][b])
+        assert r.dp_len[b] == n
+        assert np.array_equal(r.dp_s[b, :n], g["dp_s"][b, :n]) or np.allclose(r.dp_s[b, :n], g["dp_s"][b, :n], rtol=RTOL)
+        assert_rel(r.dp_l[b, :n], g["dp_l"][b, :n], RTOL, 1.0, "dp_l")
+        assert bool(r.status[b] & 1) == bool(g["dp_infeasible_banner"][b])
+        if g["status"][b] == 4:
+            assert r.status[b] & 8 and r.traj_len[b] == 0
+            continue
+        assert g["status"][b] == 0 and (r.status[b] & ~1) == 0, f"scene {b}: status {r.status[b]}"
+        m = int(g["traj_len"][b])
+        assert r.traj_len[b] == m and r.path_len[b] == m - 1
+        assert_rel(r.path_s[b, :m - 1], g["path_s"][b, :m - 1], RTOL, 1.0, "path_s")
+        assert_rel(r.path_l[b, :m - 1], g["path_l"][b, :m - 1], RTOL, 1.0, "path_l")
+        assert_rel(r.traj[b, :m, :3], g["traj"][b, :m, :3], RTOL, 1.0, "x, y, theta")
+        assert_rel(r.traj[b, :m, 3], g["traj"][b, :m, 3], RTOL, 1e-2, "kappa")   # |kappa| ~ 1e-3..1e-1 1/m
+        n_traj += 1
+    assert n_traj >= 5
+
+
+def test_cycle_batch_properties_and_device_tensors(planner):
+    """BASELINE configs[2] shape on 1024 scenes, inputs resident on the GPU (torch tensors):
+    size-independent properties + agreement with the host-pointer path."""
+    import torch
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg = S.CFG2
+    b = S.make_batch(range(5000, 6024), cfg)
+    B, P = b.ref.shape[:2]
+    host = dict(ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy,
+                start_v=b.start_v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(), smooth_params()
+    r = planner.plan_cycle(p, q, sp, **host)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in host.items()}
+    rd = planner.plan_cycle(p, q, sp, **dev)
+    planner.synchronize()
+    for name in ("dp_rows", "dp_l", "path_l", "traj", "traj_len", "status"):
+        assert np.array_equal(getattr(rd, name).cpu().numpy(), getattr(r, name)), name
+    ok = (r.status & ~1) == 0
+    assert ok.mean() > 0.6 and (r.status & 8).any(), "mostly drivable scenes plus some infeasible QPs"
+    # un-smoothed targets of every scene, to check the smoothing QP's +-0.2 m box
+    sm, _, _, bsl, _ = planner.frenet_project(**host)
+    tgt, cnt, st = planner.frenet_path_to_xy(b.ref, sm, host["n_ref"], bsl, r.path_s, r.path_l, r.path_len)
+    for i in np.nonzero(ok)[0]:
+        m = r.traj_len[i]
+        n = r.path_len[i]
+        assert m == n + 1 == 23 and cnt[i] == m
+        # the path QP honours its pinned end state: the last station sits on the reference line
+        assert abs(r.path_l[i, n - 1]) < 1e-9
+        x = r.traj[i, :m]
+        assert np.isfinite(x).all()
+        assert (np.abs(x[:, :2] - tgt[i, :m]) <= 0.2 + 1e-9).all(), "smoothed point left its box"
+        seg = np.hypot(np.diff(x[:, 0]), np.diff(x[:, 1]))
+        assert (seg[1:] > 0.5).all() and (seg < 6.0).all(), "consecutive trajectory points 2.5-5 m apart"
+        assert (np.abs(x[:, 3]) < 0.5).all()
+
+
+def test_cycle_edge_cases(planner):
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg = S.CFG_DEFAULT
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(), smooth_params()
+    b = S.make_batch(range(3), cfg)
+    B, P = b.ref.shape[:2]
+    base = dict(ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy,
+                start_v=b.start_v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+    # empty batch
+    e = {k: v[:0] for k, v in base.items()}
+    r = planner.plan_cycle(p, q, sp, **e)
+    assert r.traj.shape[0] == 0
+    # a reference line too short for the DP horizon: the reference truncates at s_map[-1] (path_planning.py:40)
+    short = dict(base)
+    short["n_ref"] = np.full(B, 30, np.int32)
+    r = planner.plan_cycle(p, q, sp, **short)
+    want = op.plan_cycle([tuple(x) for x in b.ref[0, :30]], b.origin_xy[0], b.start_xy[0], b.start_v[0], b.start_a[0],
+                         b.obs_xy[0, :b.n_obs[0]], dp_kwargs=dict(sampling_res=cfg.sampling_res, row=cfg.row,
+                                                                  col=cfg.col, sample_s=cfg.sample_s,
+                                                                  sample_l=cfg.sample_l), verbose=False)
+    m = len(want["trajectory"])
+    assert r.traj_len[0] == m and m < 26
+    assert_rel(r.traj[0, :m, :3], np.asarray(want["trajectory"], dtype=np.float64)[:, :3], RTOL, 1.0, "truncated traj")
+    # capacity too small -> flagged, nothing written out of bounds
+    r = planner.plan_cycle(p, q, sp, max_pts=20, **base)
+    assert (r.status & 32).all() and (r.traj_len == 0).all()
