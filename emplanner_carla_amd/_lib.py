@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libemplanner.so")
@@ -103,6 +104,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, the
+    # same as /opt/rocm's).  If torch is imported AFTER this library, the loader maps a second copy and that
+    # copy finds no GPU.  Importing torch first makes our DT_NEEDED resolve to the already-loaded runtime.
+    if "torch" not in sys.modules and os.environ.get("EMP_SKIP_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m emplanner_carla_amd.build` "

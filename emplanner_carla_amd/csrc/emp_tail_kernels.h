@@ -282,7 +282,7 @@ __global__ void cycle_qp_kernel(int B, int max_pts, int max_obs, QpDev Q, const 
     double* pl = path_l + o;
     int st = status[b];
     path_len[b] = 0;
-    if (n > NMAX || n + 1 > max_pts) {
+    if (n > NMAX || n + (Q.midpoint ? 1 : 0) > max_pts) {
         status[b] = st | kStTruncated;
         return;
     }

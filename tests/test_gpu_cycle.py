@@ -87,10 +87,16 @@ def test_scalar_utilities(planner):
     c = planner.quintic_coefficients(g["quintic_bc"])
     for b, coef, v in zip(g["quintic_bc"], c, g["quintic_vals"]):
         ts = np.linspace(b[6], b[7], 11)
-        # compare the polynomial on its segment: the reference's raw coefficients are the
-        # ill-conditioned part of its route (they cancel to ~1e-7 absolute in the evaluation)
-        got = sum(coef[k] * ts ** k for k in range(6))
-        assert_rel(got, v, RTOL, 1.0, "quintic on segment")
+        # Compare the polynomial on its segment, not raw coefficients.  In the absolute-s basis the
+        # terms c_k s^k reach ~1e9 and cancel to O(1): the golden values (reference coefficients evaluated
+        # in float64) carry a rounding error of a few eps * sum|c_k s^k| by construction.  We evaluate OUR
+        # coefficients in extended precision and allow exactly that error bound on top of 1e-6 relative.
+        tl_ = ts.astype(np.longdouble)
+        got = sum(np.longdouble(coef[k]) * tl_ ** k for k in range(6)).astype(np.float64)
+        mag = sum(np.abs(coef[k]) * np.abs(ts) ** k for k in range(6))
+        err = np.abs(got - v)
+        assert (err <= RTOL * np.maximum(np.abs(v), 1.0) + 16 * np.finfo(float).eps * mag).all(), \
+            f"quintic on segment: {err.max():.3e}"
     assert np.array_equal(planner.obs_cost(g["obs_sq"], 1e12), g["obs_cost"])
     assert np.array_equal(planner.obs_cost(g["obs_sq"], 7.5, danger_dis=3, safe_dis=5), g["obs_cost_w3"])
 
@@ -238,7 +244,9 @@ def test_cycle_batch_properties_and_device_tensors(planner):
         assert (np.abs(x[:, :2] - tgt[i, :m]) <= 0.2 + 1e-9).all(), "smoothed point left its box"
         seg = np.hypot(np.diff(x[:, 0]), np.diff(x[:, 1]))
         assert (seg[1:] > 0.5).all() and (seg < 6.0).all(), "consecutive trajectory points 2.5-5 m apart"
-        assert (np.abs(x[:, 3]) < 0.5).all()
+        # (points 0 and 1 nearly coincide - the reference prepends the planning start, path_planning.py:31-34 -
+        # so heading / curvature there are ill-defined in the reference too)
+        assert (np.abs(x[2:, 3]) < 0.5).all()
 
 
 def test_cycle_edge_cases(planner):
