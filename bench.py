@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py - planning cycles/s of the MI355X EM-Planner hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the whole planning cycle (projection -> S-L lattice DP -> QP bounds -> path QP ->
+midpoints -> Frenet->Cartesian -> smoothing QP -> heading/kappa; reference test_9.py:113-218) over one batch
+of synthetic scenes per GPU, with every input already resident in HBM.  Workload = BASELINE.json
+configs[2] on one GPU (4096 scenes, 40x9 lattice, 8 obstacles) and configs[3] across GPUs (weak scaling:
+4096 scenes per GPU, i.e. 32768 at 8 GPUs), plus the RCCL gather of the result records when N > 1.
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      the DP min-plus sweep kernel (HBM bound): algorithmic bytes / mean HIP-event duration
+  cpu_baseline  the reference-structured CPU port (oracle/ref_port.py), one core, bounded sample
+  kernels_ms    mean duration of every kernel of the cycle in the timed region
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(cfg, n_scenes, seed0):
+    """Time the reference-structured CPU path (the oracle's faithful port) on a bounded sample."""
+    import contextlib
+    import io
+    from emplanner_carla_amd import scenes as S
+    from oracle import ref_port as op
+    kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
+    scenes = [S.make_scene(seed0 + i, cfg) for i in range(n_scenes)]
+    t0 = time.perf_counter()
+    done = 0
+    for sc in scenes:
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                op.plan_cycle([tuple(r) for r in sc.ref], sc.origin_xy, sc.start_xy, sc.start_v, sc.start_a, sc.obs_xy,
+                              dp_kwargs=kw, obs_length=cfg.obs_length, obs_width=cfg.obs_width, verbose=False)
+        except IndexError:
+            pass
+        done += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "planning cycles/s", "cores": 1, "kind": "port",
+            "sample": f"{done} scenes of the same workload (seeds {seed0}..{seed0 + done - 1}), oracle/ref_port.py "
+                      f"plan_cycle (reference-structured NumPy path; QP by oracle/qp_dense.py, not cvxopt), "
+                      f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes-per-gpu", type=int, default=4096)
+    ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=24)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd import dist as emp_dist
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import (Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = S.CFG2
+    B = args.scenes_per_gpu
+    total = B * world
+    start, count = emp_dist.shard_range(total, rank, world)
+    batch = S.make_batch(range(start, start + count), cfg)
+    P = batch.ref.shape[1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(count, P, np.int32)), origin_xy=t(batch.origin_xy),
+                  start_xy=t(batch.start_xy), start_v=t(batch.start_v), start_a=t(batch.start_a),
+                  obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
+    torch.cuda.synchronize()
+
+    pl = Planner(local_rank)
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+    M = max_path_points(p)
+    mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
+    ts = pl.torch_stream()
+
+    def step():
+        res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
+        if world > 1:
+            with torch.cuda.stream(ts):     # RCCL gather ordered after the planner's kernels, same stream
+                rec = emp_dist.pack_records(res, p.col, M)
+                return emp_dist.gather_records(rec, total)
+        return res
+
+    def fence():
+        pl.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    pl.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    kernels = {}
+    for name in ("project", "dp_edge", "dp_sweep", "dp_fused", "dp_enrich", "path_qp", "to_cartesian", "heading"):
+        ms = pl.kernel_ms(name)
+        if ms >= 0:
+            kernels[name] = round(ms, 6)
+    pl.set_timing(False)
+
+    # outcome statistics of the last step (sanity: the work was really done)
+    if world > 1:
+        st = emp_dist.unpack_records(out, p.col, M)["status"].cpu().numpy()
+    else:
+        st = out.status.cpu().numpy()
+    ok_frac = float(((st & ~1) == 0).mean())
+
+    if rank == 0:
+        E = cfg.row + (cfg.col - 1) * cfg.row ** 2
+        bytes_dp = (8 * E + 4 * cfg.row * cfg.col + 4 * cfg.col) * count          # SURVEY.md 8(d), per launch
+        roof = None
+        if "dp_sweep" in kernels:
+            ach = bytes_dp / (kernels["dp_sweep"] * 1e-3) / 1e9
+            traffic = None
+            side = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(side):
+                try:
+                    tj = json.load(open(side))
+                    if tj.get("scenes_per_gpu") == count and tj.get("kernel") == "dp_sweep":
+                        traffic = tj.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"kernel": "dp_sweep_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": bytes_dp, "launches_timed": pl.kernel_launches("dp_sweep"),
+                    "mean_launch_us": round(kernels["dp_sweep"] * 1e3, 2)}
+        value = total * args.steps / elapsed
+        line = {
+            "metric": "planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)", "value": round(value, 1),
+            "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[3]: full planning cycle per scene (projection, S-L DP, path QP, "
+                                   "Frenet->Cartesian, smoothing QP, heading/kappa), inputs resident in HBM"
+                                   + ("; + RCCL all_gather of result records" if world > 1 else ""),
+                       "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
+                       "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
+                       "ref_line_points": int(P), "qp_stations": 21, "dp_mode": args.dp_mode,
+                       "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
+            "roofline": roof,
+            "kernels_ms": kernels,
+            "scenes_fully_planned_frac": round(ok_frac, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, 0)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    pl.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "emp_copy_to_host": (C.c_int, [_vp, _vp, _vp, _u64]),
     "emp_set_timing": (C.c_int, [_vp, C.c_int]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
+    "emp_kernel_launches": (C.c_int, [_vp, C.c_char_p]),
     "emp_edge_tensor_elems": (_u64, [C.POINTER(DpParams), _i32, C.c_int]),
     "emp_dp_edge_costs": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                     C.c_int]),
@@ -82,6 +83,7 @@ PROTOTYPES = {
                               C.c_int]),
     "emp_dp_sweep": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "emp_dp_enrich": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_enrich_nodes": (C.c_int, [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int]),
     "emp_frenet_project": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 13 + [C.c_int]),
     "emp_match_projection": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 6 + [C.c_int]),
     "emp_find_match_points": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int]),
@@ -92,6 +94,13 @@ PROTOTYPES = {
     "emp_frenet_path_to_xy": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 10 + [C.c_int]),
     "emp_plan_cycle": (C.c_int, [_vp, C.POINTER(DpParams), C.POINTER(QpParams), C.POINTER(SmoothParams), _i32, _i32,
                                  _i32, _i32, C.c_int, C.POINTER(CycleIO), C.c_int]),
+    "emp_s_map": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_s_l": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int]),
+    "emp_s_l_deri": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int]),
+    "emp_proj_point": (C.c_int, [_vp, _i32, _i32] + [_vp] * 8 + [C.c_int]),
+    "emp_trajectory_index2s": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, C.c_int]),
+    "emp_frenet2cartesian": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 7 + [_i32, C.c_int]),
+    "emp_dy_obs_deri": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
 }

@@ -69,6 +69,8 @@ class _Args:
             self.device = next(x.device for x in inputs if _is_torch(x))
             if self.device.type != "cuda":
                 raise ValueError("torch tensors passed to the planner must live on the GPU")
+            # inputs may still be in flight on torch's stream; our kernels run on the context's own stream
+            torch.cuda.current_stream(self.device).synchronize()
         self.where = L.EMP_DEVICE if self.torch else L.EMP_HOST
 
     def inp(self, x, dtype, shape=None):
@@ -93,7 +95,9 @@ class _Args:
     def out(self, shape, dtype):
         if self.torch:
             td = {np.float64: self.t.float64, np.int32: self.t.int32}[dtype]
-            a = self.t.zeros(tuple(shape), dtype=td, device=self.device)
+            # empty, not zeros: a fill kernel on torch's stream would race with ours; the library zero-fills
+            # its outputs on the context's stream
+            a = self.t.empty(tuple(shape), dtype=td, device=self.device)
             return a, C.c_void_p(a.data_ptr())
         a = np.zeros(tuple(shape), dtype=dtype)
         return a, C.c_void_p(a.ctypes.data)
@@ -150,11 +154,22 @@ class Planner:
         self._check(self._lib.emp_set_timing(self._h, int(bool(enabled))))
 
     def kernel_ms(self, name: str) -> float:
+        """Mean duration (ms) of the launches of kernel ``name`` since set_timing(True); < 0 if none."""
         return float(self._lib.emp_kernel_ms(self._h, name.encode()))
+
+    def kernel_launches(self, name: str) -> int:
+        return int(self._lib.emp_kernel_launches(self._h, name.encode()))
 
     @property
     def stream(self):
+        """Raw hipStream_t of the context."""
         return self._lib.emp_stream(self._h)
+
+    def torch_stream(self):
+        """The context's stream as a torch stream: ``with torch.cuda.stream(pl.torch_stream()):`` orders torch
+        work (e.g. an RCCL gather of the results) after the planner's kernels without a host sync."""
+        import torch
+        return torch.cuda.ExternalStream(int(self.stream), device=torch.device("cuda", self.device_id))
 
     # ---- DP ------------------------------------------------------------------------------
     def edge_tensor_elems(self, p: DpParams, B: int, layout=L.EMP_EDGE_CANONICAL) -> int:
@@ -214,6 +229,19 @@ class Planner:
             int(max_pts), psp, plp, lnp, sp, a.where))
         return ps, pl, ln, st
 
+    def enrich_nodes(self, node_s, node_l, n_nodes, start, resolution, max_pts: int):
+        """ref enrich_DP_s_l on explicit node lists: returns path_s, path_l (B,max_pts), path_len, status."""
+        a = _Args(node_s, node_l, start)
+        B, K = int(node_s.shape[0]), int(node_s.shape[1])
+        ps, psp = a.out((B, max_pts), np.float64)
+        pl, plp = a.out((B, max_pts), np.float64)
+        ln, lnp = a.out((B,), np.int32)
+        st, sp = a.out((B,), np.int32)
+        self._check(self._lib.emp_enrich_nodes(
+            self._h, B, K, float(resolution), a.inp(node_s, np.float64, (B, K)), a.inp(node_l, np.float64, (B, K)),
+            a.inp(n_nodes, np.int32, (B,)), a.inp(start, np.float64, (B, 4)), int(max_pts), psp, plp, lnp, sp, a.where))
+        return ps, pl, ln, st
+
     # ---- Cartesian <-> Frenet -------------------------------------------------------------
     def frenet_project(self, ref_line, n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs):
         """ref cal_s_map_fun + cal_s_l_fun (obstacles, start) + cal_s_l_deri_fun (start): test_9.py:113-177.
@@ -266,6 +294,80 @@ class Planner:
         self._check(self._lib.emp_heading_kappa(self._h, B, M, a.inp(xy, np.float64, (B, M, 2)),
                                                 a.inp(n_pts, np.int32, (B,)), thp, kpp, a.where))
         return th, kp
+
+    def s_map(self, ref_line, n_ref, origin_xy):
+        """ref cal_s_map_fun: returns s_map (B,P)."""
+        a = _Args(ref_line, origin_xy)
+        B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
+        sm, smp = a.out((B, P), np.float64)
+        self._check(self._lib.emp_s_map(self._h, B, P, a.inp(ref_line, np.float64, (B, P, 4)),
+                                        a.inp(n_ref, np.int32, (B,)), a.inp(origin_xy, np.float64, (B, 2)), smp, a.where))
+        return sm
+
+    def s_l(self, ref_line, s_map, n_ref, xy, n_pts, match_index=None, want_l=True):
+        """ref cal_s_l_fun (or cal_projection_s_fun when match_index is given): returns s, l (B,K)."""
+        a = _Args(ref_line, xy)
+        B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
+        s_, sp_ = a.out((B, K), np.float64)
+        l_, lp_ = a.out((B, K), np.float64) if want_l else (None, None)
+        self._check(self._lib.emp_s_l(
+            self._h, B, P, K, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(s_map, np.float64, (B, P)),
+            a.inp(n_ref, np.int32, (B,)), a.inp(xy, np.float64, (B, K, 2)), a.inp(n_pts, np.int32, (B,)),
+            a.inp(match_index, np.int32, (B, K)) if match_index is not None else None, sp_, lp_, a.where))
+        return s_, l_
+
+    def s_l_deri(self, ref_line, n_ref, xy, v_xy, a_xy, n_pts, origin_xy):
+        """ref cal_s_l_deri_fun: returns (B,K,7) = l, dl/dt, ds/dt, d2l/dt2, dl/ds, d2s/dt2, d2l/ds2."""
+        a = _Args(ref_line, xy)
+        B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
+        o, op_ = a.out((B, K, 7), np.float64)
+        self._check(self._lib.emp_s_l_deri(
+            self._h, B, P, K, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(n_ref, np.int32, (B,)),
+            a.inp(xy, np.float64, (B, K, 2)), a.inp(v_xy, np.float64, (B, K, 2)), a.inp(a_xy, np.float64, (B, K, 2)),
+            a.inp(n_pts, np.int32, (B,)), a.inp(origin_xy, np.float64, (B, 2)), op_, a.where))
+        return o
+
+    def proj_point(self, ref_line, s_map, n_ref, s, pre_match_index):
+        """ref cal_proj_point for n independent queries: returns out (n,4), index (n,), status (n,)."""
+        a = _Args(ref_line, s)
+        n, P = int(ref_line.shape[0]), int(ref_line.shape[1])
+        o, op_ = a.out((n, 4), np.float64)
+        ix, ixp = a.out((n,), np.int32)
+        st, stp = a.out((n,), np.int32)
+        self._check(self._lib.emp_proj_point(
+            self._h, n, P, a.inp(ref_line, np.float64, (n, P, 4)), a.inp(s_map, np.float64, (n, P)),
+            a.inp(n_ref, np.int32, (n,)), a.inp(s, np.float64, (n,)), a.inp(pre_match_index, np.int32, (n,)), op_, ixp,
+            stp, a.where))
+        return o, ix, st
+
+    def trajectory_index2s(self, x, y, n_pts):
+        a = _Args(x, y)
+        B, M = int(x.shape[0]), int(x.shape[1])
+        o, op_ = a.out((B, M), np.float64)
+        self._check(self._lib.emp_trajectory_index2s(self._h, B, M, a.inp(x, np.float64, (B, M)),
+                                                     a.inp(y, np.float64, (B, M)), a.inp(n_pts, np.int32, (B,)), op_,
+                                                     a.where))
+        return o
+
+    def frenet2cartesian(self, ref_line, index2s, n_ref, sl, n_pts, proj_only=False):
+        """ref Frenet2Cartesian / CalcProjPoint: sl (B,K,4) = s,l,dl,ddl -> out (B,K,4), status (B,)."""
+        a = _Args(ref_line, sl)
+        B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(sl.shape[1])
+        o, op_ = a.out((B, K, 4), np.float64)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_frenet2cartesian(
+            self._h, B, P, K, a.inp(ref_line, np.float64, (B, P, 4)), a.inp(index2s, np.float64, (B, P)),
+            a.inp(n_ref, np.int32, (B,)), a.inp(sl, np.float64, (B, K, 4)), a.inp(n_pts, np.int32, (B,)), op_, stp,
+            int(bool(proj_only)), a.where))
+        return o, st
+
+    def dy_obs_deri(self, rows):
+        """ref cal_dy_obs_deri: rows (n,5) = l, vx, vy, heading, kappa -> (n,3) = s_dot, l_dot, dl."""
+        a = _Args(rows)
+        n = int(rows.shape[0])
+        o, op_ = a.out((n, 3), np.float64)
+        self._check(self._lib.emp_dy_obs_deri(self._h, n, a.inp(rows, np.float64, (n, 5)), op_, a.where))
+        return o
 
     # ---- QP stages ------------------------------------------------------------------------
     def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):

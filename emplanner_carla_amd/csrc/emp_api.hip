@@ -202,10 +202,11 @@ void emp_destroy(emp_ctx* ctx) {
         if (b.p) (void)hipFree(b.p);
     for (auto& kv : ctx->named)
         if (kv.second.p) (void)hipFree(kv.second.p);
-    for (auto& kv : ctx->events) {
-        if (kv.second.a) (void)hipEventDestroy(kv.second.a);
-        if (kv.second.b) (void)hipEventDestroy(kv.second.b);
-    }
+    for (auto& kv : ctx->events)
+        for (auto& pr : kv.second.pairs) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -248,19 +249,30 @@ int emp_copy_to_host(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
 int emp_set_timing(emp_ctx* ctx, int enabled) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     ctx->timing = enabled != 0;
-    if (!ctx->timing)
-        for (auto& kv : ctx->events) kv.second.valid = false;
+    if (ctx->timing)
+        for (auto& kv : ctx->events) kv.second.used = 0;   // restart the statistics
     return EMP_OK;
+}
+
+int emp_kernel_launches(emp_ctx* ctx, const char* kernel) {
+    if (!ctx || !kernel) return 0;
+    auto it = ctx->events.find(kernel);
+    return it == ctx->events.end() ? 0 : (int)it->second.used;
 }
 
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel) {
     if (!ctx || !kernel) return -1.0;
     auto it = ctx->events.find(kernel);
-    if (it == ctx->events.end() || !it->second.valid) return -1.0;
-    if (hipEventSynchronize(it->second.b) != hipSuccess) return -1.0;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, it->second.a, it->second.b) != hipSuccess) return -1.0;
-    return (double)ms;
+    if (it == ctx->events.end() || it->second.used == 0) return -1.0;
+    double total = 0.0;
+    for (size_t i = 0; i < it->second.used; ++i) {
+        auto& pr = it->second.pairs[i];
+        if (hipEventSynchronize(pr.second) != hipSuccess) return -1.0;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) != hipSuccess) return -1.0;
+        total += (double)ms;
+    }
+    return total / (double)it->second.used;
 }
 
 // ---- DP ----------------------------------------------------------------------------------
@@ -291,7 +303,7 @@ int emp_dp_edge_costs(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t m
     if ((rc = st.in(n_obs, (size_t)B, &d_n))) return rc;
     if ((rc = st.in(start, (size_t)B * 4, &d_start))) return rc;
     if ((rc = st.out(start_cost, (size_t)B * d.row, &d_c0))) return rc;
-    if ((rc = st.out(edge, (size_t)emp_edge_tensor_elems(p, B, layout), &d_e, layout == EMP_EDGE_TILED))) return rc;
+    if ((rc = st.out(edge, (size_t)emp_edge_tensor_elems(p, B, layout), &d_e, layout == EMP_EDGE_TILED))) return rc;  // canonical: fully written
     if (max_obs == 0) {  // kernels index [b * max_obs + m] only for m < n_obs == 0
         double* dummy;
         if ((rc = st.tmp(1, &dummy))) return rc;
@@ -812,3 +824,209 @@ int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis,
 }
 
 }  // extern "C"
+
+// ---- stand-alone projection helpers and the utilities beside the path ---------------------------
+extern "C" {
+
+int emp_s_map(emp_ctx* ctx, int32_t B, int32_t max_ref, const double* ref_line, const int32_t* n_ref,
+              const double* origin_xy, double* s_map, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 1 && ref_line && n_ref && origin_xy && s_map, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_o;
+    const int* d_nr;
+    double* d_sm;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(origin_xy, (size_t)B * 2, &d_o))) return rc;
+    if ((rc = st.out(s_map, (size_t)B * max_ref, &d_sm))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(s_map_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, d_ref, d_nr, d_o, d_sm);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_s_l(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line, const double* s_map,
+            const int32_t* n_ref, const double* xy, const int32_t* n_pts, const int32_t* match_index, double* s,
+            double* l, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 1 && max_pts >= 1 && ref_line && s_map && n_ref && xy && n_pts && s,
+                "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_sm, *d_xy;
+    const int *d_nr, *d_np, *d_mi;
+    double *d_s, *d_l;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(s_map, (size_t)B * max_ref, &d_sm))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(xy, (size_t)B * max_pts * 2, &d_xy))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(match_index, (size_t)B * max_pts, &d_mi))) return rc;
+    if ((rc = st.out(s, (size_t)B * max_pts, &d_s))) return rc;
+    if ((rc = st.out(l, (size_t)B * max_pts, &d_l))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(s_l_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts, d_ref, d_sm, d_nr,
+                           d_xy, d_np, d_mi, d_s, d_l);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_s_l_deri(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                 const int32_t* n_ref, const double* xy, const double* v_xy, const double* a_xy, const int32_t* n_pts,
+                 const double* origin_xy, double* out, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 1 && max_pts >= 1 && ref_line && n_ref && xy && v_xy && a_xy && n_pts &&
+                         origin_xy && out, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_xy, *d_v, *d_a, *d_o;
+    const int *d_nr, *d_np;
+    double* d_out;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(xy, (size_t)B * max_pts * 2, &d_xy))) return rc;
+    if ((rc = st.in(v_xy, (size_t)B * max_pts * 2, &d_v))) return rc;
+    if ((rc = st.in(a_xy, (size_t)B * max_pts * 2, &d_a))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(origin_xy, (size_t)B * 2, &d_o))) return rc;
+    if ((rc = st.out(out, (size_t)B * max_pts * 7, &d_out))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(s_l_deri_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts, d_ref, d_nr,
+                           d_xy, d_v, d_a, d_np, d_o, d_out);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_proj_point(emp_ctx* ctx, int32_t n, int32_t max_ref, const double* ref_line, const double* s_map,
+                   const int32_t* n_ref, const double* s, const int32_t* pre_match_index, double* out, int32_t* index,
+                   int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && max_ref >= 1 && ref_line && s_map && n_ref && s && pre_match_index && out && index &&
+                         status, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_sm, *d_s;
+    const int *d_nr, *d_pre;
+    double* d_out;
+    int *d_idx, *d_st;
+    if ((rc = st.in(ref_line, (size_t)n * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(s_map, (size_t)n * max_ref, &d_sm))) return rc;
+    if ((rc = st.in(n_ref, (size_t)n, &d_nr))) return rc;
+    if ((rc = st.in(s, (size_t)n, &d_s))) return rc;
+    if ((rc = st.in(pre_match_index, (size_t)n, &d_pre))) return rc;
+    if ((rc = st.out(out, (size_t)n * 4, &d_out))) return rc;
+    if ((rc = st.out(index, (size_t)n, &d_idx))) return rc;
+    if ((rc = st.out(status, (size_t)n, &d_st))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(proj_point_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, max_ref, d_ref, d_sm, d_nr, d_s,
+                           d_pre, d_out, d_idx, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_trajectory_index2s(emp_ctx* ctx, int32_t B, int32_t max_pts, const double* x, const double* y,
+                           const int32_t* n_pts, double* index2s, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_pts >= 1 && x && y && n_pts && index2s, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_x, *d_y;
+    const int* d_np;
+    double* d_o;
+    if ((rc = st.in(x, (size_t)B * max_pts, &d_x))) return rc;
+    if ((rc = st.in(y, (size_t)B * max_pts, &d_y))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.out(index2s, (size_t)B * max_pts, &d_o))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(index2s_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, d_x, d_y, d_np, d_o);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_frenet2cartesian(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                         const double* index2s, const int32_t* n_ref, const double* sl, const int32_t* n_pts,
+                         double* out, int32_t* status, int32_t proj_only, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_ref >= 2 && max_pts >= 1 && ref_line && index2s && n_ref && sl && n_pts && out &&
+                         status, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ref, *d_i2s, *d_sl;
+    const int *d_nr, *d_np;
+    double* d_out;
+    int* d_st;
+    if ((rc = st.in(ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+    if ((rc = st.in(index2s, (size_t)B * max_ref, &d_i2s))) return rc;
+    if ((rc = st.in(n_ref, (size_t)B, &d_nr))) return rc;
+    if ((rc = st.in(sl, (size_t)B * max_pts * 4, &d_sl))) return rc;
+    if ((rc = st.in(n_pts, (size_t)B, &d_np))) return rc;
+    if ((rc = st.out(out, (size_t)B * max_pts * 4, &d_out))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(frenet2cartesian_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts, d_ref,
+                           d_i2s, d_nr, d_sl, d_np, d_out, d_st, proj_only);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_dy_obs_deri(emp_ctx* ctx, int32_t n, const double* in, double* out, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && in && out, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double* d_in;
+    double* d_out;
+    if ((rc = st.in(in, (size_t)n * 5, &d_in))) return rc;
+    if ((rc = st.out(out, (size_t)n * 3, &d_out))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(dy_obs_deri_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, d_in, d_out);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+}  // extern "C"
+
+extern "C" int emp_enrich_nodes(emp_ctx* ctx, int32_t B, int32_t max_nodes, double resolution, const double* node_s,
+                                const double* node_l, const int32_t* n_nodes, const double* start, int32_t max_pts,
+                                double* path_s, double* path_l, int32_t* path_len, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_nodes >= 1 && max_pts >= 1 && resolution > 0, "bad sizes");
+    EMP_REQUIRE(ctx, node_s && node_l && n_nodes && start && path_s && path_l && path_len && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_ns, *d_nl, *d_start;
+    const int* d_nn;
+    double *d_ps, *d_pl;
+    int *d_len, *d_st;
+    if ((rc = st.in(node_s, (size_t)B * max_nodes, &d_ns))) return rc;
+    if ((rc = st.in(node_l, (size_t)B * max_nodes, &d_nl))) return rc;
+    if ((rc = st.in(n_nodes, (size_t)B, &d_nn))) return rc;
+    if ((rc = st.in(start, (size_t)B * 4, &d_start))) return rc;
+    if ((rc = st.out(path_s, (size_t)B * max_pts, &d_ps))) return rc;
+    if ((rc = st.out(path_l, (size_t)B * max_pts, &d_pl))) return rc;
+    if ((rc = st.out(path_len, (size_t)B, &d_len))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
+    if (B) {
+        hipLaunchKernelGGL(enrich_nodes_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_nodes, resolution, d_ns,
+                           d_nl, d_nn, d_start, max_pts, d_ps, d_pl, d_len, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}

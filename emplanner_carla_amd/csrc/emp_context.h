@@ -29,8 +29,8 @@ struct emp_ctx {
     // per-kernel timing
     bool timing = false;
     struct Ev {
-        hipEvent_t a = nullptr, b = nullptr;
-        bool valid = false;
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;   // one pair per launch since timing was enabled
+        size_t used = 0;
     };
     std::map<std::string, Ev> events;
     int cu_count = 0;
@@ -92,8 +92,10 @@ class Stage {
         *out = (const T*)d;
         return EMP_OK;
     }
+    // Outputs are zero-filled on the context's stream before the kernels run, so padding beyond a scene's
+    // length reads as 0 in both memory spaces (pass zero=false for arrays the kernels fully overwrite).
     template <typename T>
-    int out(T* host, size_t n, T** outp, bool zero = false) {
+    int out(T* host, size_t n, T** outp, bool zero = true) {
         if (host == nullptr) { *outp = nullptr; return EMP_OK; }
         T* d = host;
         if (!dev_) {
@@ -136,25 +138,25 @@ class Stage {
     std::vector<Back> backs_;
 };
 
-// RAII-ish kernel timer: records events around a launch when ctx->timing is on
+// RAII kernel timer: when ctx->timing is on, brackets a launch with a fresh HIP event pair on the context's
+// stream.  emp_kernel_ms() later averages all pairs recorded since timing was (re-)enabled.
 struct KernelTimer {
     emp_ctx* ctx;
-    emp_ctx::Ev* ev = nullptr;
+    hipEvent_t stop = nullptr;
     KernelTimer(emp_ctx* c, const char* name) : ctx(c) {
         if (!c->timing) return;
         emp_ctx::Ev& e = c->events[name];
-        if (!e.a) {
-            (void)hipEventCreate(&e.a);
-            (void)hipEventCreate(&e.b);
+        if (e.used == e.pairs.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            e.pairs.push_back({a, b});
         }
-        ev = &e;
-        (void)hipEventRecord(e.a, c->stream);
+        auto& pr = e.pairs[e.used++];
+        (void)hipEventRecord(pr.first, c->stream);
+        stop = pr.second;
     }
     ~KernelTimer() {
-        if (ev) {
-            (void)hipEventRecord(ev->b, ctx->stream);
-            ev->valid = true;
-        }
+        if (stop) (void)hipEventRecord(stop, ctx->stream);
     }
 };
 

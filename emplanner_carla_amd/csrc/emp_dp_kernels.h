@@ -334,4 +334,53 @@ __global__ void dp_enrich_kernel(DpDev P, const double* __restrict__ rows, const
     }
 }
 
+// ref: enrich_DP_s_l (path_planning.py:378-432) on caller-supplied node lists (any spacing), for the drop-in
+// function of the same name: node_s, node_l [B][max_nodes], n_nodes [B].
+__global__ void enrich_nodes_kernel(int B, int max_nodes, double res, const double* __restrict__ node_s,
+                                    const double* __restrict__ node_l, const int* __restrict__ n_nodes,
+                                    const double* __restrict__ start, int max_pts, double* __restrict__ path_s,
+                                    double* __restrict__ path_l, int* __restrict__ path_len, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s0 = start[b * 4 + 0], l0 = start[b * 4 + 1], dl0 = start[b * 4 + 2], ddl0 = start[b * 4 + 3];
+    double* os = path_s + (size_t)b * max_pts;
+    double* ol = path_l + (size_t)b * max_pts;
+    int n = 0;
+    bool trunc = false;
+    double end_s = s0, end_l = l0;
+    const int cols = n_nodes[b];
+    for (int c = 0; c < cols; ++c) {
+        end_s = node_s[(size_t)b * max_nodes + c];
+        end_l = node_l[(size_t)b * max_nodes + c];
+        const double span = end_s - s0;
+        const int cnt = arange_count(span, res);
+        const Quintic q = quintic_shifted(l0, dl0, ddl0, end_l, span);
+        for (int k = 0; k < cnt; ++k) {
+            const double t = (double)k * res;
+            if (n < max_pts) {
+                os[n] = s0 + t;
+                ol[n] = quintic_l(q, t);
+                ++n;
+            } else {
+                trunc = true;
+            }
+        }
+        s0 = end_s;
+        l0 = end_l;
+        dl0 = 0.0;
+        ddl0 = 0.0;
+    }
+    if (cols > 0) {
+        if (n < max_pts) {
+            os[n] = end_s;
+            ol[n] = end_l;
+            ++n;
+        } else {
+            trunc = true;
+        }
+    }
+    path_len[b] = n;
+    status[b] = trunc ? 32 : 0;
+}
+
 }  // namespace emp

@@ -373,6 +373,155 @@ __global__ void cycle_heading_kernel(int B, int max_pts, int* __restrict__ traj_
     heading_kappa(o, 4, m, o + 2, 4, o + 3, 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// stand-alone forms of the projection helpers (one lane per scene, points in order)
+// ---------------------------------------------------------------------------------------------
+// ref: cal_s_map_fun, planning_utils.py:448-472
+__global__ void s_map_kernel(int B, int max_ref, const double* __restrict__ ref_line, const int* __restrict__ n_ref,
+                             const double* __restrict__ origin_xy, double* __restrict__ s_map) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    s_map_build(ref_line + (size_t)b * max_ref * 4, n_ref[b], origin_xy[2 * b], origin_xy[2 * b + 1],
+                s_map + (size_t)b * max_ref);
+}
+
+// ref: cal_s_l_fun, planning_utils.py:475-509 (mode 0) and cal_projection_s_fun, :429-445 (mode 1: the caller
+// supplies the match indices and only s is produced)
+__global__ void s_l_kernel(int B, int max_ref, int max_pts, const double* __restrict__ ref_line,
+                           const double* __restrict__ s_map, const int* __restrict__ n_ref,
+                           const double* __restrict__ xy, const int* __restrict__ n_pts,
+                           const int* __restrict__ match_in, double* __restrict__ out_s, double* __restrict__ out_l) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* line = ref_line + (size_t)b * max_ref * 4;
+    const double* sm = s_map + (size_t)b * max_ref;
+    const int P = n_ref[b], k = n_pts[b];
+    int m_first = 0;
+    for (int j = 0; j < k; ++j) {
+        const size_t o = (size_t)b * max_pts + j;
+        const double x = xy[o * 2], y = xy[o * 2 + 1];
+        const int m = match_in ? match_in[o] : match_scan(line, P, x, y, 0, 1, 50);
+        if (j == 0) m_first = m;
+        out_s[o] = projection_s(node_at(line, m), sm[m], x, y);
+        if (out_l) out_l[o] = lateral_offset(project_on(node_at(line, m_first), x, y), x, y);
+    }
+}
+
+// ref: cal_s_l_deri_fun, planning_utils.py:512-588: out [B][max_pts][7] = l, dl/dt, ds/dt, d2l/dt2, dl/ds, d2s/dt2, d2l/ds2
+__global__ void s_l_deri_kernel(int B, int max_ref, int max_pts, const double* __restrict__ ref_line,
+                                const int* __restrict__ n_ref, const double* __restrict__ xy,
+                                const double* __restrict__ vxy, const double* __restrict__ axy,
+                                const int* __restrict__ n_pts, const double* __restrict__ origin_xy,
+                                double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* line = ref_line + (size_t)b * max_ref * 4;
+    const int P = n_ref[b], k = n_pts[b];
+    int m_first = 0;
+    for (int j = 0; j < k; ++j) {
+        const size_t o = (size_t)b * max_pts + j;
+        const double x = xy[o * 2], y = xy[o * 2 + 1];
+        const int m = match_scan(line, P, x, y, 0, 1, 50);
+        if (j == 0) m_first = m;
+        const Node proj = project_on(node_at(line, m_first), x, y);
+        const FrenetState f = frenet_state(proj, origin_xy[2 * b], origin_xy[2 * b + 1], vxy[o * 2], vxy[o * 2 + 1],
+                                           axy[o * 2], axy[o * 2 + 1]);
+        double* r = out + o * 7;
+        r[0] = f.l; r[1] = f.l_dot; r[2] = f.s_dot; r[3] = f.l_ddot; r[4] = f.dl_ds; r[5] = f.s_ddot; r[6] = f.ddl_ds;
+    }
+}
+
+// ref: cal_proj_point, path_planning.py:52-75: one query per lane; out [n][4], idx_out [n]; status 2 = IndexError
+__global__ void proj_point_kernel(int n, int max_ref, const double* __restrict__ ref_line,
+                                  const double* __restrict__ s_map, const int* __restrict__ n_ref,
+                                  const double* __restrict__ s, const int* __restrict__ pre_idx,
+                                  double* __restrict__ out, int* __restrict__ idx_out, int* __restrict__ status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int idx = pre_idx[t];
+    Node pr{0, 0, 0, 0};
+    const bool ok = idx >= 0 && proj_point(ref_line + (size_t)t * max_ref * 4, s_map + (size_t)t * max_ref, n_ref[t], s[t], &idx, &pr);
+    out[4 * t] = pr.x; out[4 * t + 1] = pr.y; out[4 * t + 2] = pr.theta; out[4 * t + 3] = pr.kappa;
+    idx_out[t] = idx;
+    status[t] = ok ? 0 : kStSOutOfRange;
+}
+
+// ref: trajectory_index2s, planning_utils.py:758-780: cumulative chord length until the first NaN x
+__global__ void index2s_kernel(int B, int max_pts, const double* __restrict__ x, const double* __restrict__ y,
+                               const int* __restrict__ n_pts, double* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const size_t o = (size_t)b * max_pts;
+    double acc = 0.0;
+    for (int i = 0; i < n_pts[b]; ++i) out[o + i] = 0.0;
+    for (int i = 1; i < n_pts[b]; ++i) {
+        if (x[o + i] != x[o + i]) break;
+        const double dx = x[o + i] - x[o + i - 1], dy = y[o + i] - y[o + i - 1];
+        acc += sqrt(dx * dx + dy * dy);
+        out[o + i] = acc;
+    }
+}
+
+// ref: CalcProjPoint (planning_utils.py:736-755) + Frenet2Cartesian (:706-733): per point, NaN s stops the scene.
+// line [B][max_ref][4], index2s [B][max_ref]; sl [B][max_pts][4] = s, l, dl, ddl -> out [B][max_pts][4] (NaN-filled)
+__global__ void frenet2cartesian_kernel(int B, int max_ref, int max_pts, const double* __restrict__ ref_line,
+                                        const double* __restrict__ index2s, const int* __restrict__ n_ref,
+                                        const double* __restrict__ sl, const int* __restrict__ n_pts,
+                                        double* __restrict__ out, int* __restrict__ status, int proj_only) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double* line = ref_line + (size_t)b * max_ref * 4;
+    const double* sm = index2s + (size_t)b * max_ref;
+    const int P = n_ref[b];
+    const double qnan = __builtin_nan("");
+    int st = 0;
+    bool stopped = false;
+    for (int j = 0; j < n_pts[b]; ++j) {
+        const double* v = sl + ((size_t)b * max_pts + j) * 4;
+        double* o = out + ((size_t)b * max_pts + j) * 4;
+        o[0] = o[1] = o[2] = o[3] = qnan;
+        if (stopped || v[0] != v[0]) {                      // ref :718-719 break at the first NaN s
+            stopped = true;
+            continue;
+        }
+        int idx = 1;                                         // ref :742-744 starts at 1, first s_map[idx] >= s
+        while (idx < P && sm[idx] < v[0]) ++idx;
+        if (idx >= P) {
+            st = kStSOutOfRange;                             // IndexError in the reference
+            stopped = true;
+            continue;
+        }
+        const Node m = node_at(line, idx);
+        const double ds = v[0] - sm[idx];
+        const double px = m.x + ds * cos(m.theta), py = m.y + ds * sin(m.theta);
+        const double ph = m.theta + ds * m.kappa, pk = m.kappa;
+        if (proj_only) {
+            o[0] = px; o[1] = py; o[2] = ph; o[3] = pk;
+            continue;
+        }
+        const double l = v[1], dl = v[2], ddl = v[3];
+        o[0] = px + l * (-sin(ph));
+        o[1] = py + l * cos(ph);
+        const double hd = ph + atan(dl / (1.0 - pk * l));                                   // ref :727
+        const double dth = hd - ph;
+        o[2] = hd;
+        o[3] = ((ddl + pk * dl * tan(dth)) * (cos(dth) * cos(dth)) / (1.0 - pk * l) + pk) * cos(dth) / (1.0 - pk * l);
+    }
+    status[b] = st;
+}
+
+// ref: cal_dy_obs_deri, planning_utils.py:783-808: in [n][5] = l, vx, vy, heading, kappa -> out [n][3] = s_dot, l_dot, dl
+__global__ void dy_obs_deri_kernel(int n, const double* __restrict__ in, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double l = in[5 * t], vx = in[5 * t + 1], vy = in[5 * t + 2], hd = in[5 * t + 3], k = in[5 * t + 4];
+    const double l_dot = vx * (-sin(hd)) + vy * cos(hd);
+    const double s_dot = (vx * cos(hd) + vy * sin(hd)) / (1.0 - k * l);
+    out[3 * t] = s_dot;
+    out[3 * t + 1] = l_dot;
+    out[3 * t + 2] = (fabs(s_dot) < 1e-6) ? 0.0 : l_dot / s_dot;
+}
+
 // small utilities ---------------------------------------------------------------------------------
 // ref: cal_quintic_coefficient, planning_utils.py:671-703 - returns ABSOLUTE-s coefficients c0..c5 like the
 // reference, computed from the closed form in the shifted coordinate (binomial re-expansion about s0).

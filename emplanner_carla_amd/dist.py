@@ -1,0 +1,77 @@
+"""Many-scene mode across the GPUs of one node: contiguous sharding + one gather of the results.
+
+Scenes are independent (the reference is stateless per planning call, test_9.py:92-221), so each
+rank plans its own contiguous block with the single-GPU pipeline and the only exchange is the
+collection of fixed-stride result records - ``all_gather`` over RCCL/xGMI (backend "nccl" on
+ROCm).  No other collective exists on this path.  Everything here is backend-agnostic
+(``gloo`` on CPU in tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous block of scene indices of ``rank``: (start, count); earlier ranks take the remainder."""
+    base, rem = divmod(int(total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+def record_width(col: int, max_pts: int) -> int:
+    """float64 slots per scene: status, traj_len, path_len, dp rows, path (s, l), trajectory (x, y, theta, kappa)."""
+    return 3 + col + 2 * max_pts + 4 * (max_pts + 1)
+
+
+def pack_records(res, col: int, max_pts: int):
+    """CycleResult (torch tensors or numpy arrays) -> one (B, record_width) float64 matrix."""
+    import torch
+    as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    st, tl, pl_ = as_t(res.status), as_t(res.traj_len), as_t(res.path_len)
+    B = st.shape[0]
+    parts = [st.to(torch.float64).reshape(B, 1), tl.to(torch.float64).reshape(B, 1),
+             pl_.to(torch.float64).reshape(B, 1), as_t(res.dp_rows).reshape(B, col),
+             as_t(res.path_s).reshape(B, max_pts), as_t(res.path_l).reshape(B, max_pts),
+             as_t(res.traj).reshape(B, 4 * (max_pts + 1))]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def unpack_records(rec, col: int, max_pts: int):
+    """Inverse of pack_records: dict of arrays keyed like CycleResult."""
+    B = rec.shape[0]
+    o = 3
+    out = {"status": rec[:, 0].round().long(), "traj_len": rec[:, 1].round().long(),
+           "path_len": rec[:, 2].round().long(), "dp_rows": rec[:, o:o + col]}
+    o += col
+    out["path_s"] = rec[:, o:o + max_pts]
+    o += max_pts
+    out["path_l"] = rec[:, o:o + max_pts]
+    o += max_pts
+    out["traj"] = rec[:, o:].reshape(B, max_pts + 1, 4)
+    return out
+
+
+def gather_records(local, total: int, group=None):
+    """All ranks receive the (total, width) matrix of every rank's records, in scene order.
+
+    ``local`` is this rank's (count, width) matrix for the block ``shard_range(total, rank, world)``.
+    Equal shards use one ``all_gather_into_tensor``; ragged shards are padded to the largest block.
+    """
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [shard_range(total, r, world)[1] for r in range(world)]
+    assert local.shape[0] == counts[rank], "local block does not match shard_range"
+    width = local.shape[1]
+    biggest = max(counts)
+    if min(counts) == biggest:
+        out = torch.empty((total, width), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    padded = torch.zeros((biggest, width), dtype=local.dtype, device=local.device)
+    padded[:counts[rank]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

@@ -1,0 +1,35 @@
+"""Process-wide planner context for the drop-in modules (created on first use, i.e. after any fork)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+_planner = None
+_pid = None
+
+
+def planner():
+    """The process's Planner (device EMP_DEVICE, default 0).  A forked child gets its own context:
+    the reference runs ``motion_planning`` in a child process (test_9.py:225-227)."""
+    global _planner, _pid
+    if _planner is None or _pid != os.getpid():
+        from ..api import Planner
+        _planner = Planner(int(os.environ.get("EMP_DEVICE", "0")))
+        _pid = os.getpid()
+    return _planner
+
+
+def line_array(path):
+    """[(x, y, theta, kappa), ...] -> (1, P, 4) float64 + n_ref."""
+    a = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path], dtype=np.float64)
+    return a.reshape(1, -1, 4), np.array([a.shape[0]], np.int32)
+
+
+def xy_array(pts):
+    a = np.asarray([[float(p[0]), float(p[1])] for p in pts], dtype=np.float64)
+    return a.reshape(1, -1, 2), np.array([a.shape[0]], np.int32)
+
+
+def f64(x):
+    return np.float64(x)

@@ -103,11 +103,14 @@ int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
 int emp_device_free(emp_ctx* ctx, void* ptr);
 int emp_copy_to_device(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int emp_copy_to_host(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);
-/* timing of the last launch of a named kernel on this context, measured with HIP events on the
- * context's stream ("dp_edge", "dp_sweep", "dp_fused", "project", "path_qp", "to_cartesian");
- * returns milliseconds, or a negative value when that kernel has not run with timing enabled */
+/* Per-kernel timing with HIP events on the context's stream.  emp_set_timing(ctx, 1) (re)starts the
+ * statistics; every launch of a named kernel ("project", "dp_edge", "dp_sweep", "dp_enrich", "path_qp",
+ * "to_cartesian", "heading", ...) is then bracketed by an event pair.  emp_kernel_ms returns the MEAN
+ * duration in milliseconds over the launches recorded since (it synchronises on their events), or a
+ * negative value if there were none; emp_kernel_launches returns how many were recorded. */
 int emp_set_timing(emp_ctx* ctx, int enabled);
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
+int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
 
 /* ---- S-L lattice DP ------------------------------------------------------------------ */
 /* Layout of the materialised edge-cost tensor (two-kernel DP mode):
@@ -152,6 +155,12 @@ int emp_dp_enrich(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double*
                   int32_t max_pts, double* path_s, double* path_l, int32_t* path_len, int32_t* status,
                   emp_mem where);
 
+/* ref: enrich_DP_s_l (path_planning.py:378-432) exactly as the reference function takes it: arbitrary node
+ * lists node_s, node_l [B][max_nodes] with n_nodes [B], start [B][4], resolution -> path_s, path_l, path_len */
+int emp_enrich_nodes(emp_ctx* ctx, int32_t B, int32_t max_nodes, double resolution, const double* node_s,
+                     const double* node_l, const int32_t* n_nodes, const double* start, int32_t max_pts,
+                     double* path_s, double* path_l, int32_t* path_len, int32_t* status, emp_mem where);
+
 /* ---- Cartesian <-> Frenet ------------------------------------------------------------ */
 /* ref: cal_s_map_fun (planning_utils.py:448-472), cal_s_l_fun (:475-509) for the obstacles and the
  * planning start, cal_s_l_deri_fun (:512-588) for the planning start - the front half of one
@@ -166,6 +175,29 @@ int emp_frenet_project(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_obs
                        const double* start_a, const double* obs_xy, const int32_t* n_obs,
                        double* s_map, double* obs_s, double* obs_l, double* begin_sl, double* start,
                        emp_mem where);
+
+/* ref: cal_s_map_fun (planning_utils.py:448-472) alone: s_map [B][max_ref] */
+int emp_s_map(emp_ctx* ctx, int32_t B, int32_t max_ref, const double* ref_line, const int32_t* n_ref,
+              const double* origin_xy, double* s_map, emp_mem where);
+
+/* ref: cal_s_l_fun (planning_utils.py:475-509) with a caller-supplied s_map: xy [B][max_pts][2] -> s, l [B][max_pts].
+ * With match_index != NULL and l == NULL it is cal_projection_s_fun (:429-445): s from the given match indices. */
+int emp_s_l(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line, const double* s_map,
+            const int32_t* n_ref, const double* xy, const int32_t* n_pts, const int32_t* match_index,
+            double* s, double* l, emp_mem where);
+
+/* ref: cal_s_l_deri_fun (planning_utils.py:512-588): xy, v_xy, a_xy [B][max_pts][2], origin_xy [B][2]
+ * -> out [B][max_pts][7] = l, dl/dt, ds/dt, d2l/dt2, dl/ds, d2s/dt2, d2l/ds2 */
+int emp_s_l_deri(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                 const int32_t* n_ref, const double* xy, const double* v_xy, const double* a_xy,
+                 const int32_t* n_pts, const double* origin_xy, double* out, emp_mem where);
+
+/* ref: cal_proj_point (path_planning.py:52-75; twin cal_proj_point_1, planning_utils.py:647-668): n independent
+ * queries, each against its own line: s [n], pre_match_index [n] -> out [n][4] x,y,theta,kappa, index [n],
+ * status [n] (EMP_ST_S_OUT_OF_RANGE where the reference raises IndexError) */
+int emp_proj_point(emp_ctx* ctx, int32_t n, int32_t max_ref, const double* ref_line, const double* s_map,
+                   const int32_t* n_ref, const double* s, const int32_t* pre_match_index, double* out,
+                   int32_t* index, int32_t* status, emp_mem where);
 
 /* ref: match_projection_points (planning_utils.py:364-426): [B][max_pts] points against one line per scene */
 int emp_match_projection(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts,
@@ -240,6 +272,17 @@ int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* 
 /* ref: cal_obs_cost (path_planning.py:588-609): square_d [n][10] -> cost [n] */
 int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis,
                  const double* square_d, double* cost, emp_mem where);
+
+/* ref: trajectory_index2s (planning_utils.py:758-780): x, y [B][max_pts] -> cumulative chord length [B][max_pts] */
+int emp_trajectory_index2s(emp_ctx* ctx, int32_t B, int32_t max_pts, const double* x, const double* y,
+                           const int32_t* n_pts, double* index2s, emp_mem where);
+/* ref: Frenet2Cartesian (planning_utils.py:706-733; proj_only = 0) and CalcProjPoint (:736-755; proj_only = 1):
+ * sl [B][max_pts][4] = s, l, dl, ddl -> out [B][max_pts][4] = x, y, heading, kappa (NaN from the first NaN s on) */
+int emp_frenet2cartesian(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
+                         const double* index2s, const int32_t* n_ref, const double* sl, const int32_t* n_pts,
+                         double* out, int32_t* status, int32_t proj_only, emp_mem where);
+/* ref: cal_dy_obs_deri (planning_utils.py:783-808): in [n][5] = l, vx, vy, heading, kappa -> out [n][3] */
+int emp_dy_obs_deri(emp_ctx* ctx, int32_t n, const double* in, double* out, emp_mem where);
 
 #ifdef __cplusplus
 }
