@@ -471,8 +471,10 @@ class Planner:
 
 
 def max_path_points(p: DpParams) -> int:
-    """Upper bound of len(enrich_DP_s_l output): col * ceil(int(sample_s + 1) / res) + 1."""
-    per = int(np.ceil((int(p.sample_s) + 1) / p.sampling_res))
+    """Upper bound of len(enrich_DP_s_l output).  Per lattice segment the reference takes
+    len(arange(0, int(end_s - start_s), res)) samples (path_planning.py:405/:423); the float difference is
+    sample_s up to an ulp, so int() of it is at most floor(sample_s) (+1 ulp guard)."""
+    per = int(np.ceil(int(p.sample_s + 1e-9) / p.sampling_res))
     return p.col * max(per, 1) + 1
 
 

@@ -422,51 +422,44 @@ static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const doub
     return EMP_OK;
 }
 
-#define EMP_DISPATCH_N(need, CALL)              \
-    do {                                        \
-        if ((need) <= 32) { CALL(32); }         \
-        else if ((need) <= 64) { CALL(64); }    \
-        else if ((need) <= 128) { CALL(128); }  \
-        else { CALL(256); }                     \
-    } while (0)
+template <typename K>
+static int set_lds(emp_ctx* ctx, K kernel, size_t bytes) {
+    EMP_REQUIRE(ctx, bytes <= 160 * 1024, "problem too large for the LDS-resident QP solver");
+    if (bytes > 48 * 1024)
+        EMP_HIP(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return EMP_OK;
+}
 
 static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpDev& Q, const double* dp_s,
                         const double* dp_l, const int* dp_len, const double* obs_s, const double* obs_l,
                         const int* n_obs, const double* start, double* path_s, double* path_l, int* path_len,
                         int* status) {
     if (B == 0) return EMP_OK;
-    const int need = (max_pts + Q.decimate - 1) / Q.decimate;
-    EMP_REQUIRE(ctx, need <= 256, "more than 256 QP stations are not supported");
+    const int cap = (max_pts + Q.decimate - 1) / Q.decimate;          // most stations a scene can have
+    const size_t lds = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
+    int rc = set_lds(ctx, cycle_qp_wave_kernel, lds);
+    if (rc) return rc;
     KernelTimer t(ctx, "path_qp");
-#define CALL(N)                                                                                                    \
-    hipLaunchKernelGGL((cycle_qp_kernel<N>), grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, max_obs, Q, dp_s,   \
-                       dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status)
-    EMP_DISPATCH_N(need, CALL);
-#undef CALL
+    hipLaunchKernelGGL(cycle_qp_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_obs, cap, Q, dp_s, dp_l,
+                       dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
 
-static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, const emp_smooth_params* sp,
+static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, int path_cap, const emp_smooth_params* sp,
                                const double* ref_line, const double* s_map, const int* n_ref, const double* begin_sl,
                                const double* path_s, const double* path_l, const int* path_len, double* traj,
                                int* traj_len, int* status) {
     if (B == 0) return EMP_OK;
     const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
     const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
-    const int need = max_pts + 1;
-    EMP_REQUIRE(ctx, need <= 256, "more than 255 path points are not supported");
-    {
-        KernelTimer t(ctx, "to_cartesian");
-#define CALL(N)                                                                                                      \
-    hipLaunchKernelGGL((cycle_cartesian_kernel<N>), grid1(2 * B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_pts,   \
-                       sx, sy, ref_line, s_map, n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status)
-        EMP_DISPATCH_N(need, CALL);
-#undef CALL
-        EMP_LAUNCH_CHECK(ctx);
-    }
-    KernelTimer t2(ctx, "heading");
-    hipLaunchKernelGGL(cycle_heading_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, traj_len, traj, status);
+    const int cap = path_cap + 1;                                        // trajectory = planning start + path points
+    const size_t lds = ((size_t)max_ref + 3 * (size_t)cap + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
+    int rc = set_lds(ctx, cycle_cartesian_wave_kernel, lds);
+    if (rc) return rc;
+    KernelTimer t(ctx, "to_cartesian");
+    hipLaunchKernelGGL(cycle_cartesian_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_ref, max_pts, cap, sx, sy,
+                       ref_line, s_map, n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -630,12 +623,11 @@ int emp_path_qp(emp_ctx* ctx, const emp_qp_params* q, int32_t B, int32_t max_pts
     if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
     if (B) {
         const QpDev Q = make_qp_dev(q);
+        const size_t lds = (size_t)path_qp_words(max_pts) * sizeof(double);
+        if ((rc = set_lds(ctx, path_qp_wave_kernel, lds))) return rc;
         KernelTimer t(ctx, "path_qp");
-#define CALL(N)                                                                                                  \
-    hipLaunchKernelGGL((path_qp_kernel<N>), grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, Q, d_lo, d_hi, d_np, \
-                       d_s3, d_l, d_dl, d_ddl, d_it, d_st)
-        EMP_DISPATCH_N(max_pts, CALL);
-#undef CALL
+        hipLaunchKernelGGL(path_qp_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_pts, Q, d_lo, d_hi,
+                           d_np, d_s3, d_l, d_dl, d_ddl, d_it, d_st);
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();
@@ -659,20 +651,13 @@ int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_
     if ((rc = st.out(iters, (size_t)B, &d_it))) return rc;
     if ((rc = st.out(status, (size_t)B, &d_st))) return rc;
     if (B) {
-        EMP_HIP(ctx, hipMemsetAsync(d_st, 0, (size_t)B * sizeof(int), ctx->stream));
         const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
         const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
-        {
-            KernelTimer t(ctx, "smooth");
-#define CALL(N)                                                                                                    \
-    hipLaunchKernelGGL((smooth_kernel<N>), grid1(2 * B, 64), dim3(64), 0, ctx->stream, B, max_pts, sx, sy, d_xy, d_np, \
-                       d_out, d_it, d_st)
-            EMP_DISPATCH_N(max_pts, CALL);
-#undef CALL
-            EMP_LAUNCH_CHECK(ctx);
-        }
-        KernelTimer t2(ctx, "heading");
-        hipLaunchKernelGGL(traj_heading_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_pts, d_np, d_out, d_st);
+        const size_t lds = (2 * (size_t)BoxRangeQp::words(max_pts, max_pts) + (size_t)max_pts) * sizeof(double);
+        if ((rc = set_lds(ctx, smooth_wave_kernel, lds))) return rc;
+        KernelTimer t(ctx, "smooth");
+        hipLaunchKernelGGL(smooth_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_pts, sx, sy, d_xy, d_np,
+                           d_out, d_it, d_st);
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();
@@ -781,8 +766,9 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
                            d_st)))
         return rc;
-    if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen, d_traj,
-                                  d_tlen, d_st)))
+    const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
+    if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
+                                  d_traj, d_tlen, d_st)))
         return rc;
     return st.finish();
 }

@@ -11,6 +11,7 @@
 #include "emp_core.h"
 #include "emp_frenet_core.h"
 #include "emp_qp_core.h"
+#include "emp_qp_wave.h"
 
 namespace emp {
 
@@ -160,54 +161,80 @@ __global__ void lmin_lmax_kernel(int B, int max_pts, int max_obs, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// ref: Quadratic_planning, path_planning.py:78-219 (stand-alone stage)
+// heading / curvature of m points held in LDS (px, py), one point per lane (ref planning_utils.py:185-228)
+// th: LDS scratch [m].  out[i*ostride + 0..3] = x, y, theta, kappa.  Contains barriers: whole wavefront calls.
 // ---------------------------------------------------------------------------------------------
-template <int NMAX>
-__global__ void path_qp_kernel(int B, int max_pts, QpDev Q, const double* __restrict__ l_min,
-                               const double* __restrict__ l_max, const int* __restrict__ n_pts,
-                               const double* __restrict__ start_l3, double* __restrict__ qp_l,
-                               double* __restrict__ qp_dl, double* __restrict__ qp_ddl, int* __restrict__ iters,
-                               int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    PathQp<NMAX> qp;
+__device__ inline void heading_kappa_wave(const double* px, const double* py, int m, double* th, double* out,
+                                          int ostride) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < m; i += 64) {
+        const int a = (i - 1 > 0) ? i - 1 : 0, b = (i < m - 2) ? i : m - 2;
+        const double dx = ((px[a + 1] - px[a]) + (px[b + 1] - px[b])) / 2.0;
+        const double dy = ((py[a + 1] - py[a]) + (py[b + 1] - py[b])) / 2.0;
+        th[i] = atan2(dy, dx);
+    }
+    __syncthreads();
+    for (int i = lane; i < m; i += 64) {
+        const int a = (i - 1 > 0) ? i - 1 : 0, b = (i < m - 2) ? i : m - 2;
+        const double dx = ((px[a + 1] - px[a]) + (px[b + 1] - px[b])) / 2.0;
+        const double dy = ((py[a + 1] - py[a]) + (py[b + 1] - py[b])) / 2.0;
+        const double dpre = th[a + 1] - th[a], daft = th[b + 1] - th[b];
+        double* o = out + (size_t)i * ostride;
+        o[0] = px[i];
+        o[1] = py[i];
+        o[2] = th[i];
+        o[3] = sin((dpre + daft) / 2.0) / sqrt(dx * dx + dy * dy);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ref: Quadratic_planning, path_planning.py:78-219 (stand-alone stage): one wavefront per scene
+// dynamic LDS: path_qp_words(cap) doubles
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void path_qp_wave_kernel(int B, int max_pts, int cap, QpDev Q,
+                                                          const double* __restrict__ l_min,
+                                                          const double* __restrict__ l_max,
+                                                          const int* __restrict__ n_pts,
+                                                          const double* __restrict__ start_l3,
+                                                          double* __restrict__ qp_l, double* __restrict__ qp_dl,
+                                                          double* __restrict__ qp_ddl, int* __restrict__ iters,
+                                                          int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
     const size_t o = (size_t)b * max_pts;
-    const int rc = qp.solve(l_min + o, l_max + o, n_pts[b], start_l3[3 * b], start_l3[3 * b + 1], start_l3[3 * b + 2],
-                            Q.qp, qp_l + o, qp_dl + o, qp_ddl + o);
-    if (iters) iters[b] = qp.iters;
-    status[b] = rc ? kStQpFailed : 0;
+    const int n = n_pts[b];
+    int it = 0;
+    int rc = 2;
+    if (n <= cap && n <= max_pts)
+        rc = path_qp_wave(lds, l_min + o, l_max + o, n, start_l3[3 * b], start_l3[3 * b + 1], start_l3[3 * b + 2], Q.qp,
+                          qp_l + o, qp_dl + o, qp_ddl + o, &it);
+    if ((threadIdx.x & 63) == 0) {
+        if (iters) iters[b] = it;
+        status[b] = rc ? kStQpFailed : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// ref: smooth_reference_line, planning_utils.py:262-361 (stand-alone stage): two lanes per scene (x, y)
-// for the QP, then lane 0 of the pair computes heading / curvature.
+// ref: smooth_reference_line, planning_utils.py:262-361 (stand-alone stage): one wavefront per polyline,
+// x on lanes 0-31, y on lanes 32-63, then heading / curvature one point per lane.
+// dynamic LDS: 2 * BoxRangeQp::words(cap, cap) + cap doubles
 // ---------------------------------------------------------------------------------------------
-template <int MMAX>
-__global__ void smooth_kernel(int B, int max_pts, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ xy,
-                              const int* __restrict__ n_pts, double* __restrict__ out, int* __restrict__ iters,
-                              int* __restrict__ status) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = t >> 1, c = t & 1;
-    if (b >= B) return;
+__global__ __launch_bounds__(64) void smooth_wave_kernel(int B, int max_pts, int cap, SmoothQpParams sx,
+                                                         SmoothQpParams sy, const double* __restrict__ xy,
+                                                         const int* __restrict__ n_pts, double* __restrict__ out,
+                                                         int* __restrict__ iters, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
     const int m = n_pts[b];
-    BoxQp<MMAX> qp;
-    const int rc = qp.solve(xy + (size_t)b * max_pts * 2 + c, 2, m, c ? sy : sx);
-    double* o = out + (size_t)b * max_pts * 4;
-    if (rc == 0)
-        for (int i = 0; i < m; ++i) o[4 * i + c] = qp.x[i];
-    if (rc) atomicOr(&status[b], kStSmoothFailed);
-    if (iters && c == 0) iters[b] = qp.iters;
-}
-
-// heading / kappa of the smoothed points, in place in out[b][i][0..3] (ref planning_utils.py:357-360)
-__global__ void traj_heading_kernel(int B, int max_pts, const int* __restrict__ n_pts, double* __restrict__ out,
-                                    const int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int m = n_pts[b];
-    if (m < 2 || (status[b] & (kStSmoothFailed | kStQpFailed | kStBoundIndex | kStSOutOfRange))) return;
-    double* o = out + (size_t)b * max_pts * 4;
-    heading_kappa(o, 4, m, o + 2, 4, o + 3, 4);
+    int it = 0, rc = 2;
+    double *px = nullptr, *py = nullptr;
+    if (m <= cap && m <= max_pts) rc = smooth_pair_wave(lds, xy + (size_t)b * max_pts * 2, 2, m, sx, sy, &px, &py, &it);
+    if (rc == 0) heading_kappa_wave(px, py, m, lds + 2 * BoxRangeQp::words(m, m), out + (size_t)b * max_pts * 4, 4);
+    if ((threadIdx.x & 63) == 0) {
+        if (iters) iters[b] = it;
+        status[b] = rc ? kStSmoothFailed : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,114 +290,215 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 
 // ---------------------------------------------------------------------------------------------
 // One cycle, middle part (ref test_9.py:187-210): decimate -> bounds -> path QP -> midpoints.
-// Inputs: densified DP path; outputs path_s/path_l (n+1 points, or n without the midpoint step).
+// One wavefront per scene.  dynamic LDS (doubles): 5*cap + 4*max_obs + path_qp_words(cap)
 // ---------------------------------------------------------------------------------------------
-template <int NMAX>
-__global__ void cycle_qp_kernel(int B, int max_pts, int max_obs, QpDev Q, const double* __restrict__ dp_s,
-                                const double* __restrict__ dp_l, const int* __restrict__ dp_len,
-                                const double* __restrict__ obs_s, const double* __restrict__ obs_l,
-                                const int* __restrict__ n_obs, const double* __restrict__ start,
-                                double* __restrict__ path_s, double* __restrict__ path_l, int* __restrict__ path_len,
-                                int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, int max_obs, int cap, QpDev Q,
+                                                           const double* __restrict__ dp_s,
+                                                           const double* __restrict__ dp_l,
+                                                           const int* __restrict__ dp_len,
+                                                           const double* __restrict__ obs_s,
+                                                           const double* __restrict__ obs_l,
+                                                           const int* __restrict__ n_obs,
+                                                           const double* __restrict__ start,
+                                                           double* __restrict__ path_s, double* __restrict__ path_l,
+                                                           int* __restrict__ path_len, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
     const size_t o = (size_t)b * max_pts;
+    double* sd = lds;                 // decimated station s   [cap]
+    double* ld = sd + cap;            // decimated DP l        [cap]
+    double* lmin = ld + cap;          // [cap]
+    double* lmax = lmin + cap;        // [cap]
+    double* ql = lmax + cap;          // QP result l           [cap]
+    double* otab = ql + cap;          // per obstacle: lo, hi, below, bound   [4*max_obs]
+    double* qmem = otab + 4 * max_obs;
     const int ne = dp_len[b];
     const int dec = Q.decimate > 0 ? Q.decimate : 1;
     const int n = (ne + dec - 1) / dec;                                            // len(x[::dec])
+    int st = status[b];
+    if (lane == 0) path_len[b] = 0;
+    if (n > cap || n + (Q.midpoint ? 1 : 0) > max_pts || n < 1) {
+        if (lane == 0) status[b] = st | kStTruncated;
+        return;
+    }
+    for (int i = lane; i < n; i += 64) {
+        sd[i] = dp_s[o + (size_t)i * dec];
+        ld[i] = dp_l[o + (size_t)i * dec];
+    }
+    __syncthreads();
+    if (Q.use_qp) {
+        // ---- cal_lmin_lmax (ref path_planning.py:222-273): one obstacle per lane finds its index range,
+        // then one station per lane folds the (commutative) min / max over the obstacles covering it
+        const int nob = n_obs[b];
+        int bad = 0;
+        for (int k = lane; k < nob; k += 64) {
+            const double os = obs_s[(size_t)b * max_obs + k], ol = obs_l[(size_t)b * max_obs + k];
+            const int lo = argmin_abs(sd, 1, n, os - Q.obs_length / 2.0) + 2;     // ref :240
+            const int hi = argmin_abs(sd, 1, n, os + Q.obs_length / 2.0) + 2;     // ref :241
+            const int centre = argmin_abs(sd, 1, n, os);                           // ref :257
+            const bool below = ld[centre] < ol;                                    // ref :263
+            otab[4 * k + 0] = (double)lo;
+            otab[4 * k + 1] = (double)hi;
+            otab[4 * k + 2] = below ? 1.0 : 0.0;
+            otab[4 * k + 3] = below ? ol - Q.obs_width / 2.0 : ol + Q.obs_width / 2.0;
+            if (lo <= hi && hi >= n) bad = 1;                                      // IndexError in the reference
+        }
+        if (__any(bad)) {
+            if (lane == 0) status[b] = st | kStBoundIndex;
+            return;
+        }
+        __syncthreads();
+        for (int j = lane; j < n; j += 64) {
+            double a = -10.0, c = 10.0;                                            // ref :233-234
+            for (int k = 0; k < nob; ++k) {
+                if ((double)j >= otab[4 * k] && (double)j <= otab[4 * k + 1]) {
+                    if (otab[4 * k + 2] != 0.0) c = fmin(c, otab[4 * k + 3]);
+                    else a = fmax(a, otab[4 * k + 3]);
+                }
+            }
+            lmin[j] = a;
+            lmax[j] = c;
+        }
+        __syncthreads();
+        int it = 0;
+        const int rc = path_qp_wave(qmem, lmin, lmax, n, start[4 * b + 1], start[4 * b + 2], start[4 * b + 3], Q.qp, ql,
+                                    nullptr, nullptr, &it);
+        if (rc) {
+            if (lane == 0) status[b] = st | kStQpFailed;
+            return;
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) ql[i] = ld[i];
+        __syncthreads();
+    }
     double* ps = path_s + o;
     double* pl = path_l + o;
-    int st = status[b];
-    path_len[b] = 0;
-    if (n > NMAX || n + (Q.midpoint ? 1 : 0) > max_pts) {
-        status[b] = st | kStTruncated;
-        return;
-    }
-    double ql[NMAX], qdl[NMAX], qddl[NMAX];
-    if (Q.use_qp) {
-        double l_min[NMAX], l_max[NMAX];
-        if (!lmin_lmax(dp_s + o, dp_l + o, dec, n, obs_s + (size_t)b * max_obs, obs_l + (size_t)b * max_obs,
-                       n_obs[b], Q.obs_length, Q.obs_width, l_min, l_max)) {
-            status[b] = st | kStBoundIndex;
-            return;
-        }
-        PathQp<NMAX> qp;
-        const int rc = qp.solve(l_min, l_max, n, start[4 * b + 1], start[4 * b + 2], start[4 * b + 3], Q.qp, ql, qdl, qddl);
-        if (rc) {
-            status[b] = st | kStQpFailed;
-            return;
-        }
-    } else {
-        for (int i = 0; i < n; ++i) ql[i] = dp_l[o + (size_t)i * dec];
-    }
     if (Q.midpoint) {                                                              // ref test_9.py:204-210
-        ps[0] = dp_s[o];
-        pl[0] = ql[0];
-        for (int i = 1; i < n; ++i) {
-            ps[i] = (dp_s[o + (size_t)i * dec] + dp_s[o + (size_t)(i - 1) * dec]) / 2.0;
-            pl[i] = (ql[i] + ql[i - 1]) / 2.0;
+        for (int i = lane; i <= n; i += 64) {
+            if (i == 0) {
+                ps[0] = sd[0];
+                pl[0] = ql[0];
+            } else if (i == n) {
+                ps[n] = sd[n - 1];
+                pl[n] = ql[n - 1];
+            } else {
+                ps[i] = (sd[i] + sd[i - 1]) / 2.0;
+                pl[i] = (ql[i] + ql[i - 1]) / 2.0;
+            }
         }
-        ps[n] = dp_s[o + (size_t)(n - 1) * dec];
-        pl[n] = ql[n - 1];
-        path_len[b] = n + 1;
+        if (lane == 0) path_len[b] = n + 1;
     } else {
-        for (int i = 0; i < n; ++i) {
-            ps[i] = dp_s[o + (size_t)i * dec];
+        for (int i = lane; i < n; i += 64) {
+            ps[i] = sd[i];
             pl[i] = ql[i];
         }
-        path_len[b] = n;
+        if (lane == 0) path_len[b] = n;
     }
-    status[b] = st;
+    if (lane == 0) status[b] = st;
 }
 
-// One cycle, last part (ref path_planning.py:15-49): Frenet->Cartesian, then x / y smoothing on two lanes.
-template <int MMAX>
-__global__ void cycle_cartesian_kernel(int B, int max_ref, int max_pts, SmoothQpParams sx, SmoothQpParams sy,
-                                       const double* __restrict__ ref_line, const double* __restrict__ s_map,
-                                       const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
-                                       const double* __restrict__ path_s, const double* __restrict__ path_l,
-                                       const int* __restrict__ path_len, double* __restrict__ traj,
-                                       int* __restrict__ traj_len, int* __restrict__ status) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = t >> 1, c = t & 1;
-    if (b >= B) return;
+// monotone index walk of cal_proj_point from index 0 (ref path_planning.py:62-64); *off_end when it runs past
+__device__ inline int walk_from_zero(const double* sm, int P, double s, bool* off_end) {
+    int k = 0;
+    *off_end = false;
+    while (true) {
+        if (k + 1 >= P) {
+            *off_end = true;
+            break;
+        }
+        if (!(sm[k + 1] < s)) break;
+        ++k;
+    }
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One cycle, last part (ref path_planning.py:15-49): Frenet->Cartesian one point per lane, x / y smoothing
+// on the two half-waves, heading / curvature one point per lane.  One wavefront per scene.
+// dynamic LDS (doubles): max_ref + 3*cap + 2 * BoxRangeQp::words(cap, cap)
+// The reference walks the s_map index monotonically from the previous point (:42-43); with a non-decreasing
+// s_map (what cal_s_map_fun produces) that equals a running maximum of independent walks from index 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel(
+    int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
+    const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
+    const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
+    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    double* sm = lds;                       // [max_ref]
+    double* txy = sm + max_ref;             // [cap][2] interleaved x, y
+    double* th = txy + 2 * cap;             // [cap]
+    double* qmem = th + cap;
     const int st = status[b];
-    if (c == 0) traj_len[b] = 0;
+    if (lane == 0) traj_len[b] = 0;
     if (st & (kStQpFailed | kStBoundIndex | kStTruncated)) return;
-    // both lanes of the pair redo the cheap Frenet->Cartesian walk and keep only their own coordinate
-    double txy[2 * MMAX];
-    bool s_err, trunc;
-    const int cap = (max_pts + 1 < MMAX) ? max_pts + 1 : MMAX;
-    const int m = frenet_path_to_xy(ref_line + (size_t)b * max_ref * 4, s_map + (size_t)b * max_ref, n_ref[b],
-                                    begin_sl[2 * b], begin_sl[2 * b + 1], path_s + (size_t)b * max_pts,
-                                    path_l + (size_t)b * max_pts, path_len[b], txy, cap, &s_err, &trunc);
-    if (s_err || trunc || m < 2) {
-        if (c == 0) atomicOr(&status[b], s_err ? kStSOutOfRange : (trunc ? kStTruncated : kStSmoothFailed));
+    const double* line = ref_line + (size_t)b * max_ref * 4;
+    const int P = n_ref[b];
+    const int n = path_len[b];
+    for (int i = lane; i < P; i += 64) sm[i] = s_map[(size_t)b * max_ref + i];
+    __syncthreads();
+    // planning start (ref :31-34)
+    bool off = false;
+    const double bs = begin_sl[2 * b], bl = begin_sl[2 * b + 1];
+    const int idx0 = walk_from_zero(sm, P, bs, &off);
+    if (off || P < 2) {
+        if (lane == 0) status[b] = st | kStSOutOfRange;
         return;
     }
-    BoxQp<MMAX> qp;
-    const int rc = qp.solve(txy + c, 2, m, c ? sy : sx);
+    if (lane == 0) {
+        const Node m0 = node_at(line, idx0);
+        const double ds = bs - sm[idx0];
+        const double th0 = m0.theta + m0.kappa * ds;
+        txy[0] = (m0.x + ds * cos(m0.theta)) + bl * (-sin(th0));
+        txy[1] = (m0.y + ds * sin(m0.theta)) + bl * cos(th0);
+    }
+    // path points: count = leading points with s <= s_map[-1] (ref :40-41), index = running max of walks
+    const double s_last = sm[P - 1];
+    int carry = idx0, count = n;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const double s = in ? path_s[(size_t)b * max_pts + i] : 0.0;
+        const int first_bad = __builtin_ffsll((long long)__ballot(in && s > s_last));   // 1-based lane, 0 if none
+        if (first_bad) count = min(count, base + first_bad - 1);
+        bool o2 = false;
+        int k = in ? walk_from_zero(sm, P, fmin(s, s_last), &o2) : 0;
+        for (int d = 1; d < 64; d <<= 1) {                 // inclusive running maximum across lanes
+            const int v = __shfl_up(k, d, 64);
+            if (lane >= d) k = max(k, v);
+        }
+        k = max(k, carry);
+        carry = __shfl(k, 63, 64);
+        if (in && i < count && i + 1 < cap) {
+            const Node mm = node_at(line, k);
+            const double ds = s - sm[k];
+            const double thp = mm.theta + mm.kappa * ds;
+            const double l = path_l[(size_t)b * max_pts + i];
+            txy[2 * (i + 1)] = (mm.x + ds * cos(mm.theta)) + l * (-sin(thp));       // ref :44-46
+            txy[2 * (i + 1) + 1] = (mm.y + ds * sin(mm.theta)) + l * cos(thp);
+        }
+        if (first_bad) break;
+    }
+    const int m = count + 1;
+    __syncthreads();
+    if (m > cap || m > max_pts + 1) {
+        if (lane == 0) status[b] = st | kStTruncated;
+        return;
+    }
+    if (m < 2) {
+        if (lane == 0) status[b] = st | kStSmoothFailed;
+        return;
+    }
+    int it = 0;
+    double *px = nullptr, *py = nullptr;
+    const int rc = smooth_pair_wave(qmem, txy, 2, m, sx, sy, &px, &py, &it);
     if (rc) {
-        atomicOr(&status[b], kStSmoothFailed);
+        if (lane == 0) status[b] = st | kStSmoothFailed;
         return;
     }
-    double* o = traj + (size_t)b * (max_pts + 1) * 4;
-    for (int i = 0; i < m; ++i) o[4 * i + c] = qp.x[i];
-    if (c == 0) traj_len[b] = m;
-}
-
-__global__ void cycle_heading_kernel(int B, int max_pts, int* __restrict__ traj_len, double* __restrict__ traj,
-                                     int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int m = traj_len[b];
-    if (status[b] & kStSmoothFailed) {
-        traj_len[b] = 0;   // one coordinate failed after the other lane had set the length
-        return;
-    }
-    if (m < 2) return;
-    double* o = traj + (size_t)b * (max_pts + 1) * 4;
-    heading_kappa(o, 4, m, o + 2, 4, o + 3, 4);
+    heading_kappa_wave(px, py, m, th, traj + (size_t)b * (max_pts + 1) * 4, 4);
+    if (lane == 0) traj_len[b] = m;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -18,20 +18,25 @@ double hc_segment_cost(double l0, double dl0, double ddl0, double l1, double s0,
 
 int hc_path_qp(int n, const double* l_min, const double* l_max, double l0, double dl0, double ddl0, const double* prm8,
                double* out_l, double* out_dl, double* out_ddl, int* iters) {
-    static PathQp<128> qp;
+    static double mem[path_qp_words(256)];
+    if (n > 256) return 2;
     PathQpParams p{prm8[0], prm8[1], prm8[2], prm8[3], prm8[4], prm8[5], prm8[6], prm8[7]};
-    const int rc = qp.solve(l_min, l_max, n, l0, dl0, ddl0, p, out_l, out_dl, out_ddl);
-    *iters = qp.iters;
-    return rc;
+    return path_qp_solve_scalar(mem, l_min, l_max, n, l0, dl0, ddl0, p, out_l, out_dl, out_ddl, iters);
 }
 
 int hc_box_qp(int m, const double* ref, int stride, double w_smooth, double w_length, double w_ref, double thr,
               double* out, int* iters) {
-    static BoxQp<256> qp;
+    static double mem[BoxRangeQp::words(256, 256)];
+    *iters = 0;
+    if (m > 256 || m < 2) return 2;
+    BoxRangeQp Q;
+    Q.bind(mem, m, m);
     SmoothQpParams p{w_smooth, w_length, w_ref, thr};
-    const int rc = qp.solve(ref, stride, m, p);
-    for (int i = 0; i < m && i < 256; ++i) out[i] = qp.x[i];
-    *iters = qp.iters;
+    int rc = box_qp_setup(Q, ref, stride, m, p);
+    if (rc) return rc;
+    rc = Q.solve_scalar();
+    *iters = Q.iters;
+    for (int i = 0; i < m; ++i) out[i] = Q.u[i];
     return rc;
 }
 
