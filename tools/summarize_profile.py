@@ -1,0 +1,65 @@
+"""Turn gpurun_out/prof_<TAG>/ (written by tools/profile.sh on the GPU box) into the tracked evidence under
+profiles/: the rocprofv3 --kernel-trace --stats table, the per-kernel PMC means (FETCH_SIZE / WRITE_SIZE, each
+from its own pass) and profiles/traffic.json, which bench.py reads for roofline.traffic.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
+gfx950 counts 128-B requests as 64 B for wide coalesced streaming reads, so read bytes = 2 x FETCH_SIZE x 1024;
+WRITE_SIZE is taken as is.  Usage: python tools/summarize_profile.py TAG [scenes_per_gpu]"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "bench_plain.json")):
+    shutil.copy(os.path.join(src, "bench_plain.json"), os.path.join(dst, f"{tag}_bench.json"))
+
+
+def short(name):
+    name = name.replace("void ", "").replace("emp::", "")
+    return name.split("(")[0]
+
+
+pmc = collections.defaultdict(dict)
+for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    agg = collections.defaultdict(list)
+    with open(os.path.join(src, f"pmc_{kind}", f"{tag}_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc[k][counter] = sum(v) / len(v)
+        pmc[k]["launches"] = len(v)
+
+stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
+lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps 20 --warmup 5` on one MI355X ({scenes} scenes/GPU)", "",
+         "`rocprofv3 --kernel-trace --stats` (all 25 launches: 5 warm-up + 20 timed):", "",
+         "| kernel | calls | mean us | % of GPU time |", "|---|---|---|---|"]
+for r in stats:
+    lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+lines += ["", "PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs), per-launch means:", "",
+          "| kernel | FETCH_SIZE KiB | read MB (x2 gfx950 correction) | WRITE_SIZE KiB | write MB |", "|---|---|---|---|---|"]
+with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
+    f.write("kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,read_bytes_corrected,write_bytes\n")
+    for k, v in sorted(pmc.items()):
+        fs, ws = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+        f.write(f"{k},{v.get('launches', 0)},{fs:.1f},{ws:.1f},{2 * fs * 1024:.0f},{ws * 1024:.0f}\n")
+        lines.append(f"| `{k}` | {fs:.0f} | {2 * fs * 1024 / 1e6:.1f} | {ws:.0f} | {ws * 1024 / 1e6:.1f} |")
+sweep = next((k for k in pmc if k.startswith("dp_sweep_kernel")), None)
+if sweep:
+    t = {"tag": tag, "kernel": "dp_sweep", "scenes_per_gpu": scenes,
+         "hbm_bytes_per_launch": int(2 * pmc[sweep].get("FETCH_SIZE", 0) * 1024 + pmc[sweep].get("WRITE_SIZE", 0) * 1024),
+         "method": "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (KiB counters; gfx950 FETCH_SIZE counts 128-B requests as 64 B)"}
+    json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    lines += ["", f"dp_sweep HBM traffic per launch: {t['hbm_bytes_per_launch'] / 1e6:.1f} MB "
+                  f"(algorithmic {(8 * (9 + 39 * 81) + 4 * 9 * 40 + 4 * 40) * scenes / 1e6:.1f} MB)"]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
