@@ -1,5 +1,7 @@
 // emp_api.hip - C-ABI of the MI355X EM-Planner hot path (see include/emplanner.h).
 // One translation unit: kernels are header-only templates, this file owns launches and staging.
+#include <stdlib.h>
+
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
 #include "emp_tail_kernels.h"
@@ -62,24 +64,28 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
 static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, const double* edge,
                         const int* n_obs, double* rows, double* min_cost, int* status) {
     if (d.B == 0) return EMP_OK;
-    dim3 grid((d.tiles + 3) / 4), block(256);
-    const size_t lds = (size_t)4 * d.col * 64;
-    EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the predecessor table in LDS");
+    static const int variant = getenv("EMP_SWEEP_VARIANT") ? atoi(getenv("EMP_SWEEP_VARIANT")) : 0;
     KernelTimer t(ctx, "dp_sweep");
-#define EMP_SWEEP(R, PD)                                                                                   \
-    do {                                                                                                   \
-        if (lds > 48 * 1024)                                                                               \
-            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD>,                          \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL((dp_sweep_kernel<R, PD>), grid, block, lds, ctx->stream, d, start_cost, edge,   \
-                           n_obs, rows, min_cost, status);                                                 \
+#define EMP_SWEEP(R, PD, WPB)                                                                               \
+    do {                                                                                                    \
+        const size_t lds = (size_t)(WPB) * (d.col * 64 + 64 * sizeof(double));                              \
+        EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the predecessor table in LDS");           \
+        if (lds > 48 * 1024)                                                                                \
+            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB>,                      \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                           ctx->stream, d, start_cost, edge, n_obs, rows, min_cost, status);                \
     } while (0)
     switch (d.row) {
-        case 5: EMP_SWEEP(5, 4); break;
-        case 9: EMP_SWEEP(9, 4); break;
-        case 12: EMP_SWEEP(12, 3); break;
-        case 21: EMP_SWEEP(21, 2); break;
-        default: EMP_SWEEP(0, 1); break;
+        case 5: EMP_SWEEP(5, 12, 1); break;
+        case 9:
+            if (variant == 1) EMP_SWEEP(9, 12, 1);
+            else if (variant == 2) EMP_SWEEP(9, 16, 1);
+            else EMP_SWEEP(9, 8, 1);
+            break;
+        case 12: EMP_SWEEP(12, 8, 1); break;
+        case 21: EMP_SWEEP(21, 6, 1); break;
+        default: EMP_SWEEP(0, 1, 1); break;
     }
 #undef EMP_SWEEP
     EMP_LAUNCH_CHECK(ctx);

@@ -168,22 +168,23 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
 // ---------------------------------------------------------------------------------------------
 // min-plus sweep + backtrack
 // ---------------------------------------------------------------------------------------------
-// One wavefront per tile of S scenes; block = 4 wavefronts.  LDS: predecessor bytes [wave][col][64].
+// One wavefront per tile of S scenes; block = WPB wavefronts.  LDS: predecessor bytes [wave][col][64].
 // ROW > 0: compile-time row count, register double buffer of PD columns (loads for the next group are
 // in flight while the current group is reduced).  ROW == 0: generic fallback with a runtime row count.
-template <int ROW, int PD>
-__global__ __launch_bounds__(256) void dp_sweep_kernel(DpDev P, const double* __restrict__ start_cost,
+template <int ROW, int PD, int WPB>
+__global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const double* __restrict__ start_cost,
                                                        const double* __restrict__ edge,
                                                        const int* __restrict__ n_obs,
                                                        double* __restrict__ rows_out,
                                                        double* __restrict__ min_cost_out,
                                                        int* __restrict__ status_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];   // [WPB][64] doubles, then [WPB][col][64] bytes
     const int row = ROW > 0 ? ROW : P.row;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
+    double* cost_lds = reinterpret_cast<double*>(pre_lds);
+    const int tile = blockIdx.x * WPB + wave;
     if (tile >= P.tiles) return;                         // whole wavefront exits together
-    unsigned char* pre = pre_lds + (size_t)wave * P.col * 64;
+    unsigned char* pre = pre_lds + (size_t)WPB * 64 * sizeof(double) + (size_t)wave * P.col * 64;
     const int s = lane / row, i = lane - s * row;
     const int b = tile * P.S + s;
     const bool live = (lane < P.S * row) && (b < P.B);
@@ -198,8 +199,18 @@ __global__ __launch_bounds__(256) void dp_sweep_kernel(DpDev P, const double* __
     }
     const double* tile_edge = edge + (size_t)tile * (P.col - 1) * row * 64 + lane;
 
+    // The previous column's cost front is exchanged through LDS: every lane stores its cost, then reads the
+    // `row` costs of its own scene (same address across the scene's lanes = broadcast).  DS operations of one
+    // wavefront execute in issue order, so the reads see the stores without a barrier; the reads carry
+    // immediate offsets and are issued back to back (one LDS round trip per column instead of `row` cross-lane
+    // permutes, each waited for).
+    double* front = cost_lds + wave * 64;
+    auto publish = [&]() {
+        front[lane] = cost;
+        __builtin_amdgcn_wave_barrier();
+    };
     auto relax_one = [&](double e, int k, double& best, int& arg) {
-        const double ck = __shfl(cost, base + k, 64);
+        const double ck = front[base + k];
         double cand = ck + e;                             // ref :340
         if (left) cand = cand + kLanePenalty;             // ref :342
         if (cand < best) {                                // strict, k ascending: lowest k wins ties (:344)
@@ -209,40 +220,64 @@ __global__ __launch_bounds__(256) void dp_sweep_kernel(DpDev P, const double* __
     };
 
     if constexpr (ROW > 0) {
-        double bufA[PD][ROW], bufB[PD][ROW];
-        auto load_group = [&](double (&buf)[PD][ROW], int j0) {
+        // Register ring of PD columns: column j's edges are loaded PD columns before they are reduced, so one
+        // wavefront keeps PD*ROW 512-byte rows in flight (the reduction of one column takes ~0.15 us, memory
+        // latency ~1-2 us: the ring must be >= ~12 columns deep to hide it).  Columns past the end re-read the
+        // last column (never used), which keeps the loads unconditional and the code straight-line.
+        const int last_col = P.col - 1;
+        double ring[PD][ROW];
+        auto load_col = [&](double (&dst)[ROW], int jcol) {
+            const int j = min(jcol, last_col);
+            const double* src = tile_edge + (size_t)(j - 1) * ROW * 64;
 #pragma unroll
-            for (int d = 0; d < PD; ++d) {
-                const int j = j0 + d;
-#pragma unroll
-                for (int k = 0; k < ROW; ++k)
-                    buf[d][k] = (j < P.col) ? tile_edge[((size_t)(j - 1) * ROW + k) * 64] : 0.0;
-            }
+            for (int k = 0; k < ROW; ++k) dst[k] = src[k * 64];
         };
-        auto relax_group = [&](double (&buf)[PD][ROW], int j0) {
+        auto relax_col = [&](const double (&e)[ROW], int j) {
+            publish();
+            // all `row` front values first (one LDS round trip), then the candidates, then a lexicographic
+            // (cost, k) tournament: strict '<' with k ascending == lowest k wins ties
+            double cand[ROW];
 #pragma unroll
-            for (int d = 0; d < PD; ++d) {
-                if (j0 + d < P.col) {
-                    double best = INF;
-                    int arg = 1;                          // ref :304 pre_node_index initialised to ones
+            for (int k = 0; k < ROW; ++k) cand[k] = front[base + k];
 #pragma unroll
-                    for (int k = 0; k < ROW; ++k) relax_one(buf[d][k], k, best, arg);
-                    cost = best;
-                    pre[(j0 + d) * 64 + lane] = (unsigned char)arg;
+            for (int k = 0; k < ROW; ++k) {
+                cand[k] = cand[k] + e[k];                             // ref :340
+                if (left) cand[k] = cand[k] + kLanePenalty;           // ref :342
+            }
+            int idx[ROW];
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) idx[k] = k;
+#pragma unroll
+            for (int span = 1; span < ROW; span <<= 1) {
+#pragma unroll
+                for (int k = 0; k + span < ROW; k += 2 * span) {
+                    // right operand has the larger k: it wins only when strictly smaller (or when the left one
+                    // is NaN, which the reference's `<` never accepts either)
+                    const bool take = (cand[k + span] < cand[k]) || (cand[k] != cand[k]);
+                    cand[k] = take ? cand[k + span] : cand[k];
+                    idx[k] = take ? idx[k + span] : idx[k];
                 }
             }
+            // ref :301/:304/:344: cost starts at +inf and the predecessor at 1; a candidate replaces them only if
+            // it is < inf (NaN and +inf candidates leave predecessor 1 in place)
+            const bool any = cand[0] < INF;
+            cost = any ? cand[0] : INF;
+            pre[j * 64 + lane] = (unsigned char)(any ? idx[0] : 1);
         };
-        load_group(bufA, 1);
-        for (int j0 = 1; j0 < P.col; j0 += 2 * PD) {
-            load_group(bufB, j0 + PD);
-            relax_group(bufA, j0);
-            load_group(bufA, j0 + 2 * PD);
-            relax_group(bufB, j0 + PD);
+#pragma unroll
+        for (int d = 0; d < PD; ++d) load_col(ring[d], 1 + d);
+        for (int j0 = 1; j0 < P.col; j0 += PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                if (j0 + d < P.col) relax_col(ring[d], j0 + d);
+                load_col(ring[d], j0 + d + PD);
+            }
         }
     } else {
         for (int j = 1; j < P.col; ++j) {
             double best = INF;
             int arg = 1;
+            publish();
             for (int k = 0; k < row; ++k) relax_one(tile_edge[((size_t)(j - 1) * row + k) * 64], k, best, arg);
             cost = best;
             pre[j * 64 + lane] = (unsigned char)arg;
@@ -253,8 +288,9 @@ __global__ __launch_bounds__(256) void dp_sweep_kernel(DpDev P, const double* __
     double best = INF;
     int arg = 0;
     bool first = true;
+    publish();
     for (int k = 0; k < row; ++k) {
-        const double ck = __shfl(cost, base + k, 64);
+        const double ck = front[base + k];
         if (first || ck < best) {
             best = ck;
             arg = k;
