@@ -411,6 +411,7 @@ static QpDev make_qp_dev(const emp_qp_params* q) {
     d.decimate = q->decimate > 0 ? q->decimate : 1;
     d.midpoint = q->midpoint;
     d.use_qp = q->use_qp;
+    d.debug_stage = q->reserved;
     return d;
 }
 

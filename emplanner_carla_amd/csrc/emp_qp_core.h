@@ -39,6 +39,11 @@
 namespace emp {
 
 constexpr int kQpMaxIter = 60;
+// Infeasible problems never close the primal residual: a full Newton step removes it entirely, and feasible
+// problems of this family take a full step within the first ~10 iterations.  A residual still above 1e-3 m after
+// kQpStallIter iterations is reported as failure instead of iterating until the multipliers overflow.
+constexpr int kQpStallIter = 24;
+constexpr double kQpStallResidual = 1e-3;
 
 // ---------------------------------------------------------------------------------------------
 // banded SPD Cholesky: A = U'U, upper band storage a[i*(KD+1)+d] = A[i][i+d]
@@ -200,6 +205,7 @@ struct RangeQp {
             if (rd_max <= eps_d_rel * dscale && rp_max <= eps_p && mu <= eps_mu) return 0;
             if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu <= 1000.0 * eps_mu) acceptable = true;
             if (!(mu == mu) || mu > 1e30) return 2;
+            if (iters >= kQpStallIter && rp_max > kQpStallResidual) return 2;
             // ---- M = P + G'WG
             for (int m = 0; m < N * B; ++m) M[m] = P[m];
             for (int t = 0; t < ns; ++t)

@@ -17,6 +17,25 @@
 
 namespace emp {
 
+// Hardware reciprocal / reciprocal square root seeds (v_rcp_f64, v_rsq_f64: ~2^-27 relative) plus Newton steps.
+// Not correctly rounded (a few ulp): used only inside the interior-point iteration, whose result is a fixed
+// point that does not depend on how the steps are rounded.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    // Newton for 1/sqrt(x): r <- r + r * (1 - x r^2) / 2
+    double e = __builtin_fma(-x * r, r, 1.0);
+    r = __builtin_fma(0.5 * r, e, r);
+    e = __builtin_fma(-x * r, r, 1.0);
+    r = __builtin_fma(0.5 * r, e, r);
+    return r;
+}
+
 template <int G>
 __device__ __forceinline__ double group_max(double v) {
 #pragma unroll
@@ -34,6 +53,98 @@ __device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
     for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Group-cooperative banded Cholesky / triangular solves for N <= G: lane gl of the group owns row gl of the
+// band in registers.  Each elimination step broadcasts one row with v_readlane (uniform lane index), so the
+// serial recurrence runs at register latency instead of LDS round trips.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ double group_bcast(double v, int k) {     // value of lane k of MY group (k uniform)
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    if constexpr (G == 64) {
+        r.i[0] = __builtin_amdgcn_readlane(a.i[0], k);
+        r.i[1] = __builtin_amdgcn_readlane(a.i[1], k);
+        return r.d;
+    } else {
+        static_assert(G == 32, "group size must be 32 or 64");
+        union { double d; int i[2]; } r1;
+        r.i[0] = __builtin_amdgcn_readlane(a.i[0], k);
+        r.i[1] = __builtin_amdgcn_readlane(a.i[1], k);
+        r1.i[0] = __builtin_amdgcn_readlane(a.i[0], 32 + k);
+        r1.i[1] = __builtin_amdgcn_readlane(a.i[1], 32 + k);
+        return ((threadIdx.x & 63) < 32) ? r.d : r1.d;
+    }
+}
+
+// Band row in registers: a[0..KD] = A[gl][gl..gl+KD].  On return a[] holds the factor row U[gl][..], rinv = 1/U[gl][gl]
+// and low[e] = U[gl-e][e] (the column entries the forward substitution needs).  ok == false if a pivot was <= 0
+// for this group.  Lanes gl >= N carry zeros and take part in the broadcasts.
+template <int G, int KD>
+__device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rinv, double (&low)[KD + 1], int N, int gl,
+                                                bool active) {
+    bool ok = true;
+    rinv = 0.0;
+    const int nmax = __builtin_amdgcn_readfirstlane(N);            // (same N for both groups of a wave)
+    for (int k = 0; k < nmax; ++k) {
+        double rowk[KD + 1];
+#pragma unroll
+        for (int d = 0; d <= KD; ++d) rowk[d] = group_bcast<G>(a[d], k);
+        const double piv = rowk[0];
+        if (active && !(piv > 0.0)) ok = false;
+        const double r = fast_rsqrt(piv > 0.0 ? piv : 1.0);
+        double u[KD + 1];
+        u[0] = piv * r;
+#pragma unroll
+        for (int d = 1; d <= KD; ++d) u[d] = rowk[d] * r;
+        if (gl == k) {
+#pragma unroll
+            for (int d = 0; d <= KD; ++d) a[d] = u[d];
+            rinv = r;
+        }
+        const int e = gl - k;                                      // rows k+1..k+KD get the rank-1 update
+#pragma unroll
+        for (int ee = 1; ee <= KD; ++ee) {
+            if (e == ee) {
+#pragma unroll
+                for (int c = 0; c + ee <= KD; ++c) a[c] -= u[ee] * u[ee + c];
+            }
+        }
+    }
+    // column entries for the forward substitution: low[e] = U[gl-e][e]
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int e = 1; e <= KD; ++e) {
+        const double v = __shfl(a[e], (gl - e >= 0) ? lane - e : lane, 64);
+        low[e] = (gl - e >= 0) ? v : 0.0;
+    }
+    low[0] = 0.0;
+    return ok;
+}
+
+// solve U'U x = b with the factor from band_chol_group; b (one entry per lane) is overwritten with x
+template <int G, int KD>
+__device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], double rinv, const double (&low)[KD + 1],
+                                                 double& b, int N, int gl) {
+    const int nmax = __builtin_amdgcn_readfirstlane(N);
+    for (int k = 0; k < nmax; ++k) {                               // U' y = b
+        const double yk = group_bcast<G>(b, k) * group_bcast<G>(rinv, k);
+        if (gl == k) b = yk;
+        const int e = gl - k;
+#pragma unroll
+        for (int ee = 1; ee <= KD; ++ee)
+            if (e == ee) b -= low[ee] * yk;
+    }
+    for (int k = nmax - 1; k >= 0; --k) {                          // U x = y
+        const double xk = group_bcast<G>(b, k) * group_bcast<G>(rinv, k);
+        if (gl == k) b = xk;
+        const int e = k - gl;
+#pragma unroll
+        for (int ee = 1; ee <= KD; ++ee)
+            if (e == ee) b -= a[ee] * xk;
+    }
 }
 
 // gather of per-row coefficients onto unknown m:  sum over (t, f, p) with t + off0 + p == m of g[f][p] * coef[t][f]
@@ -55,7 +166,7 @@ __device__ __forceinline__ double gather_rows(const RangeQp<KD, F, W>& Q, int m,
 // false for a group without a problem (it still takes part in every barrier).  Returns 0 ok / 2 failed (per
 // group; only meaningful where live).
 template <int G, int KD, int F, int W>
-__device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live) {
+__device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int iter_cap = 1000) {
     constexpr int B = KD + 1;
     const int N = Q.N, ns = Q.ns, items = ns * F, rows = items * 2;
     int state = (live && N > 0) ? 1 : 0;          // 1 running, 0 finished ok, 2 failed
@@ -138,17 +249,25 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live) {
             mu = group_sum<G>(mu) / (double)rows;
             const double dscale = fmax(qscale, zmax);
             if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
-            else if (!(mu == mu) || mu > 1e30) state = 2;
-            else if (iters >= kQpMaxIter) state = acceptable ? 0 : 2;
+            else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
+            else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
             if (rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu)
                 acceptable = true;
         }
         __syncthreads();
         const bool go = state == 1;
-        // ---- C: factorisation (serial recurrence, lane 0 of the group)
+        // ---- C: factorisation.  N <= G: register-resident, one band row per lane; otherwise lane 0 out of LDS.
         int ok = 1;
-        if (go && gl == 0) ok = band_chol<KD>(Q.M, N) ? 1 : 0;
-        ok = __shfl(ok, (threadIdx.x & 63) & ~(G - 1), 64);
+        double fa[KD + 1], flow[KD + 1], frinv = 0.0;
+        if (N <= G) {
+#pragma unroll
+            for (int d = 0; d <= KD; ++d) fa[d] = (go && gl < N) ? Q.M[gl * B + d] : 0.0;
+            ok = band_chol_group<G, KD>(fa, frinv, flow, N, gl, go) ? 1 : 0;
+            // (every lane of a group sees the same broadcast pivots, so `ok` is already uniform within the group)
+        } else {
+            if (go && gl == 0) ok = band_chol<KD>(Q.M, N) ? 1 : 0;
+            ok = __shfl(ok, (threadIdx.x & 63) & ~(G - 1), 64);
+        }
         if (go && !ok) state = acceptable ? 0 : 2;
         const bool go2 = state == 1;
         // ---- D: predictor coefficients  -(w rp - z)_upper + (w rp - z)_lower
@@ -165,7 +284,13 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live) {
         if (go2)
             for (int m = gl; m < N; m += G) Q.dua[m] = -Q.rhs[m] + gather_rows(Q, m, Q.tmp);
         __syncthreads();
-        if (go2 && gl == 0) band_solve<KD>(Q.M, Q.dua, N);
+        if (N <= G) {
+            double bb = (go2 && gl < N) ? Q.dua[gl] : 0.0;
+            band_solve_group<G, KD>(fa, frinv, flow, bb, N, gl);
+            if (go2 && gl < N) Q.dua[gl] = bb;
+        } else if (go2 && gl == 0) {
+            band_solve<KD>(Q.M, Q.dua, N);
+        }
         __syncthreads();
         // ---- G: affine step length and centring parameter
         if (go2) {
@@ -211,7 +336,13 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live) {
         if (go2)
             for (int m = gl; m < N; m += G) Q.rhs[m] = -Q.rhs[m] + gather_rows(Q, m, Q.tmp);
         __syncthreads();
-        if (go2 && gl == 0) band_solve<KD>(Q.M, Q.rhs, N);      // rhs = du
+        if (N <= G) {                                           // rhs = du
+            double bb = (go2 && gl < N) ? Q.rhs[gl] : 0.0;
+            band_solve_group<G, KD>(fa, frinv, flow, bb, N, gl);
+            if (go2 && gl < N) Q.rhs[gl] = bb;
+        } else if (go2 && gl == 0) {
+            band_solve<KD>(Q.M, Q.rhs, N);
+        }
         __syncthreads();
         // ---- K/L: step length, then update rows (s, z) and, after a barrier, the unknowns
         if (go2) {
@@ -255,38 +386,311 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fast path: N <= G and ns*F <= G, i.e. one constraint item and one unknown per lane.  Per-item state (slacks,
+// multipliers, bounds) and per-unknown state (Hessian row, factor row) stay in registers for the whole solve;
+// only the vectors that lanes exchange (u, directions, per-item coefficients) go through LDS.  Divisions: four
+// reciprocals per lane per iteration (1/s, 1/z), ratio tests use max(-d/x) with those reciprocals.
+// ---------------------------------------------------------------------------------------------
+template <int G, int KD, int F, int W>
+__device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live, int iter_cap) {
+    constexpr int B = KD + 1;
+    const int N = Q.N, ns = Q.ns, items = ns * F, rows = items * 2;
+    int state = (live && N > 0) ? 1 : 0;
+    int iters = 0;
+    bool acceptable = false;
+    // ---- item role
+    const bool has_it = live && gl < items;
+    const int t = has_it ? gl / F : 0, f = has_it ? gl - (gl / F) * F : 0;
+    const int kb = t + Q.off0;
+    double gw[W];
+#pragma unroll
+    for (int p = 0; p < W; ++p) gw[p] = Q.g[f][p];
+    const double c_it = has_it ? Q.c[gl] : 0.0, lo_it = has_it ? Q.lo[gl] : -1e300, hi_it = has_it ? Q.hi[gl] : 1e300;
+    auto win = [&](const double* vec) {
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+            const int k = kb + p;
+            if (k >= 0 && k < N) v += gw[p] * vec[k];
+        }
+        return v;
+    };
+    // ---- unknown role
+    const bool has_m = live && gl < N;
+    const int m = gl;
+    double Prow[B], Plow[B];
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) {
+        Prow[d] = (has_m && m + d < N) ? Q.P[m * B + d] : 0.0;
+        Plow[d] = (has_m && d >= 1 && m - d >= 0) ? Q.P[(m - d) * B + d] : 0.0;
+    }
+    const double q_m = has_m ? Q.q[m] : 0.0;
+    double u_m = has_m ? Q.u[m] : 0.0;
+    auto gather = [&](const double* coef) {
+        double acc = 0.0;
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+            const int tt = m - Q.off0 - p;
+            if (tt >= 0 && tt < ns) {
+#pragma unroll
+                for (int ff = 0; ff < F; ++ff) acc += Q.g[ff][p] * coef[tt * F + ff];
+            }
+        }
+        return acc;
+    };
+    // ---- initial slacks / multipliers
+    double qscale = group_max<G>(has_m ? fabs(q_m) : 0.0);
+    qscale = fmax(qscale, 1.0);
+    double su = 1.0, sl = 1.0, zu = 1.0, zl = 1.0;
+    {
+        const double v = c_it + win(Q.u);
+        su = hi_it - v;
+        sl = v - lo_it;
+        const double smin = group_min<G>(has_it ? fmin(su, sl) : 1e300);
+        const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
+        su += shift;
+        sl += shift;
+    }
+    while (__any(state == 1)) {
+        const bool run = state == 1;
+        // ---- 1: items: residuals, reciprocals, rd gather coefficient, barrier weight
+        const double v = c_it + win(Q.u);
+        const double rpu = v - hi_it + su, rpl = lo_it - v + sl;
+        const double isu = fast_rcp(su), isl = fast_rcp(sl), izu = fast_rcp(zu), izl = fast_rcp(zl);
+        const double wu = zu * isu, wl = zl * isl;
+        if (run && has_it) {
+            Q.tmp[gl] = zu - zl;
+            Q.wgt[gl] = wu + wl;
+        }
+        double rp_max = (run && has_it) ? fmax(fabs(rpu), fabs(rpl)) : 0.0;
+        double zmax = (run && has_it) ? fmax(zu, zl) : 0.0;
+        double mu = (run && has_it) ? (su * zu + sl * zl) : 0.0;
+        __syncthreads();
+        // ---- 2: unknowns: rd, normal-matrix row (registers)
+        double rd_m = 0.0;
+        double fa[B], flow[B], frinv = 0.0;
+#pragma unroll
+        for (int d = 0; d <= KD; ++d) fa[d] = 0.0;
+        if (run && has_m) {
+            double acc = q_m;
+#pragma unroll
+            for (int d = 0; d <= KD; ++d)
+                if (m + d < N) acc += Prow[d] * Q.u[m + d];
+#pragma unroll
+            for (int d = 1; d <= KD; ++d)
+                if (m - d >= 0) acc += Plow[d] * Q.u[m - d];
+            rd_m = acc + gather(Q.tmp);
+#pragma unroll
+            for (int d = 0; d <= KD; ++d) {
+                double e = Prow[d];
+                if (m + d < N) {
+#pragma unroll
+                    for (int p = 0; p + d < W; ++p) {
+                        const int tt = m - Q.off0 - p;
+                        if (tt >= 0 && tt < ns) {
+#pragma unroll
+                            for (int ff = 0; ff < F; ++ff) e += Q.wgt[tt * F + ff] * Q.g[ff][p] * Q.g[ff][p + d];
+                        }
+                    }
+                }
+                fa[d] = e;
+            }
+        }
+        {
+            double rd_max = (run && has_m) ? fabs(rd_m) : 0.0;
+#pragma unroll
+            for (int o = G / 2; o >= 1; o >>= 1) {          // four reductions in one butterfly
+                rd_max = fmax(rd_max, __shfl_xor(rd_max, o, 64));
+                rp_max = fmax(rp_max, __shfl_xor(rp_max, o, 64));
+                zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
+                mu += __shfl_xor(mu, o, 64);
+            }
+            mu /= (double)rows;
+            if (run) {
+                const double dscale = fmax(qscale, zmax);
+                if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
+                else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
+                else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
+                if (rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu)
+                    acceptable = true;
+            }
+        }
+        const bool go = state == 1;
+        // ---- 3: factorisation in registers
+        const bool okf = band_chol_group<G, KD>(fa, frinv, flow, N, gl, go);
+        if (go && !okf) state = acceptable ? 0 : 2;
+        const bool go2 = state == 1;
+        // ---- 4: predictor
+        if (go2 && has_it) Q.tmp[gl] = -((wu * rpu - zu) - (wl * rpl - zl));
+        __syncthreads();
+        double dua_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
+        band_solve_group<G, KD>(fa, frinv, flow, dua_m, N, gl);
+        if (go2 && has_m) Q.dua[m] = dua_m;
+        __syncthreads();
+        // ---- 5: affine step length, centring parameter, corrector coefficients
+        const double gda = win(Q.dua);
+        const double dsua = -rpu - gda, dsla = -rpl + gda;
+        const double dzua = -zu - wu * dsua, dzla = -zl - wl * dsla;
+        double ratio = 0.0;
+        if (go2 && has_it) ratio = fmax(fmax(-dsua * isu, -dsla * isl), fmax(-dzua * izu, -dzla * izl));
+        ratio = group_max<G>(ratio);
+        const double a_aff = (ratio > 1.0) ? fast_rcp(ratio) : 1.0;
+        double mu_aff = (go2 && has_it) ? ((su + a_aff * dsua) * (zu + a_aff * dzua) + (sl + a_aff * dsla) * (zl + a_aff * dzla)) : 0.0;
+        mu_aff = group_sum<G>(mu_aff) / (double)rows;
+        double sigma = (mu > 0.0) ? mu_aff / mu : 0.0;
+        sigma = sigma * sigma * sigma;
+        const double rcu = su * zu + dsua * dzua - sigma * mu, rcl = sl * zl + dsla * dzla - sigma * mu;
+        if (go2 && has_it) Q.tmp[gl] = -((zu * rpu - rcu) * isu - (zl * rpl - rcl) * isl);
+        __syncthreads();
+        double du_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
+        band_solve_group<G, KD>(fa, frinv, flow, du_m, N, gl);
+        if (go2 && has_m) Q.rhs[m] = du_m;
+        __syncthreads();
+        // ---- 6: step length and update
+        const double gd = win(Q.rhs);
+        const double dsu = -rpu - gd, dsl = -rpl + gd;
+        const double dzu = -(rcu + zu * dsu) * isu, dzl = -(rcl + zl * dsl) * isl;
+        ratio = 0.0;
+        if (go2 && has_it) ratio = fmax(fmax(-dsu * isu, -dsl * isl), fmax(-dzu * izu, -dzl * izl));
+        ratio = group_max<G>(ratio);
+        const double tau = (mu < 1e-6) ? 0.999 : 0.99;
+        const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
+        if (go2) {
+            if (has_it) {
+                su += alpha * dsu;
+                sl += alpha * dsl;
+                zu += alpha * dzu;
+                zl += alpha * dzl;
+            }
+            if (has_m) {
+                u_m += alpha * du_m;
+                Q.u[m] = u_m;
+            }
+            ++iters;
+        }
+        __syncthreads();
+    }
+    Q.iters = iters;
+    return state;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Path QP set-up, one station / one unknown per lane (same mathematics as path_qp_setup in emp_qp_core.h,
+// written as gathers so that no lane has to accumulate into another lane's entry).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bsp_a(int p) { return (p == 1) ? 4.0 / 6.0 : 1.0 / 6.0; }
+__device__ __forceinline__ double bsp_b(int p, double ids2) { return (p == 1) ? -2.0 * ids2 : ids2; }
+__device__ __forceinline__ double bsp_j(int p, double ids2) {
+    return ((p == 0) ? -1.0 : (p == 1) ? 3.0 : (p == 2) ? -3.0 : 1.0) * ids2;
+}
+// Hessian entry between coefficient indices jp and jp + d (0 <= d <= 3) of the full (n+2)-coefficient problem
+__device__ __forceinline__ double path_hess_entry(int jp, int d, int n, double wl2, double wd2, double wj2, double ids2) {
+    double acc = 0.0;
+    for (int i = max(0, jp + d - 2); i <= min(n - 1, jp); ++i)
+        acc += wl2 * bsp_a(jp - i) * bsp_a(jp + d - i) + wd2 * bsp_b(jp - i, ids2) * bsp_b(jp + d - i, ids2);
+    for (int i = max(0, jp + d - 3); i <= min(n - 2, jp); ++i) acc += wj2 * bsp_j(jp - i, ids2) * bsp_j(jp + d - i, ids2);
+    return acc;
+}
+
+__device__ inline int path_qp_setup_wave(PathRangeQp& Q, double* cc, const double* l_min, const double* l_max, int n,
+                                         double l0, double dl0, double ddl0, const PathQpParams& prm) {
+    const int lane = threadIdx.x & 63;
+    if (n < 4) return 2;
+    const int N = n - 4;
+    const double ds = prm.ds, ids2 = 1.0 / (ds * ds);
+    const double hw = fabs(prm.host_w) / 2.0;
+    const int fwd = (int)ceil(prm.d1 / ds), back = (int)ceil(prm.d2 / ds);       // ref :126-127
+    path_qp_forms(Q, prm);
+    const double c0 = l0 - ds * ds * ddl0 / 6.0;
+    const double cf[3] = {c0 + ds * ds * ddl0 / 2.0 - ds * dl0, c0, c0 + ds * ds * ddl0 / 2.0 + ds * dl0};   // c_{-1}, c_0, c_1
+    for (int j = lane; j < n + 2; j += 64) cc[j] = (j == 0) ? cf[0] : (j == 1) ? cf[1] : (j == 2) ? cf[2] : 0.0;
+    const double tol = 1e-9;
+    int bad = 0;
+    for (int i = lane; i < n; i += 64) {
+        const int i1 = (i + fwd < n - 1) ? i + fwd : n - 1;                       // ref :130
+        const int i2 = (i - back > 0) ? i - back : 0;                             // ref :131
+        const double ub = l_max[i1] - hw, lb = l_min[i2] + hw;
+        if (lb > ub + tol) bad = 1;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            double v = 0.0;                                                       // fixed part of the form
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int j = i + p;
+                const double cj = (j == 0) ? cf[0] : (j == 1) ? cf[1] : (j == 2) ? cf[2] : 0.0;
+                v += Q.g[f][p] * cj;
+            }
+            if (i == 0 || i == n - 1) {
+                if (v > ub + tol || v < lb - tol) bad = 1;
+            } else {
+                Q.c[(i - 1) * 2 + f] = v;
+                Q.lo[(i - 1) * 2 + f] = lb;
+                Q.hi[(i - 1) * 2 + f] = ub;
+            }
+        }
+    }
+    const double wl2 = 2.0 * (prm.w_l + prm.w_centre), wd2 = 2.0 * prm.w_ddl, wj2 = 2.0 * prm.w_dddl;
+    for (int m = lane; m < N; m += 64) {
+        const int j = m + 3;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) Q.P[m * 4 + d] = (m + d < N) ? path_hess_entry(j, d, n, wl2, wd2, wj2, ids2) : 0.0;
+        double qm = 0.0;
+        for (int i = max(0, j - 2); i <= min(n - 1, j); ++i)
+            qm += (-2.0 * prm.w_centre * ((l_min[i] + l_max[i]) / 2.0)) * bsp_a(j - i);   // ref :201-205
+        for (int jp = max(0, j - 3); jp <= 2; ++jp)                               // fixed start coefficients
+            qm += path_hess_entry(jp, j - jp, n, wl2, wd2, wj2, ids2) * ((jp == 0) ? cf[0] : (jp == 1) ? cf[1] : cf[2]);
+        Q.q[m] = qm;
+        Q.u[m] = 0.0;
+    }
+    return __any(bad) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Path QP on one wavefront.  lds: path_qp_words(n) doubles.  l_min / l_max / outputs may be LDS or global.
 // Every lane of the wavefront must call this (it contains barriers).  returns 0 ok, 1 infeasible, 2 failed.
 // ---------------------------------------------------------------------------------------------
 __device__ inline int path_qp_wave(double* lds, const double* l_min, const double* l_max, int n, double l0, double dl0,
                                    double ddl0, const PathQpParams& prm, double* out_l, double* out_dl,
-                                   double* out_ddl, int* iters_out) {
+                                   double* out_ddl, int* iters_out, int debug_stage = 0) {
     const int lane = threadIdx.x & 63;
     *iters_out = 0;
     if (n < 4) return 2;
     PathRangeQp Q;
     double* cc = lds;
     Q.bind(lds + n + 2, n - 4, n - 2);
-    int rc = 0;
-    if (lane == 0) rc = path_qp_setup(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm);
-    rc = __shfl(rc, 0, 64);
-    path_qp_forms(Q, prm);          // per-thread constants (lane 0's setup only filled its own copy)
+    int rc = path_qp_setup_wave(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm);
     __syncthreads();
     if (rc) return rc;
+    if (debug_stage == 2) return 2;
     if (Q.N > 0) {
         // start from the unconstrained minimiser P u = -q
-        for (int m = lane; m < Q.N * 4; m += 64) Q.M[m] = Q.P[m];
-        for (int m = lane; m < Q.N; m += 64) Q.u[m] = -Q.q[m];
-        __syncthreads();
         int ok = 1;
-        if (lane == 0) {
-            ok = band_chol<3>(Q.M, Q.N) ? 1 : 0;
-            if (ok) band_solve<3>(Q.M, Q.u, Q.N);
+        if (Q.N <= 64) {
+            double fa[4], flow[4], frinv = 0.0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) fa[d] = (lane < Q.N) ? Q.P[lane * 4 + d] : 0.0;
+            ok = band_chol_group<64, 3>(fa, frinv, flow, Q.N, lane, true) ? 1 : 0;
+            double b0 = (lane < Q.N) ? -Q.q[lane] : 0.0;
+            band_solve_group<64, 3>(fa, frinv, flow, b0, Q.N, lane);
+            if (lane < Q.N) Q.u[lane] = b0;
+        } else {
+            for (int m = lane; m < Q.N * 4; m += 64) Q.M[m] = Q.P[m];
+            for (int m = lane; m < Q.N; m += 64) Q.u[m] = -Q.q[m];
+            __syncthreads();
+            if (lane == 0) {
+                ok = band_chol<3>(Q.M, Q.N) ? 1 : 0;
+                if (ok) band_solve<3>(Q.M, Q.u, Q.N);
+            }
+            ok = __shfl(ok, 0, 64);
         }
-        ok = __shfl(ok, 0, 64);
         __syncthreads();
         if (!ok) return 2;
-        rc = range_qp_solve_wave<64>(Q, lane, true);
+        if (debug_stage == 3) return 2;
+        {
+            const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
+            if (Q.N <= 64 && Q.ns * 2 <= 64) rc = range_qp_solve_wave_fast<64>(Q, lane, true, cap_it);
+            else rc = range_qp_solve_wave<64>(Q, lane, true, cap_it);
+        }
         *iters_out = Q.iters;
         if (rc) return rc;
         for (int m = lane; m < Q.N; m += 64) cc[m + 3] = Q.u[m];
@@ -325,7 +729,8 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     __syncthreads();
     const int bad_setup = __any(rc != 0);
     if (bad_setup) return 2;
-    rc = range_qp_solve_wave<32>(Q, gl, true);
+    if (m <= 32) rc = range_qp_solve_wave_fast<32>(Q, gl, true, 1000);
+    else rc = range_qp_solve_wave<32>(Q, gl, true);
     const int it_mine = Q.iters;
     *iters_out = max(__shfl(it_mine, 0, 64), __shfl(it_mine, 32, 64));
     BoxRangeQp Q0, Q1;

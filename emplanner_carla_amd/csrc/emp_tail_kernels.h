@@ -23,6 +23,7 @@ struct QpDev {
     PathQpParams qp;
     double obs_length, obs_width;
     int decimate, midpoint, use_qp;
+    int debug_stage;   // development only: cut the QP kernel short after stage N (0 = run everything)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -360,9 +361,10 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
             lmax[j] = c;
         }
         __syncthreads();
+        if (Q.debug_stage == 1) return;
         int it = 0;
         const int rc = path_qp_wave(qmem, lmin, lmax, n, start[4 * b + 1], start[4 * b + 2], start[4 * b + 3], Q.qp, ql,
-                                    nullptr, nullptr, &it);
+                                    nullptr, nullptr, &it, Q.debug_stage);
         if (rc) {
             if (lane == 0) status[b] = st | kStQpFailed;
             return;
