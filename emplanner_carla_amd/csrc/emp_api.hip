@@ -422,8 +422,13 @@ static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const doub
                        const double* obs_xy, const int* n_obs, double* s_map, double* obs_s, double* obs_l,
                        double* begin_sl, double* start) {
     if (B == 0) return EMP_OK;
+    const size_t lds = (size_t)5 * max_ref * sizeof(double);
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "reference line too long for the LDS-resident projection kernel");
+    if (lds > 48 * 1024)
+        EMP_HIP(ctx, hipFuncSetAttribute((const void*)frenet_project_wave_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer t(ctx, "project");
-    hipLaunchKernelGGL(frenet_project_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_ref, max_obs, ref_line,
+    hipLaunchKernelGGL(frenet_project_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_ref, max_obs, ref_line,
                        n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs, s_map, obs_s, obs_l, begin_sl, start);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;

@@ -70,12 +70,11 @@ __device__ __forceinline__ double group_bcast(double v, int k) {     // value of
         return r.d;
     } else {
         static_assert(G == 32, "group size must be 32 or 64");
-        union { double d; int i[2]; } r1;
-        r.i[0] = __builtin_amdgcn_readlane(a.i[0], k);
-        r.i[1] = __builtin_amdgcn_readlane(a.i[1], k);
-        r1.i[0] = __builtin_amdgcn_readlane(a.i[0], 32 + k);
-        r1.i[1] = __builtin_amdgcn_readlane(a.i[1], 32 + k);
-        return ((threadIdx.x & 63) < 32) ? r.d : r1.d;
+        // two groups per wavefront need two different source lanes: one ds_bpermute per dword
+        const int src = (((threadIdx.x & 63) & 32) + k) << 2;
+        r.i[0] = __builtin_amdgcn_ds_bpermute(src, a.i[0]);
+        r.i[1] = __builtin_amdgcn_ds_bpermute(src, a.i[1]);
+        return r.d;
     }
 }
 
@@ -711,6 +710,38 @@ __device__ inline int path_qp_wave(double* lds, const double* l_min, const doubl
     return 0;
 }
 
+// Box-QP set-up, one point per lane of the 32-lane group (same mathematics as box_qp_setup in emp_qp_core.h)
+__device__ inline int box_qp_setup_group(BoxRangeQp& Q, const double* ref, int stride, int m, const SmoothQpParams& prm,
+                                         int gl) {
+    box_qp_forms(Q);
+    if (m < 2 || !(prm.thr > 0.0)) return 2;
+    for (int i = gl; i < m; i += 32) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double e = 0.0;
+            if (i + d < m) {
+                for (int r = max(0, i + d - 2); r <= min(m - 3, i); ++r) {       // second-difference rows (ws)
+                    const double a = (i - r == 1) ? -2.0 : 1.0, b = (i + d - r == 1) ? -2.0 : 1.0;
+                    e += 2.0 * prm.w_smooth * a * b;
+                }
+                for (int r = max(0, i + d - 1); r <= min(m - 2, i); ++r) {       // first-difference rows (wl)
+                    const double a = (i - r == 0) ? 1.0 : -1.0, b = (i + d - r == 0) ? 1.0 : -1.0;
+                    e += 2.0 * prm.w_length * a * b;
+                }
+                if (d == 0) e += 2.0 * prm.w_ref;
+            }
+            Q.P[i * 3 + d] = e;
+        }
+        const double r = ref[i * stride];
+        Q.q[i] = -2.0 * prm.w_ref * r;                                             // ref :346
+        Q.c[i] = 0.0;
+        Q.lo[i] = r - prm.thr;                                                     // ref :308-311
+        Q.hi[i] = r + prm.thr;
+        Q.u[i] = r;
+    }
+    return 0;
+}
+
 // Smoothing of one polyline on one wavefront: lanes 0-31 solve x, lanes 32-63 solve y.
 // lds: 2 * BoxRangeQp::words(m, m) doubles.  xy: [m][stride] with x at +0, y at +1 (LDS or global).
 // On success the smoothed coordinates are Q.u of each half: returned through out_x / out_y pointers INTO lds.
@@ -722,10 +753,7 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     BoxRangeQp Q;
     const int words = BoxRangeQp::words(m, m);
     Q.bind(lds + grp * words, m, m);
-    int rc = 0;
-    if (gl == 0) rc = box_qp_setup(Q, xy + grp, stride, m, grp ? sy : sx);
-    rc = __shfl(rc, grp * 32, 64);
-    box_qp_forms(Q);
+    int rc = box_qp_setup_group(Q, xy + grp, stride, m, grp ? sy : sx, gl);
     __syncthreads();
     const int bad_setup = __any(rc != 0);
     if (bad_setup) return 2;

@@ -68,6 +68,146 @@ __global__ void frenet_project_kernel(int B, int max_ref, int max_obs, const dou
     start[4 * b + 3] = fs.ddl_ds;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-parallel form of the cycle front (one wavefront per scene, one reference-line node per lane).
+// The reference's nearest-node scan (planning_utils.py:383-402) is an ordered scan with an early exit after
+// 50 consecutive non-improvements; in parallel that is: L_i = first index achieving min(d_0..d_i) (a prefix
+// minimum that keeps the FIRST occurrence, because only a strict '<' counts as an improvement), stop at the first
+// i with i - L_i >= 50, answer L_i there (or L_{P-1} if the scan never stops early).
+// ---------------------------------------------------------------------------------------------
+__device__ inline int match_scan_wave(const double* lx, const double* ly, int P, double x, double y, int limit) {
+    const int lane = threadIdx.x & 63;
+    double cd = __builtin_inf();     // carry: prefix minimum and its first index over the previous chunks
+    int ci = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int i = base + lane;
+        double d = __builtin_inf();
+        int li = i;
+        if (i < P) {
+            const double dx = lx[i] - x, dy = ly[i] - y;
+            d = sqrt(dx * dx + dy * dy);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {           // inclusive prefix-min keeping the earlier index on ties
+            const double od = __shfl_up(d, off, 64);
+            const int oi = __shfl_up(li, off, 64);
+            if (lane >= off && !(d < od)) {
+                d = od;
+                li = oi;
+            }
+        }
+        if (!(d < cd)) {                                   // fold the carry (earlier) in
+            d = cd;
+            li = ci;
+        }
+        const unsigned long long stop = __ballot(i < P && i - li >= limit);
+        if (stop) {
+            const int first = __builtin_ffsll((long long)stop) - 1;
+            return __shfl(li, first, 64);
+        }
+        const int last = min(63, P - 1 - base);
+        cd = __shfl(d, last, 64);
+        ci = __shfl(li, last, 64);
+    }
+    return ci;
+}
+
+// dynamic LDS (doubles): 5 * max_ref
+__global__ __launch_bounds__(64) void frenet_project_wave_kernel(
+    int B, int max_ref, int max_obs, const double* __restrict__ ref_line, const int* __restrict__ n_ref,
+    const double* __restrict__ origin_xy, const double* __restrict__ start_xy, const double* __restrict__ start_v,
+    const double* __restrict__ start_a, const double* __restrict__ obs_xy, const int* __restrict__ n_obs,
+    double* __restrict__ s_map, double* __restrict__ obs_s, double* __restrict__ obs_l, double* __restrict__ begin_sl,
+    double* __restrict__ start) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    double* lx = lds;
+    double* ly = lx + max_ref;
+    double* lth = ly + max_ref;
+    double* lk = lth + max_ref;
+    double* sm = lk + max_ref;
+    const double* line = ref_line + (size_t)b * max_ref * 4;
+    const int P = n_ref[b];
+    for (int i = lane; i < P; i += 64) {
+        lx[i] = line[4 * i];
+        ly[i] = line[4 * i + 1];
+        lth[i] = line[4 * i + 2];
+        lk[i] = line[4 * i + 3];
+    }
+    __syncthreads();
+    // cumulative chord length (ref planning_utils.py:461-466).  The chords are computed one per lane, but the
+    // running sum is formed strictly left to right like the reference's loop: the planning-start s inherits its
+    // last bits, and with an integer sample_s those bits decide int(end_s - start_s), i.e. the number of
+    // densified points (path_planning.py:405).
+    double carry = 0.0;
+    for (int base = 0; base < P; base += 64) {
+        const int i = base + lane;
+        double d = 0.0;
+        if (i >= 1 && i < P) {
+            const double dx = lx[i] - lx[i - 1], dy = ly[i] - ly[i - 1];
+            d = sqrt(dx * dx + dy * dy);
+        }
+        double mine = 0.0;
+        const int cnt = min(64, P - base);
+        for (int k = 0; k < cnt; ++k) {
+            union { double f; int w[2]; } a, r;
+            a.f = d;
+            r.w[0] = __builtin_amdgcn_readlane(a.w[0], k);
+            r.w[1] = __builtin_amdgcn_readlane(a.w[1], k);
+            carry = (base + k >= 1) ? r.f + carry : 0.0;          // s = chord + previous s
+            if (k == lane) mine = carry;
+        }
+        if (i < P) sm[i] = mine;
+    }
+    __syncthreads();
+    auto node = [&](int i) { return Node{lx[i], ly[i], lth[i], lk[i]}; };
+    // origin of the s axis (ref :457-471)
+    const double ox = origin_xy[2 * b], oy = origin_xy[2 * b + 1];
+    const int m0 = match_scan_wave(lx, ly, P, ox, oy, 50);
+    const double s0 = projection_s(node(m0), sm[m0], ox, oy);
+    __syncthreads();
+    for (int i = lane; i < P; i += 64) {
+        const double v = sm[i] - s0;
+        sm[i] = v;
+        s_map[(size_t)b * max_ref + i] = v;
+    }
+    __syncthreads();
+    // obstacles (ref test_9.py:122): matches one after the other (each scan is wave-parallel), then one
+    // obstacle per lane for the projection arithmetic; l uses the FIRST obstacle's match (quirk :413)
+    const int k = n_obs ? n_obs[b] : 0;
+    int my_match = 0, first_match = 0;
+    for (int j = 0; j < k; ++j) {
+        const double x = obs_xy[((size_t)b * max_obs + j) * 2], y = obs_xy[((size_t)b * max_obs + j) * 2 + 1];
+        const int mj = match_scan_wave(lx, ly, P, x, y, 50);
+        if (j == 0) first_match = mj;
+        if ((j & 63) == lane) my_match = mj;
+        if ((j & 63) == 63 || j == k - 1) {                 // flush a full set of lanes
+            const int jj = (j & ~63) + lane;
+            if (jj <= j) {
+                const double px = obs_xy[((size_t)b * max_obs + jj) * 2], py = obs_xy[((size_t)b * max_obs + jj) * 2 + 1];
+                obs_s[(size_t)b * max_obs + jj] = projection_s(node(my_match), sm[my_match], px, py);
+                obs_l[(size_t)b * max_obs + jj] = lateral_offset(project_on(node(first_match), px, py), px, py);
+            }
+        }
+    }
+    // planning start (ref test_9.py:134 and :172-177)
+    const double px = start_xy[2 * b], py = start_xy[2 * b + 1];
+    const int ms = match_scan_wave(lx, ly, P, px, py, 50);
+    if (lane == 0) {
+        const Node proj = project_on(node(ms), px, py);
+        const double bs = projection_s(node(ms), sm[ms], px, py);
+        if (begin_sl) {
+            begin_sl[2 * b] = bs;
+            begin_sl[2 * b + 1] = lateral_offset(proj, px, py);
+        }
+        const FrenetState fs = frenet_state(proj, px, py, start_v[2 * b], start_v[2 * b + 1], start_a[2 * b], start_a[2 * b + 1]);
+        start[4 * b + 0] = bs;
+        start[4 * b + 1] = fs.l;
+        start[4 * b + 2] = fs.dl_ds;
+        start[4 * b + 3] = fs.ddl_ds;
+    }
+}
+
 // ref: match_projection_points (mode 0) / find_match_points (mode 1), one lane per scene, points in order
 __global__ void match_points_kernel(int B, int max_ref, int max_pts, const double* __restrict__ ref_line,
                                     const int* __restrict__ n_ref, const double* __restrict__ xy,

@@ -169,3 +169,27 @@ def test_empty_and_bypass_batches(planner):
     # max_obs == 0 arrays
     rows, mc, st = planner.dp_plan(p, np.zeros((2, 0)), np.zeros((2, 0)), np.zeros(2, np.int32), start)
     assert np.array_equal(rows, np.full((2, 6), 5.5))
+
+
+def test_cfg5_wide_lattice_matches_exact_oracle(planner):
+    """BASELINE configs[4] lattice: col=120 x row=21, sample_s=1.0, 16 obstacles.  The reference's own quintic is
+    too ill-conditioned here to serve as the yardstick (1 m segments at s ~ 100 m: 4e-4 error in its own l,
+    SURVEY.md section 0), so this config is judged against the exact restatement, bit for bit."""
+    cfg = S.CFG5
+    b = S.make_batch(range(21), cfg)                      # 7 tiles of 3 scenes
+    p = _params(cfg)
+    c0, e = planner.dp_edge_costs(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    rc0, re = ex.edge_costs(b.sl_obs_s[:4], b.sl_obs_l[:4], b.n_obs[:4], b.sl_start[:4], cfg.row, cfg.col, cfg.sample_s,
+                            cfg.sample_l)
+    assert np.array_equal(c0[:4], rc0) and np.array_equal(e[:4], re)
+    rows, mc, st = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    xrows, xfeas, xpaths = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s,
+                                      cfg.sample_l, cfg.sampling_res, chunk=7)
+    assert np.array_equal(rows, xrows)
+    assert np.array_equal(st == 1, ~xfeas)
+    from emplanner_carla_amd.api import max_path_points
+    ps, pl, ln, st2 = planner.dp_enrich(p, rows, b.sl_start, max_path_points(p))
+    for i in range(len(rows)):
+        xs, xl = xpaths[i]
+        assert ln[i] == len(xs) == 121
+        assert np.array_equal(ps[i, :121], np.asarray(xs)) and np.array_equal(pl[i, :121], np.asarray(xl))
