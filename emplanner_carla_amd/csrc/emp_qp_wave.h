@@ -129,7 +129,7 @@ __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], doub
                                                  double& b, int N, int gl) {
     const int nmax = __builtin_amdgcn_readfirstlane(N);
     for (int k = 0; k < nmax; ++k) {                               // U' y = b
-        const double yk = group_bcast<G>(b, k) * group_bcast<G>(rinv, k);
+        const double yk = group_bcast<G>(b * rinv, k);             // lane k's b is final at step k
         if (gl == k) b = yk;
         const int e = gl - k;
 #pragma unroll
@@ -137,7 +137,7 @@ __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], doub
             if (e == ee) b -= low[ee] * yk;
     }
     for (int k = nmax - 1; k >= 0; --k) {                          // U x = y
-        const double xk = group_bcast<G>(b, k) * group_bcast<G>(rinv, k);
+        const double xk = group_bcast<G>(b * rinv, k);
         if (gl == k) b = xk;
         const int e = k - gl;
 #pragma unroll
@@ -385,43 +385,78 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fast path: N <= G and ns*F <= G, i.e. one constraint item and one unknown per lane.  Per-item state (slacks,
-// multipliers, bounds) and per-unknown state (Hessian row, factor row) stay in registers for the whole solve;
-// only the vectors that lanes exchange (u, directions, per-item coefficients) go through LDS.  Divisions: four
-// reciprocals per lane per iteration (1/s, 1/z), ratio tests use max(-d/x) with those reciprocals.
+// Fast path: N <= G and ns <= G, i.e. one station (with its F forms) and one unknown per lane.  Per-station
+// state (slacks, multipliers, bounds) and per-unknown state (Hessian row, factor row) stay in registers for the
+// whole solve; only the vectors that lanes exchange (u, directions, per-row coefficients) go through LDS, read
+// with clamped indices and zeroed weights instead of bounds branches.  Divisions: four reciprocals per row per
+// iteration (1/s, 1/z); ratio tests use max(-d/x) with those reciprocals.
 // ---------------------------------------------------------------------------------------------
 template <int G, int KD, int F, int W>
 __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live, int iter_cap) {
     constexpr int B = KD + 1;
-    const int N = Q.N, ns = Q.ns, items = ns * F, rows = items * 2;
+    const int N = Q.N, ns = Q.ns, rows = ns * F * 2;
     int state = (live && N > 0) ? 1 : 0;
     int iters = 0;
     bool acceptable = false;
-    // ---- item role
-    const bool has_it = live && gl < items;
-    const int t = has_it ? gl / F : 0, f = has_it ? gl - (gl / F) * F : 0;
-    const int kb = t + Q.off0;
-    double gw[W];
+    // ---- station role: window of unknowns t+off0 .. t+off0+W-1 (clamped index, zero weight when outside)
+    const bool has_t = live && gl < ns;
+    const int t = has_t ? gl : 0;
+    int kc[W];
+    double gm[F][W];
 #pragma unroll
-    for (int p = 0; p < W; ++p) gw[p] = Q.g[f][p];
-    const double c_it = has_it ? Q.c[gl] : 0.0, lo_it = has_it ? Q.lo[gl] : -1e300, hi_it = has_it ? Q.hi[gl] : 1e300;
-    auto win = [&](const double* vec) {
-        double v = 0.0;
+    for (int p = 0; p < W; ++p) {
+        const int k = t + Q.off0 + p;
+        const bool in = has_t && k >= 0 && k < N;
+        kc[p] = in ? k : 0;
 #pragma unroll
-        for (int p = 0; p < W; ++p) {
-            const int k = kb + p;
-            if (k >= 0 && k < N) v += gw[p] * vec[k];
+        for (int f = 0; f < F; ++f) gm[f][p] = in ? Q.g[f][p] : 0.0;
+    }
+    double c_it[F], lo_it[F], hi_it[F], su[F], sl[F], zu[F], zl[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        c_it[f] = has_t ? Q.c[t * F + f] : 0.0;
+        lo_it[f] = has_t ? Q.lo[t * F + f] : -1e300;
+        hi_it[f] = has_t ? Q.hi[t * F + f] : 1e300;
+        zu[f] = zl[f] = 1.0;
+    }
+    auto win = [&](const double* vec, double (&out)[F]) {
+        double vals[W];
+#pragma unroll
+        for (int p = 0; p < W; ++p) vals[p] = vec[kc[p]];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < W; ++p) v += gm[f][p] * vals[p];
+            out[f] = v;
         }
-        return v;
     };
-    // ---- unknown role
+    // ---- unknown role: Hessian row, symmetric partners, and the stations whose windows contain unknown m
     const bool has_m = live && gl < N;
-    const int m = gl;
+    const int m = has_m ? gl : 0;
     double Prow[B], Plow[B];
+    int up[B], dn[B];
 #pragma unroll
     for (int d = 0; d <= KD; ++d) {
         Prow[d] = (has_m && m + d < N) ? Q.P[m * B + d] : 0.0;
         Plow[d] = (has_m && d >= 1 && m - d >= 0) ? Q.P[(m - d) * B + d] : 0.0;
+        up[d] = (m + d < N) ? m + d : m;
+        dn[d] = (m - d >= 0) ? m - d : m;
+    }
+    int ti[W];
+    double gq[W][F];            // gather weights g[f][p] (0 when station m-off0-p does not exist)
+    double cM[B][W][F];         // normal-matrix weights g[f][p] g[f][p+d]
+#pragma unroll
+    for (int p = 0; p < W; ++p) {
+        const int tt = m - Q.off0 - p;
+        const bool in = has_m && tt >= 0 && tt < ns;
+        ti[p] = in ? tt : 0;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            gq[p][f] = in ? Q.g[f][p] : 0.0;
+#pragma unroll
+            for (int d = 0; d <= KD; ++d) cM[d][p][f] = (in && p + d < W && m + d < N) ? Q.g[f][p] * Q.g[f][p + d] : 0.0;
+        }
     }
     const double q_m = has_m ? Q.q[m] : 0.0;
     double u_m = has_m ? Q.u[m] : 0.0;
@@ -429,43 +464,57 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         double acc = 0.0;
 #pragma unroll
         for (int p = 0; p < W; ++p) {
-            const int tt = m - Q.off0 - p;
-            if (tt >= 0 && tt < ns) {
 #pragma unroll
-                for (int ff = 0; ff < F; ++ff) acc += Q.g[ff][p] * coef[tt * F + ff];
-            }
+            for (int f = 0; f < F; ++f) acc += gq[p][f] * coef[ti[p] * F + f];
         }
         return acc;
     };
-    // ---- initial slacks / multipliers
-    double qscale = group_max<G>(has_m ? fabs(q_m) : 0.0);
-    qscale = fmax(qscale, 1.0);
-    double su = 1.0, sl = 1.0, zu = 1.0, zl = 1.0;
+    // ---- initial slacks (pushed to >= 1) and unit multipliers
+    double qscale = fmax(group_max<G>(has_m ? fabs(q_m) : 0.0), 1.0);
     {
-        const double v = c_it + win(Q.u);
-        su = hi_it - v;
-        sl = v - lo_it;
-        const double smin = group_min<G>(has_it ? fmin(su, sl) : 1e300);
+        double v[F];
+        win(Q.u, v);
+        double smin = 1e300;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            su[f] = hi_it[f] - (c_it[f] + v[f]);
+            sl[f] = (c_it[f] + v[f]) - lo_it[f];
+            if (has_t) smin = fmin(smin, fmin(su[f], sl[f]));
+        }
+        smin = group_min<G>(smin);
         const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
-        su += shift;
-        sl += shift;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            su[f] += shift;
+            sl[f] += shift;
+        }
     }
     while (__any(state == 1)) {
         const bool run = state == 1;
-        // ---- 1: items: residuals, reciprocals, rd gather coefficient, barrier weight
-        const double v = c_it + win(Q.u);
-        const double rpu = v - hi_it + su, rpl = lo_it - v + sl;
-        const double isu = fast_rcp(su), isl = fast_rcp(sl), izu = fast_rcp(zu), izl = fast_rcp(zl);
-        const double wu = zu * isu, wl = zl * isl;
-        if (run && has_it) {
-            Q.tmp[gl] = zu - zl;
-            Q.wgt[gl] = wu + wl;
+        // ---- 1: stations: residuals, reciprocals, rd gather coefficient, barrier weight
+        double v[F], rpu[F], rpl[F], isu[F], isl[F], izu[F], izl[F], wu[F], wl[F];
+        win(Q.u, v);
+        double rp_max = 0.0, zmax = 0.0, mu = 0.0;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            rpu[f] = (c_it[f] + v[f]) - hi_it[f] + su[f];
+            rpl[f] = lo_it[f] - (c_it[f] + v[f]) + sl[f];
+            isu[f] = fast_rcp(su[f]);
+            isl[f] = fast_rcp(sl[f]);
+            izu[f] = fast_rcp(zu[f]);
+            izl[f] = fast_rcp(zl[f]);
+            wu[f] = zu[f] * isu[f];
+            wl[f] = zl[f] * isl[f];
+            if (run && has_t) {
+                Q.tmp[t * F + f] = zu[f] - zl[f];
+                Q.wgt[t * F + f] = wu[f] + wl[f];
+                rp_max = fmax(rp_max, fmax(fabs(rpu[f]), fabs(rpl[f])));
+                zmax = fmax(zmax, fmax(zu[f], zl[f]));
+                mu += su[f] * zu[f] + sl[f] * zl[f];
+            }
         }
-        double rp_max = (run && has_it) ? fmax(fabs(rpu), fabs(rpl)) : 0.0;
-        double zmax = (run && has_it) ? fmax(zu, zl) : 0.0;
-        double mu = (run && has_it) ? (su * zu + sl * zl) : 0.0;
         __syncthreads();
-        // ---- 2: unknowns: rd, normal-matrix row (registers)
+        // ---- 2: unknowns: rd and the normal-matrix row (registers)
         double rd_m = 0.0;
         double fa[B], flow[B], frinv = 0.0;
 #pragma unroll
@@ -473,25 +522,22 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         if (run && has_m) {
             double acc = q_m;
 #pragma unroll
-            for (int d = 0; d <= KD; ++d)
-                if (m + d < N) acc += Prow[d] * Q.u[m + d];
+            for (int d = 0; d <= KD; ++d) acc += Prow[d] * Q.u[up[d]];
 #pragma unroll
-            for (int d = 1; d <= KD; ++d)
-                if (m - d >= 0) acc += Plow[d] * Q.u[m - d];
+            for (int d = 1; d <= KD; ++d) acc += Plow[d] * Q.u[dn[d]];
             rd_m = acc + gather(Q.tmp);
+            double wv[W][F];
+#pragma unroll
+            for (int p = 0; p < W; ++p)
+#pragma unroll
+                for (int f = 0; f < F; ++f) wv[p][f] = Q.wgt[ti[p] * F + f];
 #pragma unroll
             for (int d = 0; d <= KD; ++d) {
                 double e = Prow[d];
-                if (m + d < N) {
 #pragma unroll
-                    for (int p = 0; p + d < W; ++p) {
-                        const int tt = m - Q.off0 - p;
-                        if (tt >= 0 && tt < ns) {
+                for (int p = 0; p < W; ++p)
 #pragma unroll
-                            for (int ff = 0; ff < F; ++ff) e += Q.wgt[tt * F + ff] * Q.g[ff][p] * Q.g[ff][p + d];
-                        }
-                    }
-                }
+                    for (int f = 0; f < F; ++f) e += wv[p][f] * cM[d][p][f];
                 fa[d] = e;
             }
         }
@@ -520,46 +566,75 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         if (go && !okf) state = acceptable ? 0 : 2;
         const bool go2 = state == 1;
         // ---- 4: predictor
-        if (go2 && has_it) Q.tmp[gl] = -((wu * rpu - zu) - (wl * rpl - zl));
+        if (go2 && has_t) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) Q.tmp[t * F + f] = -((wu[f] * rpu[f] - zu[f]) - (wl[f] * rpl[f] - zl[f]));
+        }
         __syncthreads();
         double dua_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
         band_solve_group<G, KD>(fa, frinv, flow, dua_m, N, gl);
         if (go2 && has_m) Q.dua[m] = dua_m;
         __syncthreads();
         // ---- 5: affine step length, centring parameter, corrector coefficients
-        const double gda = win(Q.dua);
-        const double dsua = -rpu - gda, dsla = -rpl + gda;
-        const double dzua = -zu - wu * dsua, dzla = -zl - wl * dsla;
+        double gda[F], dsua[F], dsla[F], dzua[F], dzla[F], rcu[F], rcl[F];
+        win(Q.dua, gda);
         double ratio = 0.0;
-        if (go2 && has_it) ratio = fmax(fmax(-dsua * isu, -dsla * isl), fmax(-dzua * izu, -dzla * izl));
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            dsua[f] = -rpu[f] - gda[f];
+            dsla[f] = -rpl[f] + gda[f];
+            dzua[f] = -zu[f] - wu[f] * dsua[f];
+            dzla[f] = -zl[f] - wl[f] * dsla[f];
+            if (go2 && has_t)
+                ratio = fmax(ratio, fmax(fmax(-dsua[f] * isu[f], -dsla[f] * isl[f]), fmax(-dzua[f] * izu[f], -dzla[f] * izl[f])));
+        }
         ratio = group_max<G>(ratio);
         const double a_aff = (ratio > 1.0) ? fast_rcp(ratio) : 1.0;
-        double mu_aff = (go2 && has_it) ? ((su + a_aff * dsua) * (zu + a_aff * dzua) + (sl + a_aff * dsla) * (zl + a_aff * dzla)) : 0.0;
+        double mu_aff = 0.0;
+        if (go2 && has_t) {
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+                mu_aff += (su[f] + a_aff * dsua[f]) * (zu[f] + a_aff * dzua[f]) + (sl[f] + a_aff * dsla[f]) * (zl[f] + a_aff * dzla[f]);
+        }
         mu_aff = group_sum<G>(mu_aff) / (double)rows;
-        double sigma = (mu > 0.0) ? mu_aff / mu : 0.0;
+        double sigma = (mu > 0.0) ? mu_aff * fast_rcp(mu) : 0.0;
         sigma = sigma * sigma * sigma;
-        const double rcu = su * zu + dsua * dzua - sigma * mu, rcl = sl * zl + dsla * dzla - sigma * mu;
-        if (go2 && has_it) Q.tmp[gl] = -((zu * rpu - rcu) * isu - (zl * rpl - rcl) * isl);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            rcu[f] = su[f] * zu[f] + dsua[f] * dzua[f] - sigma * mu;
+            rcl[f] = sl[f] * zl[f] + dsla[f] * dzla[f] - sigma * mu;
+            if (go2 && has_t) Q.tmp[t * F + f] = -((zu[f] * rpu[f] - rcu[f]) * isu[f] - (zl[f] * rpl[f] - rcl[f]) * isl[f]);
+        }
         __syncthreads();
         double du_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
         band_solve_group<G, KD>(fa, frinv, flow, du_m, N, gl);
         if (go2 && has_m) Q.rhs[m] = du_m;
         __syncthreads();
         // ---- 6: step length and update
-        const double gd = win(Q.rhs);
-        const double dsu = -rpu - gd, dsl = -rpl + gd;
-        const double dzu = -(rcu + zu * dsu) * isu, dzl = -(rcl + zl * dsl) * isl;
+        double gd[F], dsu[F], dsl[F], dzu[F], dzl[F];
+        win(Q.rhs, gd);
         ratio = 0.0;
-        if (go2 && has_it) ratio = fmax(fmax(-dsu * isu, -dsl * isl), fmax(-dzu * izu, -dzl * izl));
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            dsu[f] = -rpu[f] - gd[f];
+            dsl[f] = -rpl[f] + gd[f];
+            dzu[f] = -(rcu[f] + zu[f] * dsu[f]) * isu[f];
+            dzl[f] = -(rcl[f] + zl[f] * dsl[f]) * isl[f];
+            if (go2 && has_t)
+                ratio = fmax(ratio, fmax(fmax(-dsu[f] * isu[f], -dsl[f] * isl[f]), fmax(-dzu[f] * izu[f], -dzl[f] * izl[f])));
+        }
         ratio = group_max<G>(ratio);
         const double tau = (mu < 1e-6) ? 0.999 : 0.99;
         const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
         if (go2) {
-            if (has_it) {
-                su += alpha * dsu;
-                sl += alpha * dsl;
-                zu += alpha * dzu;
-                zl += alpha * dzl;
+            if (has_t) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    su[f] += alpha * dsu[f];
+                    sl[f] += alpha * dsl[f];
+                    zu[f] += alpha * dzu[f];
+                    zl[f] += alpha * dzl[f];
+                }
             }
             if (has_m) {
                 u_m += alpha * du_m;
@@ -687,7 +762,7 @@ __device__ inline int path_qp_wave(double* lds, const double* l_min, const doubl
         if (debug_stage == 3) return 2;
         {
             const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
-            if (Q.N <= 64 && Q.ns * 2 <= 64) rc = range_qp_solve_wave_fast<64>(Q, lane, true, cap_it);
+            if (Q.N <= 64 && Q.ns <= 64) rc = range_qp_solve_wave_fast<64>(Q, lane, true, cap_it);
             else rc = range_qp_solve_wave<64>(Q, lane, true, cap_it);
         }
         *iters_out = Q.iters;
