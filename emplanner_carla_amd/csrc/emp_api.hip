@@ -448,12 +448,18 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
                         int* status) {
     if (B == 0) return EMP_OK;
     const int cap = (max_pts + Q.decimate - 1) / Q.decimate;          // most stations a scene can have
-    const size_t lds = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
-    int rc = set_lds(ctx, cycle_qp_wave_kernel, lds);
-    if (rc) return rc;
+    const size_t per_group = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
+    int rc;
     KernelTimer t(ctx, "path_qp");
-    hipLaunchKernelGGL(cycle_qp_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_obs, cap, Q, dp_s, dp_l,
-                       dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+    if (cap <= 34) {                                                  // N, ns <= 32: two scenes per wavefront
+        if ((rc = set_lds(ctx, cycle_qp_wave_kernel<32>, 2 * per_group))) return rc;
+        hipLaunchKernelGGL(cycle_qp_wave_kernel<32>, dim3((B + 1) / 2), dim3(64), 2 * per_group, ctx->stream, B, max_pts,
+                           max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+    } else {
+        if ((rc = set_lds(ctx, cycle_qp_wave_kernel<64>, per_group))) return rc;
+        hipLaunchKernelGGL(cycle_qp_wave_kernel<64>, dim3(B), dim3(64), per_group, ctx->stream, B, max_pts, max_obs, cap, Q,
+                           dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+    }
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }

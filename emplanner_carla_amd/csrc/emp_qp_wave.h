@@ -49,6 +49,12 @@ __device__ __forceinline__ double group_min(double v) {
     return v;
 }
 template <int G>
+__device__ __forceinline__ bool group_any(bool p) {             // true if p holds on any lane of MY group
+    const unsigned long long m = __ballot(p);
+    if constexpr (G == 64) return m != 0ull;
+    else return ((m >> ((threadIdx.x & 63) & 32)) & 0xffffffffull) != 0ull;
+}
+template <int G>
 __device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
     for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -78,6 +84,13 @@ __device__ __forceinline__ double group_bcast(double v, int k) {     // value of
     }
 }
 
+template <int G>
+__device__ __forceinline__ int group_nmax(int N) {                 // largest N over the groups of this wavefront
+    int n0 = __builtin_amdgcn_readlane(N, 0);
+    if constexpr (G == 32) n0 = max(n0, __builtin_amdgcn_readlane(N, 32));
+    return n0;
+}
+
 // Band row in registers: a[0..KD] = A[gl][gl..gl+KD].  On return a[] holds the factor row U[gl][..], rinv = 1/U[gl][gl]
 // and low[e] = U[gl-e][e] (the column entries the forward substitution needs).  ok == false if a pivot was <= 0
 // for this group.  Lanes gl >= N carry zeros and take part in the broadcasts.
@@ -86,13 +99,13 @@ __device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rin
                                                 bool active) {
     bool ok = true;
     rinv = 0.0;
-    const int nmax = __builtin_amdgcn_readfirstlane(N);            // (same N for both groups of a wave)
+    const int nmax = group_nmax<G>(N);                             // groups of one wavefront may differ in size
     for (int k = 0; k < nmax; ++k) {
         double rowk[KD + 1];
 #pragma unroll
         for (int d = 0; d <= KD; ++d) rowk[d] = group_bcast<G>(a[d], k);
         const double piv = rowk[0];
-        if (active && !(piv > 0.0)) ok = false;
+        if (active && k < N && !(piv > 0.0)) ok = false;
         const double r = fast_rsqrt(piv > 0.0 ? piv : 1.0);
         double u[KD + 1];
         u[0] = piv * r;
@@ -127,7 +140,7 @@ __device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rin
 template <int G, int KD>
 __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], double rinv, const double (&low)[KD + 1],
                                                  double& b, int N, int gl) {
-    const int nmax = __builtin_amdgcn_readfirstlane(N);
+    const int nmax = group_nmax<G>(N);
     for (int k = 0; k < nmax; ++k) {                               // U' y = b
         const double yk = group_bcast<G>(b * rinv, k);             // lane k's b is final at step k
         if (gl == k) b = yk;
@@ -666,21 +679,22 @@ __device__ __forceinline__ double path_hess_entry(int jp, int d, int n, double w
     return acc;
 }
 
-__device__ inline int path_qp_setup_wave(PathRangeQp& Q, double* cc, const double* l_min, const double* l_max, int n,
-                                         double l0, double dl0, double ddl0, const PathQpParams& prm) {
-    const int lane = threadIdx.x & 63;
-    if (n < 4) return 2;
+template <int G>
+__device__ inline int path_qp_setup_group(PathRangeQp& Q, double* cc, const double* l_min, const double* l_max, int n,
+                                          double l0, double dl0, double ddl0, const PathQpParams& prm, int gl, bool live) {
+    path_qp_forms(Q, prm);
+    if (!live) n = 0;                       // a group without a problem runs every loop zero times
+    if (live && n < 4) return 2;
     const int N = n - 4;
     const double ds = prm.ds, ids2 = 1.0 / (ds * ds);
     const double hw = fabs(prm.host_w) / 2.0;
     const int fwd = (int)ceil(prm.d1 / ds), back = (int)ceil(prm.d2 / ds);       // ref :126-127
-    path_qp_forms(Q, prm);
     const double c0 = l0 - ds * ds * ddl0 / 6.0;
     const double cf[3] = {c0 + ds * ds * ddl0 / 2.0 - ds * dl0, c0, c0 + ds * ds * ddl0 / 2.0 + ds * dl0};   // c_{-1}, c_0, c_1
-    for (int j = lane; j < n + 2; j += 64) cc[j] = (j == 0) ? cf[0] : (j == 1) ? cf[1] : (j == 2) ? cf[2] : 0.0;
+    for (int j = gl; j < (live ? n + 2 : 0); j += G) cc[j] = (j == 0) ? cf[0] : (j == 1) ? cf[1] : (j == 2) ? cf[2] : 0.0;
     const double tol = 1e-9;
     int bad = 0;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = gl; i < n; i += G) {
         const int i1 = (i + fwd < n - 1) ? i + fwd : n - 1;                       // ref :130
         const int i2 = (i - back > 0) ? i - back : 0;                             // ref :131
         const double ub = l_max[i1] - hw, lb = l_min[i2] + hw;
@@ -704,7 +718,7 @@ __device__ inline int path_qp_setup_wave(PathRangeQp& Q, double* cc, const doubl
         }
     }
     const double wl2 = 2.0 * (prm.w_l + prm.w_centre), wd2 = 2.0 * prm.w_ddl, wj2 = 2.0 * prm.w_dddl;
-    for (int m = lane; m < N; m += 64) {
+    for (int m = gl; m < (live ? N : 0); m += G) {
         const int j = m + 3;
 #pragma unroll
         for (int d = 0; d < 4; ++d) Q.P[m * 4 + d] = (m + d < N) ? path_hess_entry(j, d, n, wl2, wd2, wj2, ids2) : 0.0;
@@ -716,73 +730,82 @@ __device__ inline int path_qp_setup_wave(PathRangeQp& Q, double* cc, const doubl
         Q.q[m] = qm;
         Q.u[m] = 0.0;
     }
-    return __any(bad) ? 1 : 0;
+    return group_any<G>(bad != 0) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Path QP on one wavefront.  lds: path_qp_words(n) doubles.  l_min / l_max / outputs may be LDS or global.
-// Every lane of the wavefront must call this (it contains barriers).  returns 0 ok, 1 infeasible, 2 failed.
+// Path QP on one GROUP of G lanes (G = 64: one scene per wavefront, G = 32: two scenes side by side).
+// lds: this group's path_qp_words(n) doubles.  l_min / l_max / outputs may be LDS or global.  EVERY lane of the
+// wavefront must call this (it contains barriers); a group with live == false only takes part in them.
+// G = 32 requires n <= 34 (N, ns <= 32).  returns (per group) 0 ok, 1 infeasible, 2 failed.
 // ---------------------------------------------------------------------------------------------
-__device__ inline int path_qp_wave(double* lds, const double* l_min, const double* l_max, int n, double l0, double dl0,
-                                   double ddl0, const PathQpParams& prm, double* out_l, double* out_dl,
-                                   double* out_ddl, int* iters_out, int debug_stage = 0) {
-    const int lane = threadIdx.x & 63;
+template <int G>
+__device__ inline int path_qp_group(double* lds, const double* l_min, const double* l_max, int n, double l0, double dl0,
+                                    double ddl0, const PathQpParams& prm, double* out_l, double* out_dl,
+                                    double* out_ddl, int* iters_out, bool live, int debug_stage = 0) {
+    const int gl = (threadIdx.x & 63) & (G - 1);
     *iters_out = 0;
-    if (n < 4) return 2;
     PathRangeQp Q;
     double* cc = lds;
-    Q.bind(lds + n + 2, n - 4, n - 2);
-    int rc = path_qp_setup_wave(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm);
+    const int nn = live ? n : 4;
+    Q.bind(lds + nn + 2, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
+    int rc = path_qp_setup_group<G>(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm, gl, live);
+    if (!live) rc = 2;
+    if (debug_stage == 2) rc = 2;
     __syncthreads();
-    if (rc) return rc;
-    if (debug_stage == 2) return 2;
-    if (Q.N > 0) {
-        // start from the unconstrained minimiser P u = -q
-        int ok = 1;
-        if (Q.N <= 64) {
-            double fa[4], flow[4], frinv = 0.0;
+    bool ok = rc == 0;
+    const bool small = Q.N <= G && Q.ns <= G;          // G = 32: guaranteed by the launcher
+    // ---- start from the unconstrained minimiser P u = -q
+    if (small || G == 32) {
+        double fa[4], flow[4], frinv = 0.0;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) fa[d] = (lane < Q.N) ? Q.P[lane * 4 + d] : 0.0;
-            ok = band_chol_group<64, 3>(fa, frinv, flow, Q.N, lane, true) ? 1 : 0;
-            double b0 = (lane < Q.N) ? -Q.q[lane] : 0.0;
-            band_solve_group<64, 3>(fa, frinv, flow, b0, Q.N, lane);
-            if (lane < Q.N) Q.u[lane] = b0;
-        } else {
-            for (int m = lane; m < Q.N * 4; m += 64) Q.M[m] = Q.P[m];
-            for (int m = lane; m < Q.N; m += 64) Q.u[m] = -Q.q[m];
-            __syncthreads();
-            if (lane == 0) {
-                ok = band_chol<3>(Q.M, Q.N) ? 1 : 0;
-                if (ok) band_solve<3>(Q.M, Q.u, Q.N);
-            }
-            ok = __shfl(ok, 0, 64);
-        }
-        __syncthreads();
-        if (!ok) return 2;
-        if (debug_stage == 3) return 2;
-        {
-            const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
-            if (Q.N <= 64 && Q.ns <= 64) rc = range_qp_solve_wave_fast<64>(Q, lane, true, cap_it);
-            else rc = range_qp_solve_wave<64>(Q, lane, true, cap_it);
-        }
-        *iters_out = Q.iters;
-        if (rc) return rc;
-        for (int m = lane; m < Q.N; m += 64) cc[m + 3] = Q.u[m];
+        for (int d = 0; d < 4; ++d) fa[d] = (ok && gl < Q.N) ? Q.P[gl * 4 + d] : 0.0;
+        const bool okc = band_chol_group<G, 3>(fa, frinv, flow, Q.N, gl, ok && Q.N > 0);
+        double b0 = (ok && gl < Q.N) ? -Q.q[gl] : 0.0;
+        band_solve_group<G, 3>(fa, frinv, flow, b0, Q.N, gl);
+        if (ok && gl < Q.N) Q.u[gl] = b0;
+        if (ok && !okc) rc = 2;
     } else {
-        int bad = 0;
-        for (int it = lane; it < Q.ns * 2; it += 64)
-            if (Q.c[it] > Q.hi[it] + 1e-9 || Q.c[it] < Q.lo[it] - 1e-9) bad = 1;
-        if (__any(bad)) return 1;
+        for (int m = gl; m < (ok ? Q.N * 4 : 0); m += G) Q.M[m] = Q.P[m];
+        for (int m = gl; m < (ok ? Q.N : 0); m += G) Q.u[m] = -Q.q[m];
+        __syncthreads();
+        int okc = 1;
+        if (ok && gl == 0 && Q.N > 0) {
+            okc = band_chol<3>(Q.M, Q.N) ? 1 : 0;
+            if (okc) band_solve<3>(Q.M, Q.u, Q.N);
+        }
+        okc = __shfl(okc, 0, 64);
+        if (ok && !okc) rc = 2;
     }
+    if (debug_stage == 3) rc = 2;
+    __syncthreads();
+    ok = rc == 0;
+    const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
+    int rs;
+    if (small || G == 32) rs = range_qp_solve_wave_fast<G>(Q, gl, ok && Q.N > 0, cap_it);
+    else rs = range_qp_solve_wave<G>(Q, gl, ok && Q.N > 0, cap_it);
+    if (ok && Q.N > 0) {
+        *iters_out = Q.iters;
+        if (rs) rc = rs;
+    }
+    ok = rc == 0;
+    if (ok && Q.N == 0) {                                // nothing free: only check the constant forms
+        bool bad = false;
+        for (int it = gl; it < Q.ns * 2; it += G)
+            if (Q.c[it] > Q.hi[it] + 1e-9 || Q.c[it] < Q.lo[it] - 1e-9) bad = true;
+        if (group_any<G>(bad)) rc = 1;
+    }
+    ok = rc == 0;
+    for (int m = gl; m < (ok ? Q.N : 0); m += G) cc[m + 3] = Q.u[m];
     __syncthreads();
     const double ds = prm.ds;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = gl; i < (ok ? n : 0); i += G) {
         out_l[i] = (cc[i] + 4.0 * cc[i + 1] + cc[i + 2]) / 6.0;
         if (out_dl) out_dl[i] = (cc[i + 2] - cc[i]) / (2.0 * ds);
         if (out_ddl) out_ddl[i] = (cc[i] - 2.0 * cc[i + 1] + cc[i + 2]) / (ds * ds);
     }
     __syncthreads();
-    return 0;
+    return rc;
 }
 
 // Box-QP set-up, one point per lane of the 32-lane group (same mathematics as box_qp_setup in emp_qp_core.h)

@@ -347,9 +347,9 @@ __global__ __launch_bounds__(64) void path_qp_wave_kernel(int B, int max_pts, in
     const int n = n_pts[b];
     int it = 0;
     int rc = 2;
-    if (n <= cap && n <= max_pts)
-        rc = path_qp_wave(lds, l_min + o, l_max + o, n, start_l3[3 * b], start_l3[3 * b + 1], start_l3[3 * b + 2], Q.qp,
-                          qp_l + o, qp_dl + o, qp_ddl + o, &it);
+    const bool fits = n <= cap && n <= max_pts;
+    rc = path_qp_group<64>(lds, l_min + o, l_max + o, n, start_l3[3 * b], start_l3[3 * b + 1], start_l3[3 * b + 2], Q.qp,
+                           qp_l + o, qp_dl + o, qp_ddl + o, &it, fits);
     if ((threadIdx.x & 63) == 0) {
         if (iters) iters[b] = it;
         status[b] = rc ? kStQpFailed : 0;
@@ -431,8 +431,10 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 
 // ---------------------------------------------------------------------------------------------
 // One cycle, middle part (ref test_9.py:187-210): decimate -> bounds -> path QP -> midpoints.
-// One wavefront per scene.  dynamic LDS (doubles): 5*cap + 4*max_obs + path_qp_words(cap)
+// One scene per GROUP of G lanes (G = 32: two scenes per wavefront when cap <= 34 stations, else G = 64).
+// dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)
 // ---------------------------------------------------------------------------------------------
+template <int G>
 __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, int max_obs, int cap, QpDev Q,
                                                            const double* __restrict__ dp_s,
                                                            const double* __restrict__ dp_l,
@@ -443,9 +445,14 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
                                                            const double* __restrict__ start,
                                                            double* __restrict__ path_s, double* __restrict__ path_l,
                                                            int* __restrict__ path_len, int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
-    const size_t o = (size_t)b * max_pts;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    constexpr int GPW = 64 / G;                                   // groups (scenes) per wavefront
+    const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
+    const int b = blockIdx.x * GPW + grp;
+    const bool present = b < B;
+    const int per_group = 5 * cap + 4 * max_obs + path_qp_words(cap);
+    double* lds = lds_all + (size_t)grp * per_group;
+    const size_t o = (size_t)(present ? b : 0) * max_pts;
     double* sd = lds;                 // decimated station s   [cap]
     double* ld = sd + cap;            // decimated DP l        [cap]
     double* lmin = ld + cap;          // [cap]
@@ -453,16 +460,14 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
     double* ql = lmax + cap;          // QP result l           [cap]
     double* otab = ql + cap;          // per obstacle: lo, hi, below, bound   [4*max_obs]
     double* qmem = otab + 4 * max_obs;
-    const int ne = dp_len[b];
+    const int ne = present ? dp_len[b] : 0;
     const int dec = Q.decimate > 0 ? Q.decimate : 1;
     const int n = (ne + dec - 1) / dec;                                            // len(x[::dec])
-    int st = status[b];
-    if (lane == 0) path_len[b] = 0;
-    if (n > cap || n + (Q.midpoint ? 1 : 0) > max_pts || n < 1) {
-        if (lane == 0) status[b] = st | kStTruncated;
-        return;
-    }
-    for (int i = lane; i < n; i += 64) {
+    const int st = present ? status[b] : 0;
+    int fail = 0;                      // status bits this kernel adds; once set the group idles through the barriers
+    if (present && (n > cap || n + (Q.midpoint ? 1 : 0) > max_pts || n < 1)) fail = kStTruncated;
+    bool live = present && !fail;
+    for (int i = gl; i < (live ? n : 0); i += G) {
         sd[i] = dp_s[o + (size_t)i * dec];
         ld[i] = dp_l[o + (size_t)i * dec];
     }
@@ -470,9 +475,9 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
     if (Q.use_qp) {
         // ---- cal_lmin_lmax (ref path_planning.py:222-273): one obstacle per lane finds its index range,
         // then one station per lane folds the (commutative) min / max over the obstacles covering it
-        const int nob = n_obs[b];
-        int bad = 0;
-        for (int k = lane; k < nob; k += 64) {
+        const int nob = live ? n_obs[b] : 0;
+        bool bad = false;
+        for (int k = gl; k < nob; k += G) {
             const double os = obs_s[(size_t)b * max_obs + k], ol = obs_l[(size_t)b * max_obs + k];
             const int lo = argmin_abs(sd, 1, n, os - Q.obs_length / 2.0) + 2;     // ref :240
             const int hi = argmin_abs(sd, 1, n, os + Q.obs_length / 2.0) + 2;     // ref :241
@@ -482,14 +487,14 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
             otab[4 * k + 1] = (double)hi;
             otab[4 * k + 2] = below ? 1.0 : 0.0;
             otab[4 * k + 3] = below ? ol - Q.obs_width / 2.0 : ol + Q.obs_width / 2.0;
-            if (lo <= hi && hi >= n) bad = 1;                                      // IndexError in the reference
+            if (lo <= hi && hi >= n) bad = true;                                   // IndexError in the reference
         }
-        if (__any(bad)) {
-            if (lane == 0) status[b] = st | kStBoundIndex;
-            return;
+        if (group_any<G>(bad) && live) {
+            fail = kStBoundIndex;
+            live = false;
         }
         __syncthreads();
-        for (int j = lane; j < n; j += 64) {
+        for (int j = gl; j < (live ? n : 0); j += G) {
             double a = -10.0, c = 10.0;                                            // ref :233-234
             for (int k = 0; k < nob; ++k) {
                 if ((double)j >= otab[4 * k] && (double)j <= otab[4 * k + 1]) {
@@ -501,42 +506,51 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
             lmax[j] = c;
         }
         __syncthreads();
-        if (Q.debug_stage == 1) return;
+        if (Q.debug_stage == 1) live = false;
         int it = 0;
-        const int rc = path_qp_wave(qmem, lmin, lmax, n, start[4 * b + 1], start[4 * b + 2], start[4 * b + 3], Q.qp, ql,
-                                    nullptr, nullptr, &it, Q.debug_stage);
-        if (rc) {
-            if (lane == 0) status[b] = st | kStQpFailed;
-            return;
+        const int sb = present ? b : 0;
+        const int rc = path_qp_group<G>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp,
+                                        ql, nullptr, nullptr, &it, live, Q.debug_stage);
+        if (live && rc) {
+            fail = kStQpFailed;
+            live = false;
         }
     } else {
-        for (int i = lane; i < n; i += 64) ql[i] = ld[i];
+        for (int i = gl; i < (live ? n : 0); i += G) ql[i] = ld[i];
         __syncthreads();
     }
-    double* ps = path_s + o;
-    double* pl = path_l + o;
-    if (Q.midpoint) {                                                              // ref test_9.py:204-210
-        for (int i = lane; i <= n; i += 64) {
-            if (i == 0) {
-                ps[0] = sd[0];
-                pl[0] = ql[0];
-            } else if (i == n) {
-                ps[n] = sd[n - 1];
-                pl[n] = ql[n - 1];
+    if (present) {
+        double* ps = path_s + o;
+        double* pl = path_l + o;
+        int plen = 0;
+        if (live) {
+            if (Q.midpoint) {                                                      // ref test_9.py:204-210
+                for (int i = gl; i <= n; i += G) {
+                    if (i == 0) {
+                        ps[0] = sd[0];
+                        pl[0] = ql[0];
+                    } else if (i == n) {
+                        ps[n] = sd[n - 1];
+                        pl[n] = ql[n - 1];
+                    } else {
+                        ps[i] = (sd[i] + sd[i - 1]) / 2.0;
+                        pl[i] = (ql[i] + ql[i - 1]) / 2.0;
+                    }
+                }
+                plen = n + 1;
             } else {
-                ps[i] = (sd[i] + sd[i - 1]) / 2.0;
-                pl[i] = (ql[i] + ql[i - 1]) / 2.0;
+                for (int i = gl; i < n; i += G) {
+                    ps[i] = sd[i];
+                    pl[i] = ql[i];
+                }
+                plen = n;
             }
         }
-        if (lane == 0) path_len[b] = n + 1;
-    } else {
-        for (int i = lane; i < n; i += 64) {
-            ps[i] = sd[i];
-            pl[i] = ql[i];
+        if (gl == 0) {
+            path_len[b] = plen;
+            status[b] = st | fail;
         }
-        if (lane == 0) path_len[b] = n;
     }
-    if (lane == 0) status[b] = st;
 }
 
 // monotone index walk of cal_proj_point from index 0 (ref path_planning.py:62-64); *off_end when it runs past
