@@ -741,26 +741,27 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.in(io->start_a, (size_t)B * 2, &d_a))) return rc;
     if ((rc = st.in(io->obs_xy, (size_t)B * max_obs * 2, &d_oxy))) return rc;
     if ((rc = st.in(io->n_obs, (size_t)B, &d_no))) return rc;
-    // outputs (optional ones fall back to device temporaries)
+    // outputs (optional ones fall back to device temporaries); no memsets: every kernel of the cycle writes its
+    // rows completely, padding included
     double *d_rows, *d_dps, *d_dpl, *d_ps, *d_pl, *d_traj;
     int *d_dplen, *d_plen, *d_tlen, *d_st;
-    if ((rc = st.out(io->dp_rows, (size_t)B * d.col, &d_rows))) return rc;
-    if (!d_rows && (rc = st.tmp((size_t)B * d.col, &d_rows))) return rc;
-    if ((rc = st.out(io->dp_s, (size_t)B * max_pts, &d_dps))) return rc;
-    if (!d_dps && (rc = st.tmp((size_t)B * max_pts, &d_dps))) return rc;
-    if ((rc = st.out(io->dp_l, (size_t)B * max_pts, &d_dpl))) return rc;
-    if (!d_dpl && (rc = st.tmp((size_t)B * max_pts, &d_dpl))) return rc;
-    if ((rc = st.out(io->dp_len, (size_t)B, &d_dplen))) return rc;
-    if (!d_dplen && (rc = st.tmp((size_t)B, &d_dplen))) return rc;
-    if ((rc = st.out(io->path_s, (size_t)B * max_pts, &d_ps))) return rc;
-    if (!d_ps && (rc = st.tmp((size_t)B * max_pts, &d_ps))) return rc;
-    if ((rc = st.out(io->path_l, (size_t)B * max_pts, &d_pl))) return rc;
-    if (!d_pl && (rc = st.tmp((size_t)B * max_pts, &d_pl))) return rc;
-    if ((rc = st.out(io->path_len, (size_t)B, &d_plen))) return rc;
-    if (!d_plen && (rc = st.tmp((size_t)B, &d_plen))) return rc;
-    if ((rc = st.out(io->traj, (size_t)B * (max_pts + 1) * 4, &d_traj))) return rc;
-    if ((rc = st.out(io->traj_len, (size_t)B, &d_tlen))) return rc;
-    if ((rc = st.out(io->status, (size_t)B, &d_st))) return rc;
+    if ((rc = st.out(io->dp_rows, (size_t)B * d.col, &d_rows, false))) return rc;
+    if (!d_rows && (rc = st.tmp((size_t)B * d.col, &d_rows, false))) return rc;
+    if ((rc = st.out(io->dp_s, (size_t)B * max_pts, &d_dps, false))) return rc;
+    if (!d_dps && (rc = st.tmp((size_t)B * max_pts, &d_dps, false))) return rc;
+    if ((rc = st.out(io->dp_l, (size_t)B * max_pts, &d_dpl, false))) return rc;
+    if (!d_dpl && (rc = st.tmp((size_t)B * max_pts, &d_dpl, false))) return rc;
+    if ((rc = st.out(io->dp_len, (size_t)B, &d_dplen, false))) return rc;
+    if (!d_dplen && (rc = st.tmp((size_t)B, &d_dplen, false))) return rc;
+    if ((rc = st.out(io->path_s, (size_t)B * max_pts, &d_ps, false))) return rc;
+    if (!d_ps && (rc = st.tmp((size_t)B * max_pts, &d_ps, false))) return rc;
+    if ((rc = st.out(io->path_l, (size_t)B * max_pts, &d_pl, false))) return rc;
+    if (!d_pl && (rc = st.tmp((size_t)B * max_pts, &d_pl, false))) return rc;
+    if ((rc = st.out(io->path_len, (size_t)B, &d_plen, false))) return rc;
+    if (!d_plen && (rc = st.tmp((size_t)B, &d_plen, false))) return rc;
+    if ((rc = st.out(io->traj, (size_t)B * (max_pts + 1) * 4, &d_traj, false))) return rc;
+    if ((rc = st.out(io->traj_len, (size_t)B, &d_tlen, false))) return rc;
+    if ((rc = st.out(io->status, (size_t)B, &d_st, false))) return rc;
     // intermediates
     double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
     const int mo = max_obs > 0 ? max_obs : 1;

@@ -363,6 +363,10 @@ __global__ void dp_enrich_kernel(DpDev P, const double* __restrict__ rows, const
         trunc = true;
     }
     path_len[b] = n;
+    for (int k = n; k < max_pts; ++k) {                                  // padding reads as 0
+        os[k] = 0.0;
+        ol[k] = 0.0;
+    }
     if (or_status) {
         if (trunc) status[b] |= 32;                                      // EMP_ST_TRUNCATED
     } else {

@@ -546,6 +546,10 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
                 plen = n;
             }
         }
+        for (int i = plen + gl; i < max_pts; i += G) {                           // padding reads as 0
+            ps[i] = 0.0;
+            pl[i] = 0.0;
+        }
         if (gl == 0) {
             path_len[b] = plen;
             status[b] = st | fail;
@@ -587,8 +591,9 @@ __global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel(
     double* th = txy + 2 * cap;             // [cap]
     double* qmem = th + cap;
     const int st = status[b];
-    if (lane == 0) traj_len[b] = 0;
-    if (st & (kStQpFailed | kStBoundIndex | kStTruncated)) return;
+    double* out_rows = traj + (size_t)b * (max_pts + 1) * 4;
+    auto body = [&]() -> int {          // returns the number of trajectory points (0 = none); wave-uniform control flow
+    if (st & (kStQpFailed | kStBoundIndex | kStTruncated)) return 0;
     const double* line = ref_line + (size_t)b * max_ref * 4;
     const int P = n_ref[b];
     const int n = path_len[b];
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel(
     const int idx0 = walk_from_zero(sm, P, bs, &off);
     if (off || P < 2) {
         if (lane == 0) status[b] = st | kStSOutOfRange;
-        return;
+        return 0;
     }
     if (lane == 0) {
         const Node m0 = node_at(line, idx0);
@@ -640,21 +645,25 @@ __global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel(
     __syncthreads();
     if (m > cap || m > max_pts + 1) {
         if (lane == 0) status[b] = st | kStTruncated;
-        return;
+        return 0;
     }
     if (m < 2) {
         if (lane == 0) status[b] = st | kStSmoothFailed;
-        return;
+        return 0;
     }
     int it = 0;
     double *px = nullptr, *py = nullptr;
     const int rc = smooth_pair_wave(qmem, txy, 2, m, sx, sy, &px, &py, &it);
     if (rc) {
         if (lane == 0) status[b] = st | kStSmoothFailed;
-        return;
+        return 0;
     }
-    heading_kappa_wave(px, py, m, th, traj + (size_t)b * (max_pts + 1) * 4, 4);
-    if (lane == 0) traj_len[b] = m;
+    heading_kappa_wave(px, py, m, th, out_rows, 4);
+    return m;
+    };
+    const int m_out = body();
+    for (int i = m_out * 4 + lane; i < (max_pts + 1) * 4; i += 64) out_rows[i] = 0.0;       // padding reads as 0
+    if (lane == 0) traj_len[b] = m_out;
 }
 
 // ---------------------------------------------------------------------------------------------
