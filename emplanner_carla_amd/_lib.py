@@ -49,6 +49,11 @@ class SmoothParams(C.Structure):
                 ("x_thre", C.c_double), ("y_thre", C.c_double)]
 
 
+class SpeedDpParams(C.Structure):
+    _fields_ = [("reference_speed", C.c_double), ("w_cost_ref_speed", C.c_double), ("w_cost_accel", C.c_double),
+                ("w_cost_obs", C.c_double)]
+
+
 _vp, _i32, _f64, _u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
 
 
@@ -103,6 +108,11 @@ PROTOTYPES = {
     "emp_dy_obs_deri": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
+    "emp_speed_dp_params_default": (None, [C.POINTER(SpeedDpParams)]),
+    "emp_st_graph": (C.c_int, [_vp, _i32, _i32] + [_vp] * 8 + [C.c_int]),
+    "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),
+    "emp_st_edge_costs": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32, _i32] + [_vp] * 7 + [C.c_int]),
+    "emp_st_collision_cost": (C.c_int, [_vp, _i32, _f64, _vp, _vp, C.c_int]),
 }
 
 _lib = None

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from ._lib import DpParams, QpParams, SmoothParams, EmpError
+from ._lib import DpParams, QpParams, SmoothParams, SpeedDpParams, EmpError
 
 
 def dp_params(row=12, col=6, sample_s=15, sample_l=1.5, sampling_res=2, w_collision_cost=1e12,
@@ -51,6 +51,29 @@ def smooth_params(w_cost_smooth=0.4, w_cost_length=0.3, w_cost_ref=0.3, x_thre=0
     s.w_smooth, s.w_length, s.w_ref = float(w_cost_smooth), float(w_cost_length), float(w_cost_ref)
     s.x_thre, s.y_thre = float(x_thre), float(y_thre)
     return s
+
+
+def speed_dp_params(reference_speed=50, w_cost_ref_speed=4000, w_cost_accel=100, w_cost_obs=10000000) -> SpeedDpParams:
+    """Keyword defaults of reference speed_DP (speed_planning_test.py:101-102)."""
+    p = SpeedDpParams()
+    p.reference_speed, p.w_cost_ref_speed = float(reference_speed), float(w_cost_ref_speed)
+    p.w_cost_accel, p.w_cost_obs = float(w_cost_accel), float(w_cost_obs)
+    return p
+
+
+#: shape of the reference's S-T tables (speed_planning_test.py:114-122)
+ST_ROWS, ST_COLS = 40, 16
+
+
+@dataclass
+class SpeedDpResult:
+    """Outputs of ``Planner.speed_dp`` (arrays or torch tensors, batch-major)."""
+    cost: object        # (B, 40, 16) dp_st_cost, or None
+    s_dot: object       # (B, 40, 16) dp_st_s_dot, or None
+    node: object        # (B, 40, 16) int32 dp_st_node, or None
+    end_node: object    # (B, 2) int32 terminal (row, col)
+    speed_s: object     # (B, 16) s of the chosen node per t column, NaN after the terminal column
+    speed_t: object     # (B, 16)
 
 
 def _is_torch(x):
@@ -369,6 +392,56 @@ class Planner:
         self._check(self._lib.emp_dy_obs_deri(self._h, n, a.inp(rows, np.float64, (n, 5)), op_, a.where))
         return o
 
+    # ---- S-T speed DP (reference planner/speed_planning_test.py) ------------------------------
+    def st_graph(self, obs_s, obs_l, obs_s_dot, obs_l_dot):
+        """ref generate_st_graph: four (B, K) arrays (NaN = empty slot) -> s_in, s_out, t_in, t_out (B, K)."""
+        a = _Args(obs_s, obs_l, obs_s_dot, obs_l_dot)
+        B, K = int(obs_s.shape[0]), int(obs_s.shape[1])
+        outs = [a.out((B, K), np.float64) for _ in range(4)]
+        self._check(self._lib.emp_st_graph(
+            self._h, B, K, a.inp(obs_s, np.float64, (B, K)), a.inp(obs_l, np.float64, (B, K)),
+            a.inp(obs_s_dot, np.float64, (B, K)), a.inp(obs_l_dot, np.float64, (B, K)),
+            outs[0][1], outs[1][1], outs[2][1], outs[3][1], a.where))
+        return tuple(o[0] for o in outs)
+
+    def speed_dp(self, p: SpeedDpParams, s_in, s_out, t_in, t_out, plan_start_s_dot, tables=True) -> SpeedDpResult:
+        """ref speed_DP: S-T segments (B, K) + start speed (B,) -> tables, terminal node, chosen (s, t) per column."""
+        a = _Args(s_in, s_out, t_in, t_out, plan_start_s_dot)
+        B, K = int(s_in.shape[0]), int(s_in.shape[1])
+        shape = (B, ST_ROWS, ST_COLS)
+        cost, cp = a.out(shape, np.float64) if tables else (None, None)
+        sd, sp = a.out(shape, np.float64) if tables else (None, None)
+        nd, np_ = a.out(shape, np.int32) if tables else (None, None)
+        en, ep = a.out((B, 2), np.int32)
+        ss, ssp = a.out((B, ST_COLS), np.float64)
+        tt, ttp = a.out((B, ST_COLS), np.float64)
+        self._check(self._lib.emp_speed_dp(
+            self._h, C.byref(p), B, K, a.inp(s_in, np.float64, (B, K)), a.inp(s_out, np.float64, (B, K)),
+            a.inp(t_in, np.float64, (B, K)), a.inp(t_out, np.float64, (B, K)),
+            a.inp(plan_start_s_dot, np.float64, (B,)), cp, sp, np_, ep, ssp, ttp, a.where))
+        return SpeedDpResult(cost, sd, nd, en, ss, tt)
+
+    def st_edge_costs(self, p: SpeedDpParams, edges, s_in, s_out, t_in, t_out):
+        """ref CalcDpCost / CalcObsCost: edges (B, E, 5) = s0, t0, s_dot0, s1, t1 -> total (B, E), obstacle term (B, E)."""
+        a = _Args(edges, s_in)
+        B, E, K = int(edges.shape[0]), int(edges.shape[1]), int(s_in.shape[1])
+        tot, tp = a.out((B, E), np.float64)
+        obs, op_ = a.out((B, E), np.float64)
+        self._check(self._lib.emp_st_edge_costs(
+            self._h, C.byref(p), B, E, K, a.inp(edges, np.float64, (B, E, 5)), a.inp(s_in, np.float64, (B, K)),
+            a.inp(s_out, np.float64, (B, K)), a.inp(t_in, np.float64, (B, K)), a.inp(t_out, np.float64, (B, K)),
+            tp, op_, a.where))
+        return tot, obs
+
+    def st_collision_cost(self, w_cost_obs, min_dis):
+        """ref CalcCollisionCost: distances (n,) -> costs (n,)."""
+        a = _Args(min_dis)
+        n = int(min_dis.shape[0])
+        c, cp = a.out((n,), np.float64)
+        self._check(self._lib.emp_st_collision_cost(self._h, n, float(w_cost_obs), a.inp(min_dis, np.float64, (n,)), cp,
+                                                    a.where))
+        return c
+
     # ---- QP stages ------------------------------------------------------------------------
     def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):
         """ref cal_lmin_lmax: returns l_min, l_max (B,M), status (B,)."""
@@ -468,6 +541,12 @@ class Planner:
         self._check(self._lib.emp_obs_cost(self._h, n, float(w_collision), float(danger_dis), float(safe_dis),
                                            a.inp(square_d, np.float64, (n, 10)), cp, a.where))
         return c
+
+
+def st_grid():
+    """The reference's hard-coded S-T samples (speed_planning_test.py:114,116): s_list (40,), t_list (16,)."""
+    s_list = np.concatenate((np.arange(0, 5, 0.5), np.arange(5.5, 15, 1), np.arange(16, 30, 1.5), np.arange(32, 55, 2.5)))
+    return s_list, np.arange(0.5, 8.5, 0.5)
 
 
 def max_path_points(p: DpParams) -> int:

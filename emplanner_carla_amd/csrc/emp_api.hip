@@ -4,6 +4,7 @@
 
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
+#include "emp_st_kernels.h"
 #include "emp_tail_kernels.h"
 
 namespace emp {
@@ -1035,3 +1036,144 @@ extern "C" int emp_enrich_nodes(emp_ctx* ctx, int32_t B, int32_t max_nodes, doub
     }
     return st.finish();
 }
+
+// ---- S-T speed DP (reference planner/speed_planning_test.py) ------------------------------------
+extern "C" {
+
+void emp_speed_dp_params_default(emp_speed_dp_params* p) {
+    if (!p) return;
+    p->reference_speed = 50.0;
+    p->w_cost_ref_speed = 4000.0;
+    p->w_cost_accel = 100.0;
+    p->w_cost_obs = 10000000.0;
+}
+
+static emp::StDev make_st_dev(const emp_speed_dp_params* p, int B, int max_obs) {
+    emp::StDev d;
+    d.B = B;
+    d.max_obs = max_obs;
+    d.w.v_ref = p->reference_speed;
+    d.w.w_ref = p->w_cost_ref_speed;
+    d.w.w_acc = p->w_cost_accel;
+    d.w.w_obs = p->w_cost_obs;
+    return d;
+}
+
+int emp_st_graph(emp_ctx* ctx, int32_t B, int32_t max_obs, const double* obs_s, const double* obs_l,
+                 const double* obs_s_dot, const double* obs_l_dot, double* s_in, double* s_out, double* t_in,
+                 double* t_out, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_obs >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, obs_s && obs_l && obs_s_dot && obs_l_dot && s_in && s_out && t_in && t_out, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const size_t n = (size_t)B * max_obs;
+    const double *d_s, *d_l, *d_sd, *d_ld;
+    double *d_si, *d_so, *d_ti, *d_to;
+    if ((rc = st.in(obs_s, n, &d_s))) return rc;
+    if ((rc = st.in(obs_l, n, &d_l))) return rc;
+    if ((rc = st.in(obs_s_dot, n, &d_sd))) return rc;
+    if ((rc = st.in(obs_l_dot, n, &d_ld))) return rc;
+    if ((rc = st.out(s_in, n, &d_si, false))) return rc;
+    if ((rc = st.out(s_out, n, &d_so, false))) return rc;
+    if ((rc = st.out(t_in, n, &d_ti, false))) return rc;
+    if ((rc = st.out(t_out, n, &d_to, false))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "st_graph");
+        hipLaunchKernelGGL(st_graph_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_obs, d_s, d_l, d_sd, d_ld, d_si,
+                           d_so, d_ti, d_to);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t max_obs, const double* s_in,
+                 const double* s_out, const double* t_in, const double* t_out, const double* plan_start_s_dot,
+                 double* cost, double* s_dot, int32_t* node, int32_t* end_node, double* speed_s, double* speed_t,
+                 emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p != nullptr, "speed dp params are NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_obs >= 1 && max_obs <= st::kMaxObs, "bad sizes (max_obs must be in [1, 64])");
+    EMP_REQUIRE(ctx, s_in && s_out && t_in && t_out && plan_start_s_dot && end_node && speed_s && speed_t, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const size_t n = (size_t)B * max_obs, nt = (size_t)B * st::kRows * st::kCols;
+    const double *d_si, *d_so, *d_ti, *d_to, *d_v;
+    double *d_c = nullptr, *d_sd = nullptr, *d_ss, *d_tt;
+    int *d_n = nullptr, *d_e;
+    if ((rc = stg.in(s_in, n, &d_si))) return rc;
+    if ((rc = stg.in(s_out, n, &d_so))) return rc;
+    if ((rc = stg.in(t_in, n, &d_ti))) return rc;
+    if ((rc = stg.in(t_out, n, &d_to))) return rc;
+    if ((rc = stg.in(plan_start_s_dot, (size_t)B, &d_v))) return rc;
+    if (cost && (rc = stg.out(cost, nt, &d_c, false))) return rc;
+    if (s_dot && (rc = stg.out(s_dot, nt, &d_sd, false))) return rc;
+    if (node && (rc = stg.out(node, nt, &d_n, false))) return rc;
+    if ((rc = stg.out(end_node, (size_t)B * 2, &d_e, false))) return rc;
+    if ((rc = stg.out(speed_s, (size_t)B * st::kCols, &d_ss, false))) return rc;
+    if ((rc = stg.out(speed_t, (size_t)B * st::kCols, &d_tt, false))) return rc;
+    if (B) {
+        const StDev d = make_st_dev(p, B, max_obs);
+        KernelTimer t(ctx, "speed_dp");
+        hipLaunchKernelGGL(speed_dp_kernel, dim3(B), dim3(kStBlock), speed_dp_lds_bytes(max_obs), ctx->stream, d, d_si, d_so,
+                           d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+int emp_st_edge_costs(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t n_edges, int32_t max_obs,
+                      const double* edges, const double* s_in, const double* s_out, const double* t_in,
+                      const double* t_out, double* total, double* obs, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p != nullptr, "speed dp params are NULL");
+    EMP_REQUIRE(ctx, B >= 0 && B <= 65535 && n_edges >= 0 && max_obs >= 1 && max_obs <= st::kMaxObs,
+                "bad sizes (B <= 65535, max_obs in [1, 64])");
+    EMP_REQUIRE(ctx, edges && s_in && s_out && t_in && t_out && total, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const size_t n = (size_t)B * max_obs, ne = (size_t)B * n_edges;
+    const double *d_e, *d_si, *d_so, *d_ti, *d_to;
+    double *d_t, *d_o = nullptr;
+    if ((rc = stg.in(edges, ne * 5, &d_e))) return rc;
+    if ((rc = stg.in(s_in, n, &d_si))) return rc;
+    if ((rc = stg.in(s_out, n, &d_so))) return rc;
+    if ((rc = stg.in(t_in, n, &d_ti))) return rc;
+    if ((rc = stg.in(t_out, n, &d_to))) return rc;
+    if ((rc = stg.out(total, ne, &d_t, false))) return rc;
+    if (obs && (rc = stg.out(obs, ne, &d_o, false))) return rc;
+    if (ne) {
+        const StDev d = make_st_dev(p, B, max_obs);
+        dim3 grid((n_edges + 63) / 64, B);
+        hipLaunchKernelGGL(st_edge_cost_kernel, grid, dim3(64), 0, ctx->stream, d, n_edges, d_e, d_si, d_so, d_ti, d_to, d_t,
+                           d_o);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const double* min_dis, double* cost, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && min_dis && cost, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double* d_d;
+    double* d_c;
+    if ((rc = stg.in(min_dis, (size_t)n, &d_d))) return rc;
+    if ((rc = stg.out(cost, (size_t)n, &d_c, false))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(st_collision_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, w_cost_obs, d_d, d_c);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+}  // extern "C"

@@ -215,3 +215,34 @@ def make_batch(seeds, cfg: LatticeConfig = CFG2, **kw) -> SceneBatch:
         start_a=np.stack([sc.start_a for sc in scenes]),
         obs_xy=obs_xy, n_obs=n_obs, sl_obs_s=sl_s, sl_obs_l=sl_l,
         sl_start=np.stack([sc.sl_start for sc in scenes]))
+
+
+# --------------------------------------------------------------------------------------
+# S-T speed DP inputs (BASELINE config 5; SURVEY.md section 8d "cfg5")
+# --------------------------------------------------------------------------------------
+def make_dynamic_obstacles(seed: int, n_slots: int = 16, n_present: int | None = None):
+    """Dynamic obstacles in Frenet space for reference ``generate_st_graph``
+    (speed_planning_test.py:38): ``s ~ U(5,50)``, ``l ~ U(-6,6)``, ``s_dot ~ U(0,6)``,
+    ``|l_dot| ~ U(0.5,2)`` heading for the lane centre with probability 0.8; one obstacle in ten
+    drifts slower than the 0.3 m/s cut (:53) and is ignored by the reference.  Slots past
+    ``n_present`` are NaN (the reference stops scanning at the first NaN s, :51).  Returns
+    ``(obs_s, obs_l, obs_s_dot, obs_l_dot, plan_start_s_dot)``."""
+    rng = np.random.default_rng(1_000_003 + seed)
+    k = int(rng.integers(0, n_slots + 1)) if n_present is None else int(n_present)
+    s = rng.uniform(5.0, 50.0, n_slots)
+    l = rng.uniform(-6.0, 6.0, n_slots)
+    s_dot = rng.uniform(0.0, 6.0, n_slots)
+    speed = rng.uniform(0.5, 2.0, n_slots)
+    toward = rng.uniform(size=n_slots) < 0.8
+    l_dot = np.where(toward, -np.sign(l), np.sign(l)) * speed
+    slow = rng.uniform(size=n_slots) < 0.1
+    l_dot = np.where(slow, rng.uniform(-0.29, 0.29, n_slots), l_dot)
+    for a in (s, l, s_dot, l_dot):
+        a[k:] = np.nan
+    return s, l, s_dot, l_dot, float(rng.uniform(0.0, 15.0))
+
+
+def make_dynamic_batch(seeds, n_slots: int = 16, n_present: int | None = None):
+    """Stack ``make_dynamic_obstacles`` over seeds -> four [B, n_slots] arrays and start speeds [B]."""
+    rows = [make_dynamic_obstacles(int(sd), n_slots, n_present) for sd in seeds]
+    return tuple(np.stack([r[i] for r in rows]) for i in range(4)) + (np.array([r[4] for r in rows]),)

@@ -86,7 +86,14 @@ typedef struct emp_smooth_params {
     double x_thre, y_thre;                              /* 0.2, 0.2 */
 } emp_smooth_params;
 
+/* ref: keyword arguments of speed_DP, speed_planning_test.py:101-102 */
+typedef struct emp_speed_dp_params {
+    double reference_speed;                             /* 50 */
+    double w_cost_ref_speed, w_cost_accel, w_cost_obs;  /* 4000, 100, 1e7 */
+} emp_speed_dp_params;
+
 void emp_dp_params_default(emp_dp_params* p);
+void emp_speed_dp_params_default(emp_speed_dp_params* p);
 void emp_qp_params_default(emp_qp_params* p);
 void emp_smooth_params_default(emp_smooth_params* p);
 
@@ -283,6 +290,41 @@ int emp_frenet2cartesian(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_p
                          double* out, int32_t* status, int32_t proj_only, emp_mem where);
 /* ref: cal_dy_obs_deri (planning_utils.py:783-808): in [n][5] = l, vx, vy, heading, kappa -> out [n][3] */
 int emp_dy_obs_deri(emp_ctx* ctx, int32_t n, const double* in, double* out, emp_mem where);
+
+/* ---- S-T speed DP (BASELINE config 5; reference planner/speed_planning_test.py) ----------------
+ * The S-T grid is hard-coded in the reference (40 non-uniform s samples :114, 16 t samples :116); tables are
+ * [B][EMP_ST_ROWS][EMP_ST_COLS], row 0 = largest s (CalcSTCoordinate, :287-305).  Obstacle slots hold NaN when
+ * absent (:43-46, :255); max_obs <= 64. */
+#define EMP_ST_ROWS 40
+#define EMP_ST_COLS 16
+
+/* ref: generate_st_graph (speed_planning_test.py:38-98): dynamic obstacles [B][max_obs] (s, l, s_dot, l_dot; the scan
+ * stops at the first NaN s) -> S-T segments s_in, s_out, t_in, t_out [B][max_obs], NaN = ignored */
+int emp_st_graph(emp_ctx* ctx, int32_t B, int32_t max_obs, const double* obs_s, const double* obs_l,
+                 const double* obs_s_dot, const double* obs_l_dot, double* s_in, double* s_out, double* t_in,
+                 double* t_out, emp_mem where);
+
+/* ref: speed_DP (speed_planning_test.py:101-188): forward sweep over the 40 x 16 grid with state-dependent edges
+ * (CalcDpCost :191-231: source row 0 means "the DP origin", acceleration from the speed stored at the source node),
+ * terminal node = last <=-minimum over the right column then the top row (:158-172), backtrack (:178-186).
+ * The reference raises IndexError in its backtrack (float row index) and aliases its two output arrays (:156);
+ * here the predecessor is an integer and speed_s / speed_t [B][16] are separate (NaN after the terminal column).
+ * cost, s_dot [B][40][16] doubles and node [B][40][16] int32 are the reference's dp_st_cost / dp_st_s_dot /
+ * dp_st_node; each may be NULL.  end_node [B][2] = (row, col) of the terminal node, (-1, -1) if every cost is NaN. */
+int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t max_obs, const double* s_in,
+                 const double* s_out, const double* t_in, const double* t_out, const double* plan_start_s_dot,
+                 double* cost, double* s_dot, int32_t* node, int32_t* end_node, double* speed_s, double* speed_t,
+                 emp_mem where);
+
+/* ref: CalcDpCost (:191-231) / CalcObsCost (:234-271) for arbitrary edges: edges [B][n_edges][5] =
+ * s_start, t_start, s_dot_start, s_end, t_end against scene b's obstacles -> total [B][n_edges] and (optional)
+ * the obstacle term alone */
+int emp_st_edge_costs(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t n_edges, int32_t max_obs,
+                      const double* edges, const double* s_in, const double* s_out, const double* t_in,
+                      const double* t_out, double* total, double* obs, emp_mem where);
+
+/* ref: CalcCollisionCost (:274-284): n distances -> n costs */
+int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const double* min_dis, double* cost, emp_mem where);
 
 #ifdef __cplusplus
 }

@@ -111,3 +111,21 @@ def load_reference():
     finally:
         sys.path.remove(REFERENCE_ROOT)
     return pp, pu
+
+
+def load_speed_reference():
+    """Return the reference's ``planner.speed_planning_test`` module (S-T speed DP, config 5).  It imports
+    ``cvxopt`` (stubbed above) and ``scipy.interpolate`` (installed)."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        for name in ("planner", "planner.speed_planning_test"):
+            sys.modules.pop(name, None)
+        sp = importlib.import_module("planner.speed_planning_test")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        sys.modules.pop("planner", None)
+    return sp

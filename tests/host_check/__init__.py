@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "..", "..", "emplanner_carla_amd", "csrc")
 
 
 def load():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("emp_core.h", "emp_frenet_core.h", "emp_qp_core.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("emp_core.h", "emp_frenet_core.h", "emp_qp_core.h", "emp_st_core.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT],
@@ -29,4 +29,12 @@ def load():
     lib.hc_s_map.argtypes = [p, i, d, d, p]
     lib.hc_match.restype = i
     lib.hc_match.argtypes = [p, i, d, d, i, i, i]
+    lib.hc_st_edge_cost.restype = d
+    lib.hc_st_edge_cost.argtypes = [p, p, i, p, p, p, p, p]
+    lib.hc_st_graph.restype = None
+    lib.hc_st_graph.argtypes = [i] + [p] * 8
+    lib.hc_st_grid.restype = None
+    lib.hc_st_grid.argtypes = [p, p]
+    lib.hc_st_terminal.restype = i
+    lib.hc_st_terminal.argtypes = [p, p, p]
     return lib

@@ -5,6 +5,7 @@
 #include "../../emplanner_carla_amd/csrc/emp_core.h"
 #include "../../emplanner_carla_amd/csrc/emp_frenet_core.h"
 #include "../../emplanner_carla_amd/csrc/emp_qp_core.h"
+#include "../../emplanner_carla_amd/csrc/emp_st_core.h"
 
 using namespace emp;
 
@@ -46,6 +47,27 @@ void hc_s_map(const double* line, int n_ref, double ox, double oy, double* s_map
 
 int hc_match(const double* line, int n_ref, double x, double y, int first, int step, int limit) {
     return match_scan(line, n_ref, x, y, first, step, limit);
+}
+
+// ---- S-T speed DP scalar pieces (emp_st_core.h) ---------------------------------------------------
+double hc_st_edge_cost(const double* w4, const double* edge5, int n_obs, const double* s_in, const double* s_out,
+                       const double* t_in, const double* t_out, double* obs) {
+    const st::Weights w{w4[0], w4[1], w4[2], w4[3]};
+    return st::edge_cost(w, edge5[0], edge5[1], edge5[2], edge5[3], edge5[4], n_obs, s_in, s_out, t_in, t_out, obs);
+}
+
+void hc_st_graph(int n, const double* s, const double* l, const double* sd, const double* ld, double* s_in, double* s_out,
+                 double* t_in, double* t_out) {
+    st::st_graph(n, s, l, sd, ld, s_in, s_out, t_in, t_out);
+}
+
+void hc_st_grid(double* s_rows, double* t_cols) {
+    for (int r = 0; r < st::kRows; ++r) s_rows[r] = st::s_of_row(r);
+    for (int c = 0; c < st::kCols; ++c) t_cols[c] = st::t_of_col(c);
+}
+
+int hc_st_terminal(const double* cost, int* row, int* col) {
+    return st::terminal_node([&](int r, int c) { return cost[r * st::kCols + c]; }, row, col) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -176,3 +176,66 @@ def test_segment_cost_bit_exact_with_exact_oracle(hc):
             v = hc.hc_segment_cost(l0, 0.0, 0.0, l1, ps + j * cfg.sample_s, cfg.sample_s, obs_s.ctypes.data,
                                    obs_l.ctypes.data, k, 1e12, 300.0, 1000.0, 5000.0, 20.0)
             assert v == e[0, j - 1, i, kk]
+
+
+# ---- S-T speed DP scalar pieces (csrc/emp_st_core.h; reference planner/speed_planning_test.py) ---------------
+def test_st_core_grid_graph_and_edges_vs_reference_golden(hc):
+    from oracle import st_speed
+    g = load_golden("speed.npz")
+    ptr = lambda a: a.ctypes.data
+    s_rows, t_cols = np.zeros(40), np.zeros(16)
+    hc.hc_st_grid(ptr(s_rows), ptr(t_cols))
+    np.testing.assert_array_equal(s_rows, g["s_list"][::-1])
+    np.testing.assert_array_equal(t_cols, g["t_list"])
+    # generate_st_graph: bit-exact against the reference on all 64 obstacle sets
+    for b in range(g["graph_in"].shape[1]):
+        ins = [np.ascontiguousarray(g["graph_in"][i, b]) for i in range(4)]
+        outs = [np.zeros(16) for _ in range(4)]
+        hc.hc_st_graph(16, *[ptr(a) for a in ins], *[ptr(a) for a in outs])
+        for i in range(4):
+            np.testing.assert_array_equal(outs[i], g["graph_out"][i, b])
+    # CalcObsCost / CalcDpCost on the reference's edges
+    w4 = np.array([50.0, 4000.0, 100.0, 10000000.0])
+    for n, b in enumerate(g["edge_sets"]):
+        sets = [np.ascontiguousarray(g["graph_out"][i, b]) for i in range(4)]
+        for e, want in zip(g["obs_edges"][n], g["obs_cost"][n]):
+            edge = np.array([e[0], e[1], 0.0, e[2], e[3]])
+            obs = C.c_double(0)
+            hc.hc_st_edge_cost(ptr(w4), ptr(edge), 16, *[ptr(a) for a in sets], C.byref(obs))
+            assert abs(obs.value - want) <= 1e-12 * max(1.0, abs(want))
+        tab = g["dp_s_dot_table"]
+        for rc, want in zip(g["dp_idx"][n], g["dp_cost"][n]):
+            origin = rc[0] == 0
+            edge = np.array([0.0 if origin else g["s_list"][39 - rc[0]], 0.0 if origin else g["t_list"][rc[1]],
+                             7.5 if origin else tab[rc[0], rc[1]], g["s_list"][39 - rc[2]], g["t_list"][rc[3]]])
+            got = hc.hc_st_edge_cost(ptr(w4), ptr(edge), 16, *[ptr(a) for a in sets], None)
+            assert abs(got - want) <= 1e-12 * abs(want)
+    # terminal node rule on the reference's own cost tables
+    for n in range(len(g["tables_out"])):
+        cost = np.ascontiguousarray(g["tables_out"][n][0])
+        r, c = C.c_int(-9), C.c_int(-9)
+        assert hc.hc_st_terminal(ptr(cost), C.byref(r), C.byref(c)) == 1
+        assert (r.value, c.value) == st_speed.terminal_node(cost)
+
+
+def test_st_core_pruning_is_exact(hc):
+    """Obstacle pruning by bounding boxes must not change any bit: compare with the unpruned NumPy statement."""
+    from oracle import st_speed
+    rng = np.random.default_rng(11)
+    ptr = lambda a: a.ctypes.data
+    w4 = np.array([50.0, 4000.0, 100.0, 10000000.0])
+    worst = 0.0
+    for _ in range(40):
+        s_in = rng.uniform(0, 55, 16)
+        s_out = s_in + rng.uniform(-5, 25, 16)
+        t_in = rng.uniform(0, 7, 16)
+        t_out = t_in + rng.uniform(0.5, 6, 16)
+        s_in[rng.integers(0, 16, 3)] = np.nan
+        s0, s1 = rng.uniform(0, 55, 2)
+        t0 = rng.choice(np.arange(0, 8, 0.5))
+        edge = np.array([s0, t0, rng.uniform(0, 20), s1, t0 + 0.5])
+        obs = C.c_double(0)
+        hc.hc_st_edge_cost(ptr(w4), ptr(edge), 16, ptr(s_in), ptr(s_out), ptr(t_in), ptr(t_out), C.byref(obs))
+        want = float(st_speed.exact_obs_cost(s0, t0, s1, t0 + 0.5, s_in, s_out, t_in, t_out, 10000000.0))
+        worst = max(worst, abs(obs.value - want) / max(1.0, abs(want)))
+    assert worst <= 1e-13

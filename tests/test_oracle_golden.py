@@ -272,3 +272,97 @@ def test_qp_dense_known_answers():
     with np.errstate(all="ignore"):
         r = qp_dense.solve_qp(np.eye(1), [0.0], [[1.0], [-1.0]], [-1.0, -1.0])
     assert r.status != "optimal"
+
+
+# --------------------------------------------------------------------------------------
+# S-T speed DP (reference planner/speed_planning_test.py:38-305) - oracle/st_speed.py vs the reference
+# --------------------------------------------------------------------------------------
+def _speed():
+    from oracle import st_speed
+    return st_speed, load_golden("speed.npz")
+
+
+def test_st_graph_port_and_exact_match_reference():
+    st, g = _speed()
+    gin, gout = g["graph_in"], g["graph_out"]
+    for b in range(gin.shape[1]):
+        got = st.port_generate_st_graph(*gin[:, b])
+        for i in range(4):
+            np.testing.assert_array_equal(got[i], gout[i, b])
+    ex = st.exact_generate_st_graph(*gin)
+    for i in range(4):
+        np.testing.assert_array_equal(ex[i], gout[i])
+    # a NaN s in the middle ends the scan (:51)
+    got = st.exact_generate_st_graph(*[a[None] for a in g["graph_mid_in"]])
+    for i in range(4):
+        np.testing.assert_array_equal(got[i][0], g["graph_mid_out"][i])
+    assert np.isnan(g["graph_mid_out"][0][4:]).all()
+
+
+def test_st_grid_and_collision_cost():
+    st, g = _speed()
+    s_list, t_list = st.grid()
+    np.testing.assert_array_equal(s_list, g["s_list"])
+    np.testing.assert_array_equal(t_list, g["t_list"])
+    for r in (0, 7, 39):
+        for c in (0, 15):
+            assert tuple(g["coord"][r, c]) == st.port_st_coordinate(r, c, s_list, t_list)
+    port = np.array([float(st.port_collision_cost(10000000, np.float64(x))) for x in g["coll_d"]])
+    np.testing.assert_array_equal(port, g["coll_cost"])
+    assert g["coll_cost"][1] == 0.0 and g["coll_cost"][2] == 0.0          # exactly 0.5 / 1.5 cost nothing
+    assert_rel(st.exact_collision_cost(10000000, g["coll_d"]), g["coll_cost"], 1e-14, scale=1.0)
+
+
+def test_st_edge_costs_vs_reference():
+    st, g = _speed()
+    s_list, t_list = st.grid()
+    for n, b in enumerate(g["edge_sets"]):
+        sets = [g["graph_out"][i, b] for i in range(4)]
+        e = g["obs_edges"][n]
+        port = [float(st.port_obs_cost(*row, *sets, 10000000)) for row in e[:12]]
+        np.testing.assert_array_equal(port, g["obs_cost"][n][:12])
+        ex = st.exact_obs_cost(e[:, 0], e[:, 1], e[:, 2], e[:, 3], *sets, 10000000)
+        assert_rel(ex, g["obs_cost"][n], 1e-12, scale=1.0)
+        rc = g["dp_idx"][n]
+        tab = g["dp_s_dot_table"]
+        port = [float(st.port_dp_cost(int(a), int(b_), int(c), int(d), *sets, 4000, 50, 100, 10000000, 7.5, s_list,
+                                      t_list, tab)) for a, b_, c, d in rc[:12]]
+        np.testing.assert_array_equal(port, g["dp_cost"][n][:12])
+        origin = rc[:, 0] == 0
+        s0 = np.where(origin, 0.0, s_list[39 - rc[:, 0]])
+        t0 = np.where(origin, 0.0, t_list[rc[:, 1]])
+        v0 = np.where(origin, 7.5, tab[rc[:, 0], rc[:, 1]])
+        ex = st.exact_edge_cost(s0, t0, v0, s_list[39 - rc[:, 2]], t_list[rc[:, 3]], *sets)
+        assert_rel(ex, g["dp_cost"][n], 1e-12, scale=1.0)
+
+
+def test_st_forward_tables_vs_reference():
+    """The reference's own speed_DP tables (read from the frame in which it raises)."""
+    st, g = _speed()
+    for n in range(len(g["tables_in"])):
+        sets = g["tables_in"][n][:64].reshape(4, 16)
+        v0 = g["tables_in"][n][64]
+        kw = dict(zip(("reference_speed", "w_cost_ref_speed", "w_cost_accel", "w_cost_obs"), g["tables_kw"][n]))
+        cost, s_dot, node = g["tables_out"][n]
+        ex = st.exact_speed_dp(sets[0], sets[1], sets[2], sets[3], v0, **kw)
+        assert_rel(ex["cost"][0], cost, 1e-12, scale=1.0)
+        np.testing.assert_array_equal(ex["node"][0], node.astype(np.int32))
+        np.testing.assert_array_equal(ex["s_dot"][0], s_dot)
+        r, c = st.terminal_node(cost)
+        assert tuple(ex["end"][0]) == (r, c)
+        # int-cast backtrack: one node per column up to the terminal column, NaN after it
+        ss, tt = ex["speed_s"][0], ex["speed_t"][0]
+        assert np.isfinite(ss[:c + 1]).all() and np.isnan(ss[c + 1:]).all()
+        np.testing.assert_array_equal(tt[:c + 1], g["t_list"][:c + 1])
+
+
+def test_st_port_sweep_matches_reference_tables():
+    """Faithful port, full sweep, on the obstacle-free and the two-obstacle scene (bit for bit)."""
+    st, g = _speed()
+    for n in (0, 1):
+        sets = g["tables_in"][n][:64].reshape(4, 16)
+        res = st.port_speed_dp_tables(sets[0], sets[1], sets[2], sets[3], g["tables_in"][n][64])
+        cost, s_dot, node = g["tables_out"][n]
+        np.testing.assert_array_equal(res["cost"], cost)
+        np.testing.assert_array_equal(res["s_dot"], s_dot)
+        np.testing.assert_array_equal(res["node"], node)
