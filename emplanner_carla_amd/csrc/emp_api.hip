@@ -1151,7 +1151,7 @@ int emp_st_edge_costs(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int
     if (ne) {
         const StDev d = make_st_dev(p, B, max_obs);
         dim3 grid((n_edges + 63) / 64, B);
-        hipLaunchKernelGGL(st_edge_cost_kernel, grid, dim3(64), 0, ctx->stream, d, n_edges, d_e, d_si, d_so, d_ti, d_to, d_t,
+        hipLaunchKernelGGL(st_edge_cost_kernel, grid, dim3(64), 7 * (size_t)max_obs * sizeof(double), ctx->stream, d, n_edges, d_e, d_si, d_so, d_ti, d_to, d_t,
                            d_o);
         EMP_LAUNCH_CHECK(ctx);
     }

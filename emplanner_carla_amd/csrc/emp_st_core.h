@@ -30,6 +30,24 @@ EMP_HD double s_list_at(int idx) {
 EMP_HD double s_of_row(int row) { return s_list_at(kRows - row - 1); }
 EMP_HD double t_of_col(int col) { return 0.5 + (double)col * 0.5; }
 
+EMP_HD int ctz64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)v) - 1;
+#else
+    return __builtin_ctzll(v);
+#endif
+}
+
+// x / dt.  Every edge between two grid columns has dt == 0.5 (ref :116), where the quotient is the exact
+// power-of-two scaling x * 2; only edges that start at the DP origin need a real division.
+EMP_HD double div_dt(double x, double dt) { return dt == 0.5 ? x * 2.0 : x / dt; }
+
+#if defined(__HIPCC__)
+#define EMP_ST_COLD __host__ __device__ __noinline__
+#else
+#define EMP_ST_COLD __attribute__((noinline))
+#endif
+
 // ref :274-284 (CalcCollisionCost)
 EMP_HD double collision_cost(double w, double d) {
     const double a = fabs(d);
@@ -38,55 +56,133 @@ EMP_HD double collision_cost(double w, double d) {
     return 0.0;
 }
 
-// ref :258-269 - cost of one sample point (s, t) against one S-T obstacle segment
+// ref :258-269 - cost of one sample point (s, t) against one S-T obstacle segment: the reference's arithmetic
 EMP_HD double point_cost(double w, double s, double t, double s_in, double t_in, double s_out, double t_out) {
     const double v1x = s_in - s, v1y = t_in - t;
     const double v2x = s_out - s, v2y = t_out - t;
     const double v3x = v2x - v1x, v3y = v2y - v1y;
     const double p = v1x * v3x + v1y * v3y;
     const double q = v2x * v3x + v2y * v3y;
-    if ((p > 0.0 && q > 0.0) || (p < 0.0 && q < 0.0)) {
+    double d;
+    if ((p > 0.0 && q > 0.0) || (p < 0.0 && q < 0.0)) {  // the foot of the perpendicular misses the segment
         const double d11 = v1x * v1x + v1y * v1y;
         const double d22 = v2x * v2x + v2y * v2y;
-        const double m = d22 < d11 ? d22 : d11;
-        if (m >= 2.25) return 0.0;  // sqrt is monotone and sqrt(2.25) == 1.5 exactly: d >= 1.5 costs nothing
-        return collision_cost(w, sqrt(m));
+        d = sqrt(d22 < d11 ? d22 : d11);  // min(dis1, dis2): sqrt is monotone, so min and sqrt commute
+    } else {
+        d = fabs(v1x * v3y - v1y * v3x) / sqrt(v3x * v3x + v3y * v3y);
     }
-    const double cross = v1x * v3y - v1y * v3x;
-    const double d33 = v3x * v3x + v3y * v3y;
-    if (cross * cross > 2.2500001 * d33) return 0.0;  // d > 1.5 (1 + 2e-8): far outside rounding of the quotient
-    return collision_cost(w, fabs(cross) / sqrt(d33));
+    return collision_cost(w, d);
 }
 
-// ref :234-271 (CalcObsCost).  Obstacles whose bounding box is farther than kPruneGap from the edge's
-// sample span in s or in t contribute exactly 0 and are skipped; n_obs <= kMaxObs.
-EMP_HD double obs_cost(double w, double s0, double t0, double s1, double t1, int n_obs, const double* s_in,
-                       const double* s_out, const double* t_in, const double* t_out) {
-    const double dt = (t1 - t0) / 4.0;
-    const double k = (s1 - s0) / (t1 - t0);
-    double ss[kStSamples], tt[kStSamples];
-#pragma unroll
-    for (int m = 0; m < kStSamples; ++m) {
-        const double f = (double)(m - 1);  // ref :251-252: the first sample lies one step BEFORE the edge
-        tt[m] = t0 + f * dt;
-        ss[m] = s0 + (k * f) * dt;
-    }
-    const double s_lo = fmin(ss[0], ss[kStSamples - 1]), s_hi = fmax(ss[0], ss[kStSamples - 1]);
-    const double t_lo = fmin(tt[0], tt[kStSamples - 1]), t_hi = fmax(tt[0], tt[kStSamples - 1]);
+// Out-of-line copy for the kernels: samples that are near an obstacle are rare per lane but not per
+// wavefront, so they are gathered first and costed together (obs_cost below); one copy of the long pow()
+// expansion per kernel.
+EMP_ST_COLD static double point_cost_cold(double w, double s, double t, double s_in, double t_in, double s_out,
+                                          double t_out) {
+    return point_cost(w, s, t, s_in, t_in, s_out, t_out);
+}
+
+// True only if point_cost is exactly 0, decided with the reference's own intermediate values and no sqrt /
+// division: d >= 1.5 costs nothing (ref :281-282).  sqrt(2.25) == 1.5 exactly and sqrt is monotone; for the
+// perpendicular distance the test leaves a 2e-8 relative margin, far outside the rounding of the quotient.
+EMP_HD bool point_is_far(double s, double t, double s_in, double t_in, double s_out, double t_out) {
+    const double v1x = s_in - s, v1y = t_in - t;
+    const double v2x = s_out - s, v2y = t_out - t;
+    const double v3x = v2x - v1x, v3y = v2y - v1y;
+    const double p = v1x * v3x + v1y * v3y;
+    const double q = v2x * v3x + v2y * v3y;
+    const bool outside = (p > 0.0 && q > 0.0) || (p < 0.0 && q < 0.0);
+    const double d11 = v1x * v1x + v1y * v1y;
+    const double d22 = v2x * v2x + v2y * v2y;
+    const double m = d22 < d11 ? d22 : d11;
+    const double cross = v1x * v3y - v1y * v3x;
+    const double d33 = v3x * v3x + v3y * v3y;
+    return outside ? m >= 2.25 : cross * cross > 2.2500001 * d33;
+}
+
+// Obstacle segments of one scene plus, per segment, its unit direction (ux, uy) in the (s, t) plane and its
+// length: only used to REJECT obstacles / samples that are provably farther than kPruneGap (distance to a
+// segment >= distance to its line, and >= the overshoot along it), never to compute a cost.  A degenerate
+// segment has NaN direction, every rejection test is then false and the exact path runs.
+struct ObsSet {
+    int n;
+    const double *s_in, *s_out, *t_in, *t_out, *ux, *uy, *len;
+};
+
+EMP_HD void obs_frame(double s_in, double t_in, double s_out, double t_out, double* ux, double* uy, double* len) {
+    const double dx = s_out - s_in, dy = t_out - t_in;
+    const double L = sqrt(dx * dx + dy * dy);
+    *len = L;
+    *ux = dx / L;
+    *uy = dy / L;
+}
+
+// ref :234-271 (CalcObsCost).  Obstacles / samples that are provably at least kPruneGap (> 1.5) away
+// contribute exactly 0 and are skipped; everything else goes through the reference's arithmetic.
+EMP_HD double obs_cost(double w, double s0, double t0, double s1, double t1, const ObsSet& o) {
+    const double dt = (t1 - t0) * 0.25;  // == (t1 - t0) / (n - 1), n = 5 (ref :244-246)
+    const double k = div_dt(s1 - s0, t1 - t0);
+    // ref :251-252: sample m sits at t0 + (m-1) dt, s0 + (k (m-1)) dt - the first one lies BEFORE the edge
+    const double s_a = s0 + (k * -1.0) * dt, s_b = s0 + (k * 3.0) * dt;
+    const double t_a = t0 + -1.0 * dt, t_b = t0 + 3.0 * dt;
+    const double s_lo = fmin(s_a, s_b), s_hi = fmax(s_a, s_b);
+    const double t_lo = fmin(t_a, t_b), t_hi = fmax(t_a, t_b);
+    const double G = kPruneGap;
     uint64_t live = 0;
-    for (int j = 0; j < n_obs; ++j) {
-        if (isnan(s_in[j])) continue;  // ref :255
-        const bool apart = fmin(s_in[j], s_out[j]) - s_hi >= kPruneGap || s_lo - fmax(s_in[j], s_out[j]) >= kPruneGap ||
-                           fmin(t_in[j], t_out[j]) - t_hi >= kPruneGap || t_lo - fmax(t_in[j], t_out[j]) >= kPruneGap;
+    for (int j = 0; j < o.n; ++j) {
+        const double si = o.s_in[j], so = o.s_out[j], ti = o.t_in[j], to = o.t_out[j];
+        if (isnan(si)) continue;  // ref :255
+        // axis-aligned boxes of the sample span and of the segment
+        bool apart = fmin(si, so) - s_hi >= G || s_lo - fmax(si, so) >= G || fmin(ti, to) - t_hi >= G || t_lo - fmax(ti, to) >= G;
+        // the same in the segment's own frame: both end samples on one side of the 1.6-wide band / beyond one end
+        const double ux = o.ux[j], uy = o.uy[j], top = o.len[j] + G;
+        const double ax = s_a - si, ay = t_a - ti, bx = s_b - si, by = t_b - ti;
+        const double na = ay * ux - ax * uy, nb = by * ux - bx * uy;
+        const double la = ax * ux + ay * uy, lb = bx * ux + by * uy;
+        apart = apart || (na >= G && nb >= G) || (na <= -G && nb <= -G) || (la <= -G && lb <= -G) || (la >= top && lb >= top);
         if (!apart) live |= (uint64_t)1 << j;
     }
     double total = 0.0;
     if (live == 0) return total;
+    // pass 1: which (sample, obstacle) pairs are near?  Cheap arithmetic only.
+    uint64_t near[kStSamples];
 #pragma unroll
-    for (int m = 0; m < kStSamples; ++m)
-        for (int j = 0; j < n_obs; ++j)
-            if ((live >> j) & 1) total = total + point_cost(w, ss[m], tt[m], s_in[j], t_in[j], s_out[j], t_out[j]);
-    return total;
+    for (int m = 0; m < kStSamples; ++m) {
+        const double f = (double)(m - 1);
+        const double t = t0 + f * dt;
+        const double s = s0 + (k * f) * dt;
+        uint64_t hit = 0;
+        for (uint64_t rest = live; rest; rest &= rest - 1) {
+            const int j = ctz64(rest);
+            const double si = o.s_in[j], ti = o.t_in[j];
+            const double ux = o.ux[j], uy = o.uy[j];
+            const double px = s - si, py = t - ti;
+            const double nn = py * ux - px * uy, ll = px * ux + py * uy;
+            if (fabs(nn) >= G || ll <= -G || ll >= o.len[j] + G) continue;  // provably >= 1.6 away: exact 0
+            if (!point_is_far(s, t, si, ti, o.s_out[j], o.t_out[j])) hit |= (uint64_t)1 << j;
+        }
+        near[m] = hit;
+    }
+    // pass 2: the near pairs in the reference's order (sample outer, obstacle inner; ref :249-269).  Each
+    // lane pops its next pair, so a wavefront runs the expensive path max-over-lanes(#near) times.
+    for (;;) {
+        int m = -1;
+        uint64_t word = 0;
+#pragma unroll
+        for (int i = kStSamples - 1; i >= 0; --i)
+            if (near[i]) {
+                m = i;
+                word = near[i];
+            }
+        if (m < 0) break;
+        const int j = ctz64(word);
+#pragma unroll
+        for (int i = 0; i < kStSamples; ++i)
+            if (i == m) near[i] = word & (word - 1);
+        const double f = (double)(m - 1);
+        total = total + point_cost_cold(w, s0 + (k * f) * dt, t0 + f * dt, o.s_in[j], o.t_in[j], o.s_out[j], o.t_out[j]);
+    }
+    return total;  // adding the exact zeros of the skipped pairs would not change any bit
 }
 
 struct Weights {
@@ -96,8 +192,8 @@ struct Weights {
 // ref :217-226 - the state-dependent part of CalcDpCost (everything except the obstacle term)
 EMP_HD void kinematic_cost(const Weights& w, double s0, double t0, double v0, double s1, double t1, double* acc,
                            double* ref) {
-    const double v = (s1 - s0) / (t1 - t0);
-    const double a = (v - v0) / (t1 - t0);
+    const double v = div_dt(s1 - s0, t1 - t0);
+    const double a = div_dt(v - v0, t1 - t0);
     const double e = v - w.v_ref;
     *ref = w.w_ref * (e * e);
     const double a2 = a * a;
@@ -105,11 +201,11 @@ EMP_HD void kinematic_cost(const Weights& w, double s0, double t0, double v0, do
 }
 
 // ref :191-231 (CalcDpCost) given the resolved start state
-EMP_HD double edge_cost(const Weights& w, double s0, double t0, double v0, double s1, double t1, int n_obs,
-                        const double* s_in, const double* s_out, const double* t_in, const double* t_out, double* obs_out) {
+EMP_HD double edge_cost(const Weights& w, double s0, double t0, double v0, double s1, double t1, const ObsSet& o,
+                        double* obs_out) {
     double acc, ref;
     kinematic_cost(w, s0, t0, v0, s1, t1, &acc, &ref);
-    const double obs = obs_cost(w.w_obs, s0, t0, s1, t1, n_obs, s_in, s_out, t_in, t_out);
+    const double obs = obs_cost(w.w_obs, s0, t0, s1, t1, o);
     if (obs_out) *obs_out = obs;
     return (obs + acc) + ref;
 }

@@ -225,7 +225,7 @@ def test_st_core_pruning_is_exact(hc):
     ptr = lambda a: a.ctypes.data
     w4 = np.array([50.0, 4000.0, 100.0, 10000000.0])
     worst = 0.0
-    for _ in range(40):
+    for trial in range(600):
         s_in = rng.uniform(0, 55, 16)
         s_out = s_in + rng.uniform(-5, 25, 16)
         t_in = rng.uniform(0, 7, 16)
@@ -233,6 +233,11 @@ def test_st_core_pruning_is_exact(hc):
         s_in[rng.integers(0, 16, 3)] = np.nan
         s0, s1 = rng.uniform(0, 55, 2)
         t0 = rng.choice(np.arange(0, 8, 0.5))
+        if trial % 3 == 0:          # put a few segments right next to the edge: the 1.5 .. 1.6 zone matters
+            for j in range(0, 16, 4):
+                off = rng.uniform(1.3, 1.8) * rng.choice([-1, 1])
+                s_in[j], t_in[j] = s0 + off, t0 + rng.uniform(-0.3, 0.3)
+                s_out[j], t_out[j] = s_in[j] + rng.uniform(-3, 3), t_in[j] + rng.uniform(0.2, 3)
         edge = np.array([s0, t0, rng.uniform(0, 20), s1, t0 + 0.5])
         obs = C.c_double(0)
         hc.hc_st_edge_cost(ptr(w4), ptr(edge), 16, ptr(s_in), ptr(s_out), ptr(t_in), ptr(t_out), C.byref(obs))
