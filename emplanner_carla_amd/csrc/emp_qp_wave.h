@@ -15,6 +15,14 @@
 
 #include "emp_qp_core.h"
 
+// Development hook: tools/qp_wave_bench.hip defines EMP_QP_PROF(i) to accumulate clock ticks per solver section.
+#ifndef EMP_QP_PROF
+#define EMP_QP_PROF(i)
+#endif
+#ifndef EMP_QP_DEBUG
+#define EMP_QP_DEBUG(...)
+#endif
+
 namespace emp {
 
 // Hardware reciprocal / reciprocal square root seeds (v_rcp_f64, v_rsq_f64: ~2^-27 relative) plus Newton steps.
@@ -91,72 +99,133 @@ __device__ __forceinline__ int group_nmax(int N) {                 // largest N 
     return n0;
 }
 
-// Band row in registers: a[0..KD] = A[gl][gl..gl+KD].  On return a[] holds the factor row U[gl][..], rinv = 1/U[gl][gl]
-// and low[e] = U[gl-e][e] (the column entries the forward substitution needs).  ok == false if a pivot was <= 0
-// for this group.  Lanes gl >= N carry zeros and take part in the broadcasts.
+// Whole-wavefront shifts by one lane (DPP wave_shr:1 / wave_shl:1, a VALU move: no LDS traffic).  Lanes without
+// a source read 0.  With G = 32 the shift crosses from one group into the next; every use below multiplies the
+// shifted-in value by a band entry that is exactly 0 there, or selects it away.
+__device__ __forceinline__ double lane_up1(double v) {               // lane i <- lane i - 1
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x138, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x138, 0xF, 0xF, true);
+    return r.d;
+}
+__device__ __forceinline__ double lane_dn1(double v) {               // lane i <- lane i + 1
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], 0x130, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], 0x130, 0xF, 0xF, true);
+    return r.d;
+}
+
+// Band row in registers: a[0..KD] = A[gl][gl..gl+KD] (entries past column N-1 are 0; lanes gl >= N and groups
+// that are not `active` carry zeros).  On return a[] holds the factor row U[gl][..], rinv = 1/U[gl][gl] and
+// low[e] = U[gl-e][e] (the column entries the forward substitution needs).  ok == false if a pivot of this
+// group was <= 0.
+//
+// Left-looking Cholesky as a lane-parallel sweep: row j of U only needs rows j-1..j-KD,
+//     U[j][j+d] = (A[j][j+d] - sum_{e=1..KD-d} U[j-e][e] U[j-e][e+d]) / U[j][j],
+// so EVERY lane recomputes its row from A and its neighbours' current rows (fetched with lane shifts) at every
+// step; after step k rows 0..k are final.  No broadcasts, no selects on the pivot index, no LDS.  Rows that
+// are not final yet hold garbage (possibly NaN) that is overwritten, never accumulated.  Entries past column
+// N-1 are written as exact zeros at every step: those are the entries a shift carries across the end of a row
+// block (into idle lanes, or with G = 32 into the first rows of the next group), so nothing else needs a mask.
 template <int G, int KD>
 __device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rinv, double (&low)[KD + 1], int N, int gl,
                                                 bool active) {
-    bool ok = true;
-    rinv = 0.0;
+    static_assert(KD >= 1 && KD <= 3, "band_chol_group handles half bandwidths 1..3");
+    const bool row = active && gl < N;
+    double A[KD + 1];
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) A[d] = row ? a[d] : (d == 0 ? 1.0 : 0.0);     // idle lanes: identity rows
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) a[d] = A[d];
+    bool inband[KD + 1];
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) inband[d] = row && gl + d < N;
+    double diag = A[0];
+    rinv = 1.0;
     const int nmax = group_nmax<G>(N);                             // groups of one wavefront may differ in size
     for (int k = 0; k < nmax; ++k) {
-        double rowk[KD + 1];
+        // s[e][c] = U[gl-e][e+c] (c = 0..KD-e): row gl-e shifted up by e lanes
+        double s1[KD], s2[KD > 1 ? KD - 1 : 1], s3[1];
 #pragma unroll
-        for (int d = 0; d <= KD; ++d) rowk[d] = group_bcast<G>(a[d], k);
-        const double piv = rowk[0];
-        if (active && k < N && !(piv > 0.0)) ok = false;
-        const double r = fast_rsqrt(piv > 0.0 ? piv : 1.0);
-        double u[KD + 1];
-        u[0] = piv * r;
+        for (int c = 0; c < KD; ++c) s1[c] = lane_up1(a[1 + c]);
+        if constexpr (KD >= 2) {
 #pragma unroll
-        for (int d = 1; d <= KD; ++d) u[d] = rowk[d] * r;
-        if (gl == k) {
-#pragma unroll
-            for (int d = 0; d <= KD; ++d) a[d] = u[d];
-            rinv = r;
+            for (int c = 0; c < KD - 1; ++c) s2[c] = lane_up1(s1[1 + c]);
         }
-        const int e = gl - k;                                      // rows k+1..k+KD get the rank-1 update
+        if constexpr (KD >= 3) s3[0] = lane_up1(s2[1]);
+        const double h1 = s1[0];
+        double acc[KD + 1];
 #pragma unroll
-        for (int ee = 1; ee <= KD; ++ee) {
-            if (e == ee) {
+        for (int d = 0; d <= KD; ++d) acc[d] = A[d];
 #pragma unroll
-                for (int c = 0; c + ee <= KD; ++c) a[c] -= u[ee] * u[ee + c];
-            }
+        for (int c = 0; c < KD; ++c) acc[c] = __builtin_fma(-h1, s1[c], acc[c]);
+        if constexpr (KD >= 2) {
+            const double h2 = s2[0];
+#pragma unroll
+            for (int c = 0; c < KD - 1; ++c) acc[c] = __builtin_fma(-h2, s2[c], acc[c]);
         }
+        if constexpr (KD >= 3) {
+            acc[0] = __builtin_fma(-s3[0], s3[0], acc[0]);
+        }
+        diag = acc[0];
+        const double r = fast_rsqrt(diag > 0.0 ? diag : 1.0);
+        a[0] = diag * r;
+#pragma unroll
+        for (int d = 1; d <= KD; ++d) a[d] = inband[d] ? acc[d] * r : 0.0;
+        rinv = r;
     }
+    const bool bad = row && !(diag > 0.0);
     // column entries for the forward substitution: low[e] = U[gl-e][e]
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int e = 1; e <= KD; ++e) {
-        const double v = __shfl(a[e], (gl - e >= 0) ? lane - e : lane, 64);
-        low[e] = (gl - e >= 0) ? v : 0.0;
-    }
     low[0] = 0.0;
-    return ok;
+    {
+        double t = lane_up1(a[1]);
+        low[1] = (gl >= 1) ? t : 0.0;
+        if constexpr (KD >= 2) {
+            t = lane_up1(lane_up1(a[2]));
+            low[2] = (gl >= 2) ? t : 0.0;
+        }
+        if constexpr (KD >= 3) {
+            t = lane_up1(lane_up1(lane_up1(a[3])));
+            low[3] = (gl >= 3) ? t : 0.0;
+        }
+    }
+    return !group_any<G>(bad);
 }
 
-// solve U'U x = b with the factor from band_chol_group; b (one entry per lane) is overwritten with x
+// solve U'U x = b with the factor from band_chol_group; b (one entry per lane) is overwritten with x.
+// Same sweep idea: y_j = (b_j - sum_e U[j-e][e] y_{j-e}) / U[j][j] is recomputed by every lane at every step from
+// its neighbours' current values; after step k entries 0..k are final (backward: N-1..N-1-k).  All operands are
+// finite (the factor is final), and shifted-in values from outside the group meet a zero coefficient.
 template <int G, int KD>
 __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], double rinv, const double (&low)[KD + 1],
                                                  double& b, int N, int gl) {
     const int nmax = group_nmax<G>(N);
-    for (int k = 0; k < nmax; ++k) {                               // U' y = b
-        const double yk = group_bcast<G>(b * rinv, k);             // lane k's b is final at step k
-        if (gl == k) b = yk;
-        const int e = gl - k;
-#pragma unroll
-        for (int ee = 1; ee <= KD; ++ee)
-            if (e == ee) b -= low[ee] * yk;
+    const double rhs = b;
+    double y = rhs * rinv;
+    for (int k = 1; k < nmax; ++k) {                               // U' y = b
+        const double y1 = lane_up1(y);
+        double acc = __builtin_fma(-low[1], y1, rhs);
+        if constexpr (KD >= 2) {
+            const double y2 = lane_up1(y1);
+            acc = __builtin_fma(-low[2], y2, acc);
+            if constexpr (KD >= 3) acc = __builtin_fma(-low[3], lane_up1(y2), acc);
+        }
+        y = acc * rinv;
     }
-    for (int k = nmax - 1; k >= 0; --k) {                          // U x = y
-        const double xk = group_bcast<G>(b * rinv, k);
-        if (gl == k) b = xk;
-        const int e = k - gl;
-#pragma unroll
-        for (int ee = 1; ee <= KD; ++ee)
-            if (e == ee) b -= a[ee] * xk;
+    double x = y * rinv;
+    for (int k = 1; k < nmax; ++k) {                               // U x = y
+        const double x1 = lane_dn1(x);
+        double acc = __builtin_fma(-a[1], x1, y);
+        if constexpr (KD >= 2) {
+            const double x2 = lane_dn1(x1);
+            acc = __builtin_fma(-a[2], x2, acc);
+            if constexpr (KD >= 3) acc = __builtin_fma(-a[3], lane_dn1(x2), acc);
+        }
+        x = acc * rinv;
     }
+    b = x;
 }
 
 // gather of per-row coefficients onto unknown m:  sum over (t, f, p) with t + off0 + p == m of g[f][p] * coef[t][f]
@@ -504,6 +573,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
     }
     while (__any(state == 1)) {
         const bool run = state == 1;
+        EMP_QP_PROF(0);
         // ---- 1: stations: residuals, reciprocals, rd gather coefficient, barrier weight
         double v[F], rpu[F], rpl[F], isu[F], isl[F], izu[F], izl[F], wu[F], wl[F];
         win(Q.u, v);
@@ -527,6 +597,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
             }
         }
         __syncthreads();
+        EMP_QP_PROF(1);
         // ---- 2: unknowns: rd and the normal-matrix row (registers)
         double rd_m = 0.0;
         double fa[B], flow[B], frinv = 0.0;
@@ -554,6 +625,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
                 fa[d] = e;
             }
         }
+        EMP_QP_PROF(2);
         {
             double rd_max = (run && has_m) ? fabs(rd_m) : 0.0;
 #pragma unroll
@@ -566,6 +638,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
             mu /= (double)rows;
             if (run) {
                 const double dscale = fmax(qscale, zmax);
+                EMP_QP_DEBUG("it %d rd %.3e rp %.3e mu %.3e zmax %.3e\n", iters, rd_max, rp_max, mu, zmax);
                 if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
                 else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
                 else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
@@ -574,10 +647,13 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
             }
         }
         const bool go = state == 1;
+        EMP_QP_PROF(3);
         // ---- 3: factorisation in registers
         const bool okf = band_chol_group<G, KD>(fa, frinv, flow, N, gl, go);
+        EMP_QP_DEBUG("   chol ok %d\n", (int)okf);
         if (go && !okf) state = acceptable ? 0 : 2;
         const bool go2 = state == 1;
+        EMP_QP_PROF(4);
         // ---- 4: predictor
         if (go2 && has_t) {
 #pragma unroll
@@ -585,9 +661,11 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         }
         __syncthreads();
         double dua_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
+        EMP_QP_PROF(5);
         band_solve_group<G, KD>(fa, frinv, flow, dua_m, N, gl);
         if (go2 && has_m) Q.dua[m] = dua_m;
         __syncthreads();
+        EMP_QP_PROF(6);
         // ---- 5: affine step length, centring parameter, corrector coefficients
         double gda[F], dsua[F], dsla[F], dzua[F], dzla[F], rcu[F], rcl[F];
         win(Q.dua, gda);
@@ -620,9 +698,11 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         }
         __syncthreads();
         double du_m = (go2 && has_m) ? (-rd_m + gather(Q.tmp)) : 0.0;
+        EMP_QP_PROF(7);
         band_solve_group<G, KD>(fa, frinv, flow, du_m, N, gl);
         if (go2 && has_m) Q.rhs[m] = du_m;
         __syncthreads();
+        EMP_QP_PROF(8);
         // ---- 6: step length and update
         double gd[F], dsu[F], dsl[F], dzu[F], dzl[F];
         win(Q.rhs, gd);
@@ -656,6 +736,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
             ++iters;
         }
         __syncthreads();
+        EMP_QP_PROF(9);
     }
     Q.iters = iters;
     return state;
@@ -762,7 +843,10 @@ __device__ inline int path_qp_group(double* lds, const double* l_min, const doub
         for (int d = 0; d < 4; ++d) fa[d] = (ok && gl < Q.N) ? Q.P[gl * 4 + d] : 0.0;
         const bool okc = band_chol_group<G, 3>(fa, frinv, flow, Q.N, gl, ok && Q.N > 0);
         double b0 = (ok && gl < Q.N) ? -Q.q[gl] : 0.0;
+        EMP_QP_DEBUG("init: N %d P0 %.4e %.4e %.4e %.4e q0 %.4e | U0 %.4e %.4e rinv %.4e okc %d\n", Q.N, Q.P[0], Q.P[1], Q.P[2],
+                     Q.P[3], Q.q[0], fa[0], fa[1], frinv, (int)okc);
         band_solve_group<G, 3>(fa, frinv, flow, b0, Q.N, gl);
+        EMP_QP_DEBUG("init: u0 %.6e\n", b0);
         if (ok && gl < Q.N) Q.u[gl] = b0;
         if (ok && !okc) rc = 2;
     } else {
