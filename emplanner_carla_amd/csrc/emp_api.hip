@@ -1,6 +1,7 @@
 // emp_api.hip - C-ABI of the MI355X EM-Planner hot path (see include/emplanner.h).
 // One translation unit: kernels are header-only templates, this file owns launches and staging.
 #include <stdlib.h>
+#include <string.h>
 
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
@@ -49,14 +50,35 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         if (chunks > ncol) chunks = ncol;
         if (chunks < 1) chunks = 1;
     }
-    const int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
+    // each of the block's 4 wavefronts takes whole columns: chunk sizes are multiples of 4 where possible
+    int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
+    cols_per_chunk = cols_per_chunk >= 4 ? (cols_per_chunk / 4) * 4 : 4;
     chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
     dim3 grid(d.tiles, chunks), block(256);
+    // pair table: rebuilt only when the lattice parameters change (stream-ordered before its first use)
+    const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
+    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
+    emp_ctx::Buf& tb = ctx->named["dp_pair_table"];
+    if (tb.bytes < tab_bytes) {
+        if (tb.p) EMP_HIP(ctx, hipFree(tb.p));
+        tb.p = nullptr;
+        tb.bytes = 0;
+        EMP_HIP(ctx, hipMalloc(&tb.p, tab_bytes));
+        tb.bytes = tab_bytes;
+        ctx->pair_table_valid = false;
+    }
+    if (!ctx->pair_table_valid || memcmp(key, ctx->pair_table_key, sizeof(key)) != 0) {
+        hipLaunchKernelGGL(dp_pair_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d, (double*)tb.p);
+        EMP_LAUNCH_CHECK(ctx);
+        memcpy(ctx->pair_table_key, key, sizeof(key));
+        ctx->pair_table_valid = true;
+    }
+    const double* pair_tab = (const double*)tb.p;
     auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer t(ctx, "dp_edge");
-    hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, obs_s, obs_l, n_obs, start, start_cost, edge,
+    hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
                        cols_per_chunk);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;

@@ -26,6 +26,9 @@ struct emp_ctx {
     size_t cursor = 0;
     // persistent named scratch (survives across the staged buffers of one call)
     std::map<std::string, Buf> named;
+    // lattice parameters the "dp_pair_table" scratch was built for (emp_api.hip: dev_dp_edge)
+    double pair_table_key[8] = {0};
+    bool pair_table_valid = false;
     // per-kernel timing
     bool timing = false;
     struct Ev {

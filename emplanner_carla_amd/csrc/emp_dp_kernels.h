@@ -37,28 +37,14 @@ constexpr int kTableFields = kSamples + 7;  // l samples, a3, a4, a5, base smoot
 // ---------------------------------------------------------------------------------------------
 // edge costs
 // ---------------------------------------------------------------------------------------------
-// grid = (tiles, column chunks), block = 256.  Dynamic LDS: pair table [kTableFields][row*row] doubles
-// followed by the tile's obstacles [S][max_obs] x2 doubles.
-template <bool TILED>
-__global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __restrict__ obs_s,
-                                                      const double* __restrict__ obs_l,
-                                                      const int* __restrict__ n_obs,
-                                                      const double* __restrict__ start,
-                                                      double* __restrict__ start_cost,
-                                                      double* __restrict__ edge, int cols_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+// Pair table: everything of a neighbour edge that depends neither on the scene nor on the column
+// (dl0 = ddl0 = 0, T = sample_s: the lateral samples, sum l^2, sum dl^2, sum ddl^2, a3..a5 are functions of the
+// row pair (k, i) only; the quirked jerk term and the obstacles are what see the absolute s).  It depends only
+// on the lattice parameters, so it is built once per parameter set by this one-block kernel and kept in device
+// memory: [kTableFields][row*row] doubles (pair index = k*row + i) followed by the kSamples sample offsets.
+__global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __restrict__ tab) {
     const int row = P.row, rr = P.row * P.row;
-    double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
-    double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
-    double* t_obs_l = t_obs_s + P.S * P.max_obs;
-    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples] sample offsets t_n (one division each)
-    const int tile = blockIdx.x;
-    const int tid = threadIdx.x;
-
-    // ---- per-pair table: everything of a neighbour edge that does not depend on scene or column.
-    // (dl0 = ddl0 = 0, T = sample_s; the lateral samples, sum l^2, sum dl^2, sum ddl^2 are shared by all
-    // columns and scenes; only the quirked jerk term and the obstacles see the absolute s.)
-    for (int p = tid; p < rr; p += blockDim.x) {
+    for (int p = threadIdx.x; p < rr; p += blockDim.x) {
         const int k = p / row, i = p - k * row;
         const double l_pre = lattice_l(row, k, P.sample_l);
         const double l_cur = lattice_l(row, i, P.sample_l);
@@ -82,7 +68,30 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
         tab[(kSamples + 5) * rr + p] = fmin(l_pre, l_cur);
         tab[(kSamples + 6) * rr + p] = fmax(l_pre, l_cur);
     }
-    if (tid < kSamples) t_smp[tid] = sample_t(tid, P.sample_s);
+    if (threadIdx.x < kSamples) tab[kTableFields * rr + threadIdx.x] = sample_t(threadIdx.x, P.sample_s);
+}
+
+// grid = (tiles, column chunks), block = 256.  Dynamic LDS: the pair table (copied from `pair_tab`),
+// followed by the tile's obstacles [S][max_obs] x2 doubles and the sample offsets.
+template <bool TILED>
+__global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
+                                                      const double* __restrict__ obs_s,
+                                                      const double* __restrict__ obs_l,
+                                                      const int* __restrict__ n_obs,
+                                                      const double* __restrict__ start,
+                                                      double* __restrict__ start_cost,
+                                                      double* __restrict__ edge, int cols_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int row = P.row, rr = P.row * P.row;
+    double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
+    double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
+    double* t_obs_l = t_obs_s + P.S * P.max_obs;
+    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples] sample offsets t_n
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
+    if (tid < kSamples) t_smp[tid] = pair_tab[kTableFields * rr + tid];
     for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
         const int s = x / P.max_obs, m = x - s * P.max_obs;
         const int b = tile * P.S + s;
@@ -108,59 +117,81 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
         }
     }
 
-    // ---- neighbour edges of this block's column chunk.  A thread keeps its lane (scene, row i) and walks
-    // over (column, source row k) items; consecutive lanes store consecutive doubles of the tiled tensor.
+    // ---- neighbour edges of this block's column chunk.  A thread keeps its lane (scene, row i); each
+    // wavefront takes whole columns, so what depends on (scene, column) only - the sample abscissae and which
+    // obstacles are within longitudinal reach - is set up once and reused for the `row` source rows.
+    // Consecutive lanes store consecutive doubles of the tiled tensor.
     const int j_begin = 1 + blockIdx.y * cols_per_chunk;
     const int j_end = min(P.col, j_begin + cols_per_chunk);
-    const int n_jk = (j_end - j_begin) * row;
     const int lane = tid & 63;
     const int s = lane / row, i = lane - s * row;
     const int b = tile * P.S + s;
     if (lane >= lanes_used || b >= P.B) return;
     const double ps = start[b * 4 + 0];
     const int nob = n_obs[b];
-    for (int jk = tid >> 6; jk < n_jk; jk += (int)(blockDim.x >> 6)) {
-        const int jj = jk / row, k = jk - jj * row;
-        const int j = j_begin + jj;
-        const int p = k * row + i;
+    const int nmask = min(nob, 64);
+    const double* my_obs_s = t_obs_s + s * P.max_obs;
+    const double* my_obs_l = t_obs_l + s * P.max_obs;
+    for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
         const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
-        Quintic q;
-        q.a3 = tab[(kSamples + 0) * rr + p];
-        q.a4 = tab[(kSamples + 1) * rr + p];
-        q.a5 = tab[(kSamples + 2) * rr + p];
-        const JerkQuirk jq = jerk_quirk(q, s0);
-        double S_d3 = 0.0;
+        double sn[kSamples];
 #pragma unroll
-        for (int n = 0; n < kSamples; ++n) {
-            const double d3 = jerk_quirk_at(jq, s0 + t_smp[n]);
-            S_d3 = S_d3 + d3 * d3;
+        for (int n = 0; n < kSamples; ++n) sn[n] = s0 + t_smp[n];
+        // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
+        unsigned long long near_s = 0;
+        for (int m = 0; m < nmask; ++m) {
+            const double os = my_obs_s[m];
+            if (os > s0 - 6.5 && os < sn[kSamples - 1] + 6.5) near_s |= 1ull << m;
         }
-        const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
-        const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
-        double coll = 0.0;
-        for (int m = 0; m < nob; ++m) {
-            const double os = t_obs_s[s * P.max_obs + m], ol = t_obs_l[s * P.max_obs + m];
-            if (!obstacle_in_reach(os, ol, s0, s0 + t_last, l_lo, l_hi)) continue;   // contributes exactly 0
-            double c = 0.0;
+        for (int k = 0; k < row; ++k) {
+            const int p = k * row + i;
+            Quintic q;
+            q.a3 = tab[(kSamples + 0) * rr + p];
+            q.a4 = tab[(kSamples + 1) * rr + p];
+            q.a5 = tab[(kSamples + 2) * rr + p];
+            const JerkQuirk jq = jerk_quirk(q, s0);
+            double S_d3 = 0.0;
+#pragma unroll
             for (int n = 0; n < kSamples; ++n) {
-                const double sn = s0 + t_smp[n];
-                const double d_lon = os - sn;
-                const double d_lat = ol - tab[n * rr + p];
-                const double d2 = d_lon * d_lon + d_lat * d_lat;
-                if (d2 <= kDanger2) {
-                    c = c + P.w_coll;
-                    break;
-                } else if (d2 < kSafe2) {
-                    c = c + kSoftGain / d2;
-                }
+                const double d3 = jerk_quirk_at(jq, sn[n]);
+                S_d3 = S_d3 + d3 * d3;
             }
-            coll = coll + c;
-        }
-        const double cost = (smooth + coll) + tab[(kSamples + 4) * rr + p];
-        if (TILED) {
-            edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
-        } else {
-            edge[(size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + i * row + k] = cost;
+            const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
+            const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
+            double coll = 0.0;
+            auto one_obstacle = [&](double os, double ol) {              // ref :588-609 for one obstacle
+                double c = 0.0;
+#pragma unroll
+                for (int n = 0; n < kSamples; ++n) {
+                    const double d_lon = os - sn[n];
+                    const double d_lat = ol - tab[n * rr + p];
+                    const double d2 = d_lon * d_lon + d_lat * d_lat;
+                    if (d2 <= kDanger2) {
+                        c = c + P.w_coll;
+                        break;
+                    } else if (d2 < kSafe2) {
+                        c = c + kSoftGain / d2;
+                    }
+                }
+                coll = coll + c;
+            };
+            for (unsigned long long rest = near_s; rest; rest &= rest - 1) {   // ascending m, as the reference
+                const int m = __ffsll((long long)rest) - 1;
+                const double ol = my_obs_l[m];
+                if (!(ol > l_lo - 6.5 && ol < l_hi + 6.5)) continue;         // lateral half: contributes exactly 0
+                one_obstacle(my_obs_s[m], ol);
+            }
+            for (int m = 64; m < nob; ++m) {                                  // beyond the mask: full test per edge
+                const double os = my_obs_s[m], ol = my_obs_l[m];
+                if (!obstacle_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;
+                one_obstacle(os, ol);
+            }
+            const double cost = (smooth + coll) + tab[(kSamples + 4) * rr + p];
+            if (TILED) {
+                edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
+            } else {
+                edge[(size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + i * row + k] = cost;
+            }
         }
     }
 }
@@ -191,6 +222,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
     const int base = s * row;
     const bool left = i < (row >> 1);                    // ref :317 / :341 lane penalty rows
     const double INF = __builtin_inf();
+    const double pen = left ? kLanePenalty : 0.0;
 
     double cost = INF;
     if (live) {
@@ -241,8 +273,9 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
             for (int k = 0; k < ROW; ++k) cand[k] = front[base + k];
 #pragma unroll
             for (int k = 0; k < ROW; ++k) {
-                cand[k] = cand[k] + e[k];                             // ref :340
-                if (left) cand[k] = cand[k] + kLanePenalty;           // ref :342
+                // ref :340, :342.  `pen` is 0.0 off the penalty rows: x + 0.0 == x bit for bit.  The reference's
+                // `<` never accepts a NaN candidate; fmin(NaN, inf) = inf makes it lose every comparison below.
+                cand[k] = __builtin_fmin((cand[k] + e[k]) + pen, INF);
             }
             int idx[ROW];
 #pragma unroll
@@ -251,9 +284,8 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
             for (int span = 1; span < ROW; span <<= 1) {
 #pragma unroll
                 for (int k = 0; k + span < ROW; k += 2 * span) {
-                    // right operand has the larger k: it wins only when strictly smaller (or when the left one
-                    // is NaN, which the reference's `<` never accepts either)
-                    const bool take = (cand[k + span] < cand[k]) || (cand[k] != cand[k]);
+                    // the right operand has the larger k: it wins only when strictly smaller
+                    const bool take = cand[k + span] < cand[k];
                     cand[k] = take ? cand[k + span] : cand[k];
                     idx[k] = take ? idx[k + span] : idx[k];
                 }

@@ -13,6 +13,8 @@ pl = Planner(0)
 p = dp_params_from_cfg(cfg)
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+if len(sys.argv) > 2 and sys.argv[2] == 'noobs':
+    batch.n_obs[:] = 0
 obs_s, obs_l, n_obs, start = t(batch.sl_obs_s), t(batch.sl_obs_l), t(batch.n_obs), t(batch.sl_start)
 pl.set_timing(True)
 for mode in (0, 1):
