@@ -228,6 +228,120 @@ __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], doub
     b = x;
 }
 
+// NP independent problems in the same lanes (same N): one loop, NP interleaved dependency chains.
+template <int G, int KD, int NP>
+__device__ __forceinline__ bool band_chol_group_n(double (&a)[NP][KD + 1], double (&rinv)[NP], double (&low)[NP][KD + 1],
+                                                  int N, int gl, const bool (&active)[NP]) {
+    static_assert(KD >= 1 && KD <= 3, "band_chol_group_n handles half bandwidths 1..3");
+    double A[NP][KD + 1], diag[NP];
+    bool row[NP], inband[NP][KD + 1];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        row[p] = active[p] && gl < N;
+#pragma unroll
+        for (int d = 0; d <= KD; ++d) {
+            A[p][d] = row[p] ? a[p][d] : (d == 0 ? 1.0 : 0.0);
+            a[p][d] = A[p][d];
+            inband[p][d] = row[p] && gl + d < N;
+        }
+        diag[p] = A[p][0];
+        rinv[p] = 1.0;
+    }
+    const int nmax = group_nmax<G>(N);
+    for (int k = 0; k < nmax; ++k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double s1[KD], s2[KD > 1 ? KD - 1 : 1], s3[1];
+#pragma unroll
+            for (int c = 0; c < KD; ++c) s1[c] = lane_up1(a[p][1 + c]);
+            if constexpr (KD >= 2) {
+#pragma unroll
+                for (int c = 0; c < KD - 1; ++c) s2[c] = lane_up1(s1[1 + c]);
+            }
+            if constexpr (KD >= 3) s3[0] = lane_up1(s2[1]);
+            double acc[KD + 1];
+#pragma unroll
+            for (int d = 0; d <= KD; ++d) acc[d] = A[p][d];
+#pragma unroll
+            for (int c = 0; c < KD; ++c) acc[c] = __builtin_fma(-s1[0], s1[c], acc[c]);
+            if constexpr (KD >= 2) {
+#pragma unroll
+                for (int c = 0; c < KD - 1; ++c) acc[c] = __builtin_fma(-s2[0], s2[c], acc[c]);
+            }
+            if constexpr (KD >= 3) acc[0] = __builtin_fma(-s3[0], s3[0], acc[0]);
+            diag[p] = acc[0];
+            const double r = fast_rsqrt(diag[p] > 0.0 ? diag[p] : 1.0);
+            a[p][0] = diag[p] * r;
+#pragma unroll
+            for (int d = 1; d <= KD; ++d) a[p][d] = inband[p][d] ? acc[d] * r : 0.0;
+            rinv[p] = r;
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (row[p] && !(diag[p] > 0.0)) {
+            bad = true;
+            rinv[p] = -1.0;                              // marks this problem's failed pivot for the caller
+        }
+        low[p][0] = 0.0;
+        double t = lane_up1(a[p][1]);
+        low[p][1] = (gl >= 1) ? t : 0.0;
+        if constexpr (KD >= 2) {
+            t = lane_up1(lane_up1(a[p][2]));
+            low[p][2] = (gl >= 2) ? t : 0.0;
+        }
+        if constexpr (KD >= 3) {
+            t = lane_up1(lane_up1(lane_up1(a[p][3])));
+            low[p][3] = (gl >= 3) ? t : 0.0;
+        }
+    }
+    return !group_any<G>(bad);
+}
+
+template <int G, int KD, int NP>
+__device__ __forceinline__ void band_solve_group_n(const double (&a)[NP][KD + 1], const double (&rinv)[NP],
+                                                   const double (&low)[NP][KD + 1], double (&b)[NP], int N, int gl) {
+    const int nmax = group_nmax<G>(N);
+    double rhs[NP], y[NP], x[NP], ri[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ri[p] = rinv[p] > 0.0 ? rinv[p] : 1.0;
+        rhs[p] = b[p];
+        y[p] = rhs[p] * ri[p];
+    }
+    for (int k = 1; k < nmax; ++k) {                               // U' y = b
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const double y1 = lane_up1(y[p]);
+            double acc = __builtin_fma(-low[p][1], y1, rhs[p]);
+            if constexpr (KD >= 2) {
+                const double y2 = lane_up1(y1);
+                acc = __builtin_fma(-low[p][2], y2, acc);
+                if constexpr (KD >= 3) acc = __builtin_fma(-low[p][3], lane_up1(y2), acc);
+            }
+            y[p] = acc * ri[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) x[p] = y[p] * ri[p];
+    for (int k = 1; k < nmax; ++k) {                               // U x = y
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const double x1 = lane_dn1(x[p]);
+            double acc = __builtin_fma(-a[p][1], x1, y[p]);
+            if constexpr (KD >= 2) {
+                const double x2 = lane_dn1(x1);
+                acc = __builtin_fma(-a[p][2], x2, acc);
+                if constexpr (KD >= 3) acc = __builtin_fma(-a[p][3], lane_dn1(x2), acc);
+            }
+            x[p] = acc * ri[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) b[p] = x[p];
+}
+
 // gather of per-row coefficients onto unknown m:  sum over (t, f, p) with t + off0 + p == m of g[f][p] * coef[t][f]
 template <int KD, int F, int W>
 __device__ __forceinline__ double gather_rows(const RangeQp<KD, F, W>& Q, int m, const double* coef) {
@@ -924,7 +1038,215 @@ __device__ inline int box_qp_setup_group(BoxRangeQp& Q, const double* ref, int s
     return 0;
 }
 
-// Smoothing of one polyline on one wavefront: lanes 0-31 solve x, lanes 32-63 solve y.
+// ---------------------------------------------------------------------------------------------
+// Smoothing QPs of one polyline of m <= 64 points on one wavefront, one POINT per lane; the x and the y
+// problem (same structure, independent data) run side by side in the same lanes so that their two serial
+// chains interleave.  The box QP has G = I (W = 1, F = 1, off0 = 0): a station IS its unknown, so the whole
+// interior-point iteration lives in registers - neighbours for P u and for the Cholesky / substitution sweeps
+// come from lane shifts, norms and ratio tests from butterflies.  Same algorithm, stopping rule and constants
+// as range_qp_solve_wave_fast with BoxRangeQp (emp_qp_core.h: box_qp_forms / box_qp_setup).
+// rx, ry: this lane's reference point (lanes >= m: anything).  Returns 0 ok / 2 failed (wave-uniform).
+// ---------------------------------------------------------------------------------------------
+__device__ inline int smooth_pair_lanes(double rx, double ry, int m, const SmoothQpParams& sx, const SmoothQpParams& sy,
+                                        double* out_x, double* out_y, int* iters_out) {
+    constexpr int NP = 2, KD = 2;
+    const int gl = threadIdx.x & 63;
+    const bool has = gl < m;
+    *iters_out = 0;
+    if (m < 2 || !(sx.thr > 0.0) || !(sy.thr > 0.0)) return 2;
+    const SmoothQpParams prm[NP] = {sx, sy};
+    const double eps_p = 1e-10, eps_mu = 1e-13, eps_d_rel = 1e-10;   // box_qp_forms
+    double Prow[NP][KD + 1], Plow[NP][KD + 1], q[NP], lo[NP], hi[NP], u[NP], su[NP], sl[NP], zu[NP], zl[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const double r = p == 0 ? rx : ry;
+#pragma unroll
+        for (int d = 0; d <= KD; ++d) {                  // ref planning_utils.py:262-361 cost matrices, as box_qp_setup_group
+            double e = 0.0;
+            if (has && gl + d < m) {
+                for (int rr = max(0, gl + d - 2); rr <= min(m - 3, gl); ++rr) {
+                    const double a = (gl - rr == 1) ? -2.0 : 1.0, b = (gl + d - rr == 1) ? -2.0 : 1.0;
+                    e += 2.0 * prm[p].w_smooth * a * b;
+                }
+                for (int rr = max(0, gl + d - 1); rr <= min(m - 2, gl); ++rr) {
+                    const double a = (gl - rr == 0) ? 1.0 : -1.0, b = (gl + d - rr == 0) ? 1.0 : -1.0;
+                    e += 2.0 * prm[p].w_length * a * b;
+                }
+                if (d == 0) e += 2.0 * prm[p].w_ref;
+            }
+            Prow[p][d] = e;
+        }
+        Plow[p][0] = 0.0;
+        Plow[p][1] = lane_up1(Prow[p][1]);               // P[gl-1][gl]; 0 for gl = 0 (lane 0 has no source)
+        Plow[p][2] = lane_up1(lane_up1(Prow[p][2]));
+        q[p] = has ? -2.0 * prm[p].w_ref * r : 0.0;      // ref :346
+        lo[p] = has ? r - prm[p].thr : -1e300;           // ref :308-311
+        hi[p] = has ? r + prm[p].thr : 1e300;
+        u[p] = has ? r : 0.0;
+        zu[p] = zl[p] = 1.0;
+    }
+    const int rows = m * 2;
+    int state[NP], iters[NP];
+    bool acceptable[NP];
+    double qscale[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        state[p] = 1;
+        iters[p] = 0;
+        acceptable[p] = false;
+        qscale[p] = fmax(group_max<64>(has ? fabs(q[p]) : 0.0), 1.0);
+        su[p] = hi[p] - u[p];                            // = thr: no shift needed when thr >= 1, else push to >= 1
+        sl[p] = u[p] - lo[p];
+        double smin = has ? fmin(su[p], sl[p]) : 1e300;
+        smin = group_min<64>(smin);
+        const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
+        su[p] += shift;
+        sl[p] += shift;
+    }
+    while (state[0] == 1 || state[1] == 1) {
+        double rpu[NP], rpl[NP], isu[NP], isl[NP], izu[NP], izl[NP], wu[NP], wl[NP], rd[NP], mu[NP];
+        double fa[NP][KD + 1], flow[NP][KD + 1], frinv[NP];
+        double red[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            rpu[p] = u[p] - hi[p] + su[p];
+            rpl[p] = lo[p] - u[p] + sl[p];
+            isu[p] = fast_rcp(su[p]);
+            isl[p] = fast_rcp(sl[p]);
+            izu[p] = fast_rcp(zu[p]);
+            izl[p] = fast_rcp(zl[p]);
+            wu[p] = zu[p] * isu[p];
+            wl[p] = zl[p] * isl[p];
+            const double u1 = lane_dn1(u[p]), u2 = lane_dn1(u1), d1 = lane_up1(u[p]), d2 = lane_up1(d1);
+            double acc = q[p] + Prow[p][0] * u[p];
+            acc += Prow[p][1] * u1 + Prow[p][2] * u2 + Plow[p][1] * d1 + Plow[p][2] * d2;
+            rd[p] = has ? acc + (zu[p] - zl[p]) : 0.0;
+            fa[p][0] = has ? Prow[p][0] + (wu[p] + wl[p]) : 0.0;
+            fa[p][1] = Prow[p][1];
+            fa[p][2] = Prow[p][2];
+            red[p][0] = fabs(rd[p]);
+            red[p][1] = has ? fmax(fabs(rpu[p]), fabs(rpl[p])) : 0.0;
+            red[p][2] = has ? fmax(zu[p], zl[p]) : 0.0;
+            red[p][3] = has ? su[p] * zu[p] + sl[p] * zl[p] : 0.0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {              // eight reductions in one butterfly
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                red[p][0] = fmax(red[p][0], __shfl_xor(red[p][0], o, 64));
+                red[p][1] = fmax(red[p][1], __shfl_xor(red[p][1], o, 64));
+                red[p][2] = fmax(red[p][2], __shfl_xor(red[p][2], o, 64));
+                red[p][3] += __shfl_xor(red[p][3], o, 64);
+            }
+        }
+        bool go[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            mu[p] = red[p][3] / (double)rows;
+            if (state[p] == 1) {
+                const double rd_max = red[p][0], rp_max = red[p][1], dscale = fmax(qscale[p], red[p][2]);
+                if (rd_max <= eps_d_rel * dscale && rp_max <= eps_p && mu[p] <= eps_mu) state[p] = 0;
+                else if (!(mu[p] == mu[p]) || mu[p] > 1e30 || (iters[p] >= kQpStallIter && rp_max > kQpStallResidual)) state[p] = 2;
+                else if (iters[p] >= kQpMaxIter) state[p] = acceptable[p] ? 0 : 2;
+                if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu[p] <= 1000.0 * eps_mu)
+                    acceptable[p] = true;
+            }
+            go[p] = state[p] == 1;
+        }
+        if (!go[0] && !go[1]) break;
+        const bool okf = band_chol_group_n<64, KD, NP>(fa, frinv, flow, m, gl, go);
+        (void)okf;
+        double pivot_bad[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pivot_bad[p] = (go[p] && has && !(frinv[p] == frinv[p] && frinv[p] > 0.0 && frinv[p] < 1e300)) ? 1.0 : 0.0;
+        const double any_bad0 = group_max<64>(pivot_bad[0]), any_bad1 = group_max<64>(pivot_bad[1]);
+        if (go[0] && any_bad0 != 0.0) state[0] = acceptable[0] ? 0 : 2;
+        if (go[1] && any_bad1 != 0.0) state[1] = acceptable[1] ? 0 : 2;
+        bool go2[NP];
+        double dua[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            go2[p] = state[p] == 1;
+            dua[p] = (go2[p] && has) ? -rd[p] - ((wu[p] * rpu[p] - zu[p]) - (wl[p] * rpl[p] - zl[p])) : 0.0;
+        }
+        band_solve_group_n<64, KD, NP>(fa, frinv, flow, dua, m, gl);
+        double dsua[NP], dsla[NP], dzua[NP], dzla[NP], ratio[NP], mu_aff[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            dsua[p] = -rpu[p] - dua[p];
+            dsla[p] = -rpl[p] + dua[p];
+            dzua[p] = -zu[p] - wu[p] * dsua[p];
+            dzla[p] = -zl[p] - wl[p] * dsla[p];
+            ratio[p] = (go2[p] && has) ? fmax(fmax(-dsua[p] * isu[p], -dsla[p] * isl[p]), fmax(-dzua[p] * izu[p], -dzla[p] * izl[p])) : 0.0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ratio[0] = fmax(ratio[0], __shfl_xor(ratio[0], o, 64));
+            ratio[1] = fmax(ratio[1], __shfl_xor(ratio[1], o, 64));
+        }
+        double a_aff[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            a_aff[p] = (ratio[p] > 1.0) ? fast_rcp(ratio[p]) : 1.0;
+            mu_aff[p] = (go2[p] && has) ? (su[p] + a_aff[p] * dsua[p]) * (zu[p] + a_aff[p] * dzua[p]) +
+                                              (sl[p] + a_aff[p] * dsla[p]) * (zl[p] + a_aff[p] * dzla[p])
+                                        : 0.0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mu_aff[0] += __shfl_xor(mu_aff[0], o, 64);
+            mu_aff[1] += __shfl_xor(mu_aff[1], o, 64);
+        }
+        double rcu[NP], rcl[NP], du[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            mu_aff[p] /= (double)rows;
+            double sigma = (mu[p] > 0.0) ? mu_aff[p] * fast_rcp(mu[p]) : 0.0;
+            sigma = sigma * sigma * sigma;
+            rcu[p] = su[p] * zu[p] + dsua[p] * dzua[p] - sigma * mu[p];
+            rcl[p] = sl[p] * zl[p] + dsla[p] * dzla[p] - sigma * mu[p];
+            du[p] = (go2[p] && has) ? -rd[p] - ((zu[p] * rpu[p] - rcu[p]) * isu[p] - (zl[p] * rpl[p] - rcl[p]) * isl[p]) : 0.0;
+        }
+        band_solve_group_n<64, KD, NP>(fa, frinv, flow, du, m, gl);
+        double dsu[NP], dsl[NP], dzu[NP], dzl[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            dsu[p] = -rpu[p] - du[p];
+            dsl[p] = -rpl[p] + du[p];
+            dzu[p] = -(rcu[p] + zu[p] * dsu[p]) * isu[p];
+            dzl[p] = -(rcl[p] + zl[p] * dsl[p]) * isl[p];
+            ratio[p] = (go2[p] && has) ? fmax(fmax(-dsu[p] * isu[p], -dsl[p] * isl[p]), fmax(-dzu[p] * izu[p], -dzl[p] * izl[p])) : 0.0;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ratio[0] = fmax(ratio[0], __shfl_xor(ratio[0], o, 64));
+            ratio[1] = fmax(ratio[1], __shfl_xor(ratio[1], o, 64));
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const double tau = (mu[p] < 1e-6) ? 0.999 : 0.99;
+            const double alpha = (ratio[p] > tau) ? tau * fast_rcp(ratio[p]) : 1.0;   // min(1, tau / ratio)
+            if (go2[p]) {
+                if (has) {
+                    su[p] += alpha * dsu[p];
+                    sl[p] += alpha * dsl[p];
+                    zu[p] += alpha * dzu[p];
+                    zl[p] += alpha * dzl[p];
+                    u[p] += alpha * du[p];
+                }
+                ++iters[p];
+            }
+        }
+    }
+    *iters_out = max(iters[0], iters[1]);
+    *out_x = u[0];
+    *out_y = u[1];
+    return (state[0] == 0 && state[1] == 0) ? 0 : 2;
+}
+
+// Smoothing of one polyline on one wavefront.  m <= 32: lanes 0-31 solve x, lanes 32-63 solve y (register fast
+// path); 32 < m <= 64: smooth_pair_lanes (one point per lane, x and y side by side, registers only); longer
+// polylines: the two half-waves with the LDS-resident solver.
 // lds: 2 * BoxRangeQp::words(m, m) doubles.  xy: [m][stride] with x at +0, y at +1 (LDS or global).
 // On success the smoothed coordinates are Q.u of each half: returned through out_x / out_y pointers INTO lds.
 __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride, int m, const SmoothQpParams& sx,
@@ -932,6 +1254,22 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     const int lane = threadIdx.x & 63, grp = lane >> 5, gl = lane & 31;
     *iters_out = 0;
     if (m < 2) return 2;
+#ifndef EMP_SMOOTH_FORCE_LDS
+    if (m > 32 && m <= 64) {                            // one point per lane, x and y side by side, all in registers
+        double ux = 0.0, uy = 0.0;
+        const double rx = lane < m ? xy[(size_t)lane * stride] : 0.0, ry = lane < m ? xy[(size_t)lane * stride + 1] : 0.0;
+        const int rc = smooth_pair_lanes(rx, ry, m, sx, sy, &ux, &uy, iters_out);
+        __syncthreads();
+        if (lane < m) {
+            lds[lane] = ux;
+            lds[m + lane] = uy;
+        }
+        __syncthreads();
+        *out_x = lds;
+        *out_y = lds + m;
+        return rc;
+    }
+#endif
     BoxRangeQp Q;
     const int words = BoxRangeQp::words(m, m);
     Q.bind(lds + grp * words, m, m);

@@ -579,7 +579,7 @@ __device__ inline int walk_from_zero(const double* sm, int P, double s, bool* of
 // The reference walks the s_map index monotonically from the previous point (:42-43); with a non-decreasing
 // s_map (what cal_s_map_fun produces) that equals a running maximum of independent walks from index 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void cycle_cartesian_wave_kernel(
     int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
     const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
