@@ -44,17 +44,61 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return r;
 }
 
-template <int G>
-__device__ __forceinline__ double group_max(double v) {
+// All-lanes reductions over a group of G = 32 or 64 lanes without LDS traffic: four DPP butterfly levels inside
+// each row of 16 lanes (quad_perm x2, row_half_mirror, row_mirror: after level k every aligned block of 2^k
+// lanes holds its own reduction, so a mirror works as the next exchange), then gfx950's row swaps
+// (v_permlane16_swap / v_permlane32_swap) across rows.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, a.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, a.i[1], CTRL, 0xF, 0xF, true);
+    return r.d;
+}
+// the partner value of the xor-16 (ROWS = 16) or xor-32 (ROWS = 32) exchange, for values uniform per row
+template <int ROWS>
+__device__ __forceinline__ void row_swap(double v, double* mine, double* other) {
+    union { double d; int i[2]; } a, m, o;
+    a.d = v;
 #pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    for (int w = 0; w < 2; ++w) {
+        if constexpr (ROWS == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(a.i[w], a.i[w], false, false);
+            m.i[w] = r[0];
+            o.i[w] = r[1];
+        } else {
+            const auto r = __builtin_amdgcn_permlane32_swap(a.i[w], a.i[w], false, false);
+            m.i[w] = r[0];
+            o.i[w] = r[1];
+        }
+    }
+    *mine = m.d;
+    *other = o.d;
+}
+template <int G, class Op>
+__device__ __forceinline__ double group_reduce(double v, Op op) {
+    static_assert(G == 32 || G == 64, "group size must be 32 or 64");
+    v = op(v, dpp_move<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141>(v));     // row_half_mirror
+    v = op(v, dpp_move<0x140>(v));     // row_mirror
+    double x, y;
+    row_swap<16>(v, &x, &y);
+    v = op(x, y);
+    if constexpr (G == 64) {
+        row_swap<32>(v, &x, &y);
+        v = op(x, y);
+    }
     return v;
 }
 template <int G>
+__device__ __forceinline__ double group_max(double v) {
+    return group_reduce<G>(v, [](double a, double b) { return fmax(a, b); });
+}
+template <int G>
 __device__ __forceinline__ double group_min(double v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
+    return group_reduce<G>(v, [](double a, double b) { return fmin(a, b); });
 }
 template <int G>
 __device__ __forceinline__ bool group_any(bool p) {             // true if p holds on any lane of MY group
@@ -64,9 +108,7 @@ __device__ __forceinline__ bool group_any(bool p) {             // true if p hol
 }
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return group_reduce<G>(v, [](double a, double b) { return a + b; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -742,13 +784,10 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         EMP_QP_PROF(2);
         {
             double rd_max = (run && has_m) ? fabs(rd_m) : 0.0;
-#pragma unroll
-            for (int o = G / 2; o >= 1; o >>= 1) {          // four reductions in one butterfly
-                rd_max = fmax(rd_max, __shfl_xor(rd_max, o, 64));
-                rp_max = fmax(rp_max, __shfl_xor(rp_max, o, 64));
-                zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
-                mu += __shfl_xor(mu, o, 64);
-            }
+            rd_max = group_max<G>(rd_max);
+            rp_max = group_max<G>(rp_max);
+            zmax = group_max<G>(zmax);
+            mu = group_sum<G>(mu);
             mu /= (double)rows;
             if (run) {
                 const double dscale = fmax(qscale, zmax);
@@ -1130,14 +1169,11 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
             red[p][3] = has ? su[p] * zu[p] + sl[p] * zl[p] : 0.0;
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {              // eight reductions in one butterfly
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                red[p][0] = fmax(red[p][0], __shfl_xor(red[p][0], o, 64));
-                red[p][1] = fmax(red[p][1], __shfl_xor(red[p][1], o, 64));
-                red[p][2] = fmax(red[p][2], __shfl_xor(red[p][2], o, 64));
-                red[p][3] += __shfl_xor(red[p][3], o, 64);
-            }
+        for (int p = 0; p < NP; ++p) {
+            red[p][0] = group_max<64>(red[p][0]);
+            red[p][1] = group_max<64>(red[p][1]);
+            red[p][2] = group_max<64>(red[p][2]);
+            red[p][3] = group_sum<64>(red[p][3]);
         }
         bool go[NP];
 #pragma unroll
@@ -1179,11 +1215,8 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
             dzla[p] = -zl[p] - wl[p] * dsla[p];
             ratio[p] = (go2[p] && has) ? fmax(fmax(-dsua[p] * isu[p], -dsla[p] * isl[p]), fmax(-dzua[p] * izu[p], -dzla[p] * izl[p])) : 0.0;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            ratio[0] = fmax(ratio[0], __shfl_xor(ratio[0], o, 64));
-            ratio[1] = fmax(ratio[1], __shfl_xor(ratio[1], o, 64));
-        }
+        ratio[0] = group_max<64>(ratio[0]);
+        ratio[1] = group_max<64>(ratio[1]);
         double a_aff[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1192,11 +1225,8 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
                                               (sl[p] + a_aff[p] * dsla[p]) * (zl[p] + a_aff[p] * dzla[p])
                                         : 0.0;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            mu_aff[0] += __shfl_xor(mu_aff[0], o, 64);
-            mu_aff[1] += __shfl_xor(mu_aff[1], o, 64);
-        }
+        mu_aff[0] = group_sum<64>(mu_aff[0]);
+        mu_aff[1] = group_sum<64>(mu_aff[1]);
         double rcu[NP], rcl[NP], du[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1217,11 +1247,8 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
             dzl[p] = -(rcl[p] + zl[p] * dsl[p]) * isl[p];
             ratio[p] = (go2[p] && has) ? fmax(fmax(-dsu[p] * isu[p], -dsl[p] * isl[p]), fmax(-dzu[p] * izu[p], -dzl[p] * izl[p])) : 0.0;
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            ratio[0] = fmax(ratio[0], __shfl_xor(ratio[0], o, 64));
-            ratio[1] = fmax(ratio[1], __shfl_xor(ratio[1], o, 64));
-        }
+        ratio[0] = group_max<64>(ratio[0]);
+        ratio[1] = group_max<64>(ratio[1]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const double tau = (mu[p] < 1e-6) ? 0.999 : 0.99;

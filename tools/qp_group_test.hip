@@ -62,8 +62,38 @@ int run(int N0, int N1) {
     return worst < 1e-11 ? 0 : 1;
 }
 
-int main() {
+__global__ void k_red(const double* v, double* out) {
+    const double x = v[threadIdx.x];
+    out[threadIdx.x] = group_max<32>(x);
+    out[64 + threadIdx.x] = group_min<32>(x);
+    out[128 + threadIdx.x] = group_sum<32>(x);
+    out[192 + threadIdx.x] = group_max<64>(x);
+    out[256 + threadIdx.x] = group_sum<64>(x);
+}
+
+static int test_reductions() {
+    double h[64], o[320];
+    for (int i = 0; i < 64; ++i) h[i] = (rand() % 2001) - 1000;            // integers: sums are exact in any order
+    double *dv, *dout;
+    hipMalloc(&dv, sizeof(h)); hipMalloc(&dout, sizeof(o));
+    hipMemcpy(dv, h, sizeof(h), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_red, dim3(1), dim3(64), 0, 0, dv, dout);
+    hipMemcpy(o, dout, sizeof(o), hipMemcpyDeviceToHost);
     int bad = 0;
+    for (int g = 0; g < 2; ++g) {
+        double mx = -1e300, mn = 1e300, sm = 0;
+        for (int i = 0; i < 32; ++i) { mx = fmax(mx, h[g * 32 + i]); mn = fmin(mn, h[g * 32 + i]); sm += h[g * 32 + i]; }
+        for (int i = 0; i < 32; ++i) bad += (o[g * 32 + i] != mx) + (o[64 + g * 32 + i] != mn) + (o[128 + g * 32 + i] != sm);
+    }
+    double mx = -1e300, sm = 0;
+    for (int i = 0; i < 64; ++i) { mx = fmax(mx, h[i]); sm += h[i]; }
+    for (int i = 0; i < 64; ++i) bad += (o[192 + i] != mx) + (o[256 + i] != sm);
+    printf("group reductions: %d mismatches\n", bad);
+    return bad ? 1 : 0;
+}
+
+int main() {
+    int bad = test_reductions();
     bad += run<32, 3>(17, 17);
     bad += run<32, 3>(32, 5);
     bad += run<32, 3>(1, 30);
