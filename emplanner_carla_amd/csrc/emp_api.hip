@@ -496,11 +496,12 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
     const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
     const int cap = path_cap + 1;                                        // trajectory = planning start + path points
     const size_t lds = ((size_t)max_ref + 3 * (size_t)cap + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
-    int rc = set_lds(ctx, cycle_cartesian_wave_kernel, lds);
+    auto kern = cap > 32 ? cycle_cartesian_wave_kernel_wide : cycle_cartesian_wave_kernel_narrow;
+    int rc = set_lds(ctx, kern, lds);
     if (rc) return rc;
     KernelTimer t(ctx, "to_cartesian");
-    hipLaunchKernelGGL(cycle_cartesian_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_ref, max_pts, cap, sx, sy,
-                       ref_line, s_map, n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map, n_ref,
+                       begin_sl, path_s, path_l, path_len, traj, traj_len, status);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -695,9 +696,10 @@ int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_
         const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
         const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
         const size_t lds = (2 * (size_t)BoxRangeQp::words(max_pts, max_pts) + (size_t)max_pts) * sizeof(double);
-        if ((rc = set_lds(ctx, smooth_wave_kernel, lds))) return rc;
+        auto kern = max_pts > 32 ? smooth_wave_kernel<true> : smooth_wave_kernel<false>;
+        if ((rc = set_lds(ctx, kern, lds))) return rc;
         KernelTimer t(ctx, "smooth");
-        hipLaunchKernelGGL(smooth_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_pts, sx, sy, d_xy, d_np,
+        hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, ctx->stream, B, max_pts, max_pts, sx, sy, d_xy, d_np,
                            d_out, d_it, d_st);
         EMP_LAUNCH_CHECK(ctx);
     }

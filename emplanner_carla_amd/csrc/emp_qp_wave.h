@@ -1276,13 +1276,18 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
 // polylines: the two half-waves with the LDS-resident solver.
 // lds: 2 * BoxRangeQp::words(m, m) doubles.  xy: [m][stride] with x at +0, y at +1 (LDS or global).
 // On success the smoothed coordinates are Q.u of each half: returned through out_x / out_y pointers INTO lds.
+// WIDE == false: the caller guarantees m <= 32 and only the half-wave register path is compiled (fewer VGPRs).
+template <bool WIDE>
 __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride, int m, const SmoothQpParams& sx,
                                        const SmoothQpParams& sy, double** out_x, double** out_y, int* iters_out) {
     const int lane = threadIdx.x & 63, grp = lane >> 5, gl = lane & 31;
     *iters_out = 0;
     if (m < 2) return 2;
+    if constexpr (!WIDE) {
+        if (m > 32) return 2;
+    }
 #ifndef EMP_SMOOTH_FORCE_LDS
-    if (m > 32 && m <= 64) {                            // one point per lane, x and y side by side, all in registers
+    if (WIDE && m > 32 && m <= 64) {                    // one point per lane, x and y side by side, all in registers
         double ux = 0.0, uy = 0.0;
         const double rx = lane < m ? xy[(size_t)lane * stride] : 0.0, ry = lane < m ? xy[(size_t)lane * stride + 1] : 0.0;
         const int rc = smooth_pair_lanes(rx, ry, m, sx, sy, &ux, &uy, iters_out);
@@ -1305,7 +1310,7 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     const int bad_setup = __any(rc != 0);
     if (bad_setup) return 2;
     if (m <= 32) rc = range_qp_solve_wave_fast<32>(Q, gl, true, 1000);
-    else rc = range_qp_solve_wave<32>(Q, gl, true);
+    else if constexpr (WIDE) rc = range_qp_solve_wave<32>(Q, gl, true);
     const int it_mine = Q.iters;
     *iters_out = max(__shfl(it_mine, 0, 64), __shfl(it_mine, 32, 64));
     BoxRangeQp Q0, Q1;

@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64) void path_qp_wave_kernel(int B, int max_pts, in
 // x on lanes 0-31, y on lanes 32-63, then heading / curvature one point per lane.
 // dynamic LDS: 2 * BoxRangeQp::words(cap, cap) + cap doubles
 // ---------------------------------------------------------------------------------------------
+template <bool WIDE>
 __global__ __launch_bounds__(64) void smooth_wave_kernel(int B, int max_pts, int cap, SmoothQpParams sx,
                                                          SmoothQpParams sy, const double* __restrict__ xy,
                                                          const int* __restrict__ n_pts, double* __restrict__ out,
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(64) void smooth_wave_kernel(int B, int max_pts, int
     const int m = n_pts[b];
     int it = 0, rc = 2;
     double *px = nullptr, *py = nullptr;
-    if (m <= cap && m <= max_pts) rc = smooth_pair_wave(lds, xy + (size_t)b * max_pts * 2, 2, m, sx, sy, &px, &py, &it);
+    if (m <= cap && m <= max_pts) rc = smooth_pair_wave<WIDE>(lds, xy + (size_t)b * max_pts * 2, 2, m, sx, sy, &px, &py, &it);
     if (rc == 0) heading_kappa_wave(px, py, m, lds + 2 * BoxRangeQp::words(m, m), out + (size_t)b * max_pts * 4, 4);
     if ((threadIdx.x & 63) == 0) {
         if (iters) iters[b] = it;
@@ -579,7 +580,10 @@ __device__ inline int walk_from_zero(const double* sm, int P, double s, bool* of
 // The reference walks the s_map index monotonically from the previous point (:42-43); with a non-decreasing
 // s_map (what cal_s_map_fun produces) that equals a running maximum of independent walks from index 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void cycle_cartesian_wave_kernel(
+// WIDE == false (cap <= 32, the benchmark's 23-point trajectories): only the half-wave smoothing path is
+// compiled, which fits four wavefronts per SIMD - all 4096 scenes of a batch are resident at once.
+template <bool WIDE>
+__device__ __forceinline__ void cycle_cartesian_body(
     int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
     const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
     int it = 0;
     double *px = nullptr, *py = nullptr;
-    const int rc = smooth_pair_wave(qmem, txy, 2, m, sx, sy, &px, &py, &it);
+    const int rc = smooth_pair_wave<WIDE>(qmem, txy, 2, m, sx, sy, &px, &py, &it);
     if (rc) {
         if (lane == 0) status[b] = st | kStSmoothFailed;
         return 0;
@@ -665,6 +669,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     for (int i = m_out * 4 + lane; i < (max_pts + 1) * 4; i += 64) out_rows[i] = 0.0;       // padding reads as 0
     if (lane == 0) traj_len[b] = m_out;
 }
+
+#define EMP_CARTESIAN_ARGS B, max_ref, max_pts, cap, sx, sy, ref_line, s_map, n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status
+__global__ __launch_bounds__(64) void cycle_cartesian_wave_kernel_wide(
+    int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
+    const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
+    const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
+    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
+    cycle_cartesian_body<true>(EMP_CARTESIAN_ARGS);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cycle_cartesian_wave_kernel_narrow(
+    int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
+    const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
+    const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
+    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
+    cycle_cartesian_body<false>(EMP_CARTESIAN_ARGS);
+}
+#undef EMP_CARTESIAN_ARGS
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone forms of the projection helpers (one lane per scene, points in order)

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void bench_kernel(int m, SmoothQpParams sx, Smo
     double *px, *py;
     int it = 0;
     const unsigned long long t0 = clock64();
-    const int rc = smooth_pair_wave(qmem, xy, 2, m, sx, sy, &px, &py, &it);
+    const int rc = smooth_pair_wave<true>(qmem, xy, 2, m, sx, sy, &px, &py, &it);
     const unsigned long long t1 = clock64();
     if (lane == 0) {
         iters[blockIdx.x] = rc ? -rc : it;
