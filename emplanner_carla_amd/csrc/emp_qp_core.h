@@ -39,10 +39,18 @@
 namespace emp {
 
 constexpr int kQpMaxIter = 60;
+// Fraction of the step to the boundary.  It approaches 1 with the complementarity gap (as in Mehrotra-type
+// codes: tau = max(0.99, 1 - mu)), which turns the endgame from a fixed 100x reduction of mu per iteration into
+// a superlinear one.
+#ifndef EMP_QP_TAU
+#define EMP_QP_TAU(mu) fmax(0.99, 1.0 - (mu))
+#endif
+EMP_HD double qp_step_fraction(double mu) { return EMP_QP_TAU(mu); }
 // Infeasible problems never close the primal residual: a full Newton step removes it entirely, and feasible
-// problems of this family take a full step within the first ~10 iterations.  A residual still above 1e-3 m after
-// kQpStallIter iterations is reported as failure instead of iterating until the multipliers overflow.
-constexpr int kQpStallIter = 24;
+// problems of this family take one early (on the 902 feasible benchmark scenes of tools/qp_iters_probe.py the
+// residual is below 1e-3 m by iteration 8 at the latest).  A residual still above 1e-3 m after kQpStallIter
+// iterations is reported as failure instead of iterating until the multipliers overflow.
+constexpr int kQpStallIter = 16;
 constexpr double kQpStallResidual = 1e-3;
 
 // ---------------------------------------------------------------------------------------------
@@ -106,6 +114,12 @@ struct RangeQp {
     double* tmp = nullptr;   // [ns][F][2] scratch (wave solver); unused by the scalar solver
     double* wgt = nullptr;   // [ns][F]    scratch (wave solver)
     double eps_p = 1e-9, eps_mu = 1e-12, eps_d_rel = 1e-9;   // stopping thresholds (see solve_scalar)
+    // Starting multipliers: max(1, z0_rel * max_m P[m][m]).  With z0_rel = 1 they start at the scale of the
+    // Hessian - the size a multiplier needs to move an unknown by one unit; path QPs through hard corridors
+    // otherwise spend ten iterations growing z by three orders of magnitude (mean 9.6 -> 8.0 iterations, worst
+    // case 25 -> 16 on the benchmark scenes).  The smoothing QP (0.2 m boxes, Hessian ~7) is best left at 1.
+    double z0_rel = 0.0;
+    EMP_HD double initial_multiplier(double pscale) const { return fmax(1.0, z0_rel * pscale); }
     int iters = 0;
 
     static constexpr int words(int N_, int ns_) {            // doubles of storage the pointers need
@@ -179,9 +193,12 @@ struct RangeQp {
                 smin = fmin(smin, fmin(s[(t * F + f) * 2], s[(t * F + f) * 2 + 1]));
             }
         const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
+        double pscale = 0.0;
+        for (int m = 0; m < N; ++m) pscale = fmax(pscale, P[m * B]);
+        const double z0 = initial_multiplier(pscale);
         for (int r = 0; r < rows; ++r) {
             s[r] += shift;
-            z[r] = 1.0;
+            z[r] = z0;
         }
         bool acceptable = false;
         for (iters = 0; iters < kQpMaxIter; ++iters) {
@@ -273,7 +290,7 @@ struct RangeQp {
             band_solve<KD>(M, rhs, N);                      // rhs = du
             alpha = 1e300;
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) alpha = fmin(1.0, ((mu < 1e-6) ? 0.999 : 0.99) * alpha);
+                if (pass == 1) alpha = fmin(1.0, qp_step_fraction(mu) * alpha);
                 for (int t = 0; t < ns; ++t)
                     for (int f = 0; f < F; ++f) {
                         const int k = (t * F + f) * 2;
@@ -320,6 +337,7 @@ struct PathQpParams {
 EMP_HD void path_qp_forms(PathRangeQp& Q, const PathQpParams& prm) {
     const double ds = prm.ds;
     Q.off0 = -2;
+    Q.z0_rel = 1.0;
     Q.g[0][0] = 1.0 / 6.0 - prm.d1 / (2.0 * ds);
     Q.g[0][1] = 4.0 / 6.0;
     Q.g[0][2] = 1.0 / 6.0 + prm.d1 / (2.0 * ds);

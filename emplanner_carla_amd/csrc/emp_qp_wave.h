@@ -423,12 +423,15 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
         }
         qscale = group_max<G>(qscale);
         smin = group_min<G>(smin);
+        double pscale = 0.0;
+        for (int m = gl; m < N; m += G) pscale = fmax(pscale, Q.P[m * B]);
+        const double z0 = Q.initial_multiplier(group_max<G>(pscale));
         const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
         for (int it = gl; it < items; it += G) {
             Q.s[it * 2] += shift;
             Q.s[it * 2 + 1] += shift;
-            Q.z[it * 2] = 1.0;
-            Q.z[it * 2 + 1] = 1.0;
+            Q.z[it * 2] = z0;
+            Q.z[it * 2 + 1] = z0;
         }
     }
     __syncthreads();
@@ -585,7 +588,7 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
         if (go2) {
             double a_loc = 1e300;
             for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) alpha = fmin(1.0, ((mu < 1e-6) ? 0.999 : 0.99) * group_min<G>(a_loc));
+                if (pass == 1) alpha = fmin(1.0, qp_step_fraction(mu) * group_min<G>(a_loc));
                 for (int it = gl; it < items; it += G) {
                     const int t = it / F, f = it - t * F;
                     const double v = Q.c[it] + Q.form_val(t, f, Q.u);
@@ -698,6 +701,11 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
     }
     const double q_m = has_m ? Q.q[m] : 0.0;
     double u_m = has_m ? Q.u[m] : 0.0;
+    {
+        const double z0 = Q.initial_multiplier(group_max<G>(has_m ? Prow[0] : 0.0));
+#pragma unroll
+        for (int f = 0; f < F; ++f) zu[f] = zl[f] = z0;
+    }
     auto gather = [&](const double* coef) {
         double acc = 0.0;
 #pragma unroll
@@ -870,7 +878,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
                 ratio = fmax(ratio, fmax(fmax(-dsu[f] * isu[f], -dsl[f] * isl[f]), fmax(-dzu[f] * izu[f], -dzl[f] * izl[f])));
         }
         ratio = group_max<G>(ratio);
-        const double tau = (mu < 1e-6) ? 0.999 : 0.99;
+        const double tau = qp_step_fraction(mu);
         const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
         if (go2) {
             if (has_t) {
@@ -1251,7 +1259,7 @@ __device__ inline int smooth_pair_lanes(double rx, double ry, int m, const Smoot
         ratio[1] = group_max<64>(ratio[1]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const double tau = (mu[p] < 1e-6) ? 0.999 : 0.99;
+            const double tau = qp_step_fraction(mu[p]);
             const double alpha = (ratio[p] > tau) ? tau * fast_rcp(ratio[p]) : 1.0;   // min(1, tau / ratio)
             if (go2[p]) {
                 if (has) {

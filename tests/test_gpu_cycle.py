@@ -181,6 +181,32 @@ def test_smooth_line_reference_line_size(planner):
         assert_rel(out[b, :n, 3], want[b][:, 3], RTOL, 1e-2, "kappa")
 
 
+@pytest.mark.parametrize("cap,sizes", [(24, [24, 23, 9, 2]), (100, [100, 70, 65, 33])])
+def test_smooth_line_all_kernel_paths(planner, cap, sizes):
+    """The three smoothing code paths: <= 32 points (x | y on the half-waves), 33..64 (one point per lane,
+    covered above) and > 64 (LDS-resident solver), each against the faithful port."""
+    from emplanner_carla_amd.api import smooth_params
+    rng = np.random.default_rng(cap)
+    B = len(sizes)
+    xy = np.zeros((B, cap, 2))
+    n_pts = np.array(sizes, np.int32)
+    want = []
+    for b in range(B):
+        t = np.arange(n_pts[b]) * 2.0
+        pts = np.stack([t * np.cos(0.2 * b) + rng.normal(0, 0.12, n_pts[b]),
+                        t * np.sin(0.2 * b) + 10 * np.sin(t / 35.0) + rng.normal(0, 0.12, n_pts[b])], axis=1)
+        xy[b, :n_pts[b]] = pts
+        want.append(np.asarray(op.smooth_reference_line([tuple(p) for p in pts]), dtype=np.float64))
+    out, iters, st = planner.smooth_line(smooth_params(), xy, n_pts)
+    assert (st == 0).all() and (iters > 0).all()
+    for b in range(B):
+        n = n_pts[b]
+        assert_rel(out[b, :n, :2], want[b][:, :2], RTOL, 1.0, "smoothed xy")
+        if n >= 3:
+            assert_rel(out[b, :n, 2], want[b][:, 2], RTOL, 1.0, "theta")
+            assert_rel(out[b, :n, 3], want[b][:, 3], RTOL, 1e-2, "kappa")
+
+
 @pytest.mark.parametrize("key", list(GOLD))
 def test_full_cycle_vs_reference(planner, key):
     """emp_plan_cycle == reference motion_planning body (test_9 / test_7 / test_6 driver forms)."""

@@ -21,3 +21,5 @@ l, dl, ddl, iters, st4 = pl.path_qp(qp_params(), lo, hi, n.astype(np.int32), np.
 print("status counts", {int(k): int((st4 == k).sum()) for k in np.unique(st4)})
 for k in np.unique(st4):
     print("status", k, "iters mean %.1f max %d" % (iters[st4 == k].mean(), iters[st4 == k].max()), np.bincount(iters[st4 == k]))
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed("gpurun_out/qp_cases.npz", lo=lo, hi=hi, n=n.astype(np.int32), start=np.ascontiguousarray(start[:, 1:]), iters=iters, status=st4)
