@@ -119,8 +119,8 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
                          double* path_s, double* path_l, int* path_len, int* status, int or_status) {
     if (d.B == 0) return EMP_OK;
     KernelTimer t(ctx, "dp_enrich");
-    hipLaunchKernelGGL(dp_enrich_kernel, dim3((d.B + 63) / 64), dim3(64), 0, ctx->stream, d, rows, start, max_pts,
-                       path_s, path_l, path_len, status, or_status);
+    hipLaunchKernelGGL(dp_enrich_wave_kernel, dim3(d.B), dim3(64), 0, ctx->stream, d, rows, start, max_pts, path_s, path_l,
+                       path_len, status, or_status);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }

@@ -13,7 +13,7 @@
 //                      FP64 VALU bound; writes the tiled (or canonical) tensor, 8 B per lane coalesced.
 //   dp_sweep_kernel    min-plus sweep + argmin + backtrack (ref: path_planning.py:301-361), HBM bound:
 //                      streams the tiled tensor once with a register double buffer of PD columns.
-//   dp_enrich_kernel   row indices -> densified (s, l) path (ref: path_planning.py:364-432).
+//   dp_enrich_wave_kernel   row indices -> densified (s, l) path (ref: path_planning.py:364-432).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -354,55 +354,80 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
 // ---------------------------------------------------------------------------------------------
 // densification (ref: path_planning.py:364-432)
 // ---------------------------------------------------------------------------------------------
-__global__ void dp_enrich_kernel(DpDev P, const double* __restrict__ rows, const double* __restrict__ start,
-                                 int max_pts, double* __restrict__ path_s, double* __restrict__ path_l,
-                                 int* __restrict__ path_len, int* __restrict__ status, int or_status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= P.B) return;
+// One wavefront per scene and one lattice segment per lane: every segment's start state is known
+// from the chosen rows alone (s0 = plan_start_s + c * sample_s, l0 = the previous node, dl0 = ddl0 = 0 after the
+// first segment), so the quintics are independent and only the output offsets need a prefix sum over the
+// per-segment sample counts (ref :405 / :423: len(arange(0, int(end_s - start_s), res))).
+__global__ __launch_bounds__(64) void dp_enrich_wave_kernel(DpDev P, const double* __restrict__ rows,
+                                                           const double* __restrict__ start, int max_pts,
+                                                           double* __restrict__ path_s, double* __restrict__ path_l,
+                                                           int* __restrict__ path_len, int* __restrict__ status,
+                                                           int or_status) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
     const double ps = start[b * 4 + 0];
-    double s0 = ps, l0 = start[b * 4 + 1], dl0 = start[b * 4 + 2], ddl0 = start[b * 4 + 3];
     double* os = path_s + (size_t)b * max_pts;
     double* ol = path_l + (size_t)b * max_pts;
-    int n = 0;
+    const double* my_rows = rows + (size_t)b * P.col;
+    int n_before = 0;
     bool trunc = false;
-    double end_s = ps, end_l = l0;
-    for (int c = 0; c < P.col; ++c) {
-        end_s = ps + (double)(c + 1) * P.sample_s;                       // ref :369
-        end_l = lattice_l_f(P.row, rows[(size_t)b * P.col + c], P.sample_l);   // ref :370
+    double last_s = ps, last_l = start[b * 4 + 1];
+    for (int c0 = 0; c0 < P.col; c0 += 64) {
+        const int c = c0 + lane;
+        const bool in = c < P.col;
+        const int cc = in ? c : P.col - 1;
+        const double s0 = (cc == 0) ? ps : ps + (double)cc * P.sample_s;              // previous segment's end_s (ref :369)
+        const double end_s = ps + (double)(cc + 1) * P.sample_s;
+        const double l0 = (cc == 0) ? start[b * 4 + 1] : lattice_l_f(P.row, my_rows[cc - 1], P.sample_l);
+        const double dl0 = (cc == 0) ? start[b * 4 + 2] : 0.0, ddl0 = (cc == 0) ? start[b * 4 + 3] : 0.0;
+        const double end_l = lattice_l_f(P.row, my_rows[cc], P.sample_l);            // ref :370
         const double span = end_s - s0;
-        const int cnt = arange_count(span, P.res);                       // ref :405 / :423
+        const int cnt = in ? arange_count(span, P.res) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int off = n_before + incl - cnt;
         const Quintic q = quintic_shifted(l0, dl0, ddl0, end_l, span);
         for (int k = 0; k < cnt; ++k) {
             const double t = (double)k * P.res;
+            const int n = off + k;
             if (n < max_pts) {
                 os[n] = s0 + t;
                 ol[n] = quintic_l(q, t);
-                ++n;
             } else {
                 trunc = true;
             }
         }
-        s0 = end_s;
-        l0 = end_l;
-        dl0 = 0.0;
-        ddl0 = 0.0;
+        n_before += __shfl(incl, 63, 64);
+        const int owner = min(P.col - 1 - c0, 63);                                   // lane of the chunk's last real segment
+        last_s = __shfl(end_s, owner, 64);
+        last_l = __shfl(end_l, owner, 64);
     }
-    if (n < max_pts) {                                                   // ref :429-430
-        os[n] = end_s;
-        ol[n] = end_l;
+    int n = n_before;
+    if (n < max_pts) {                                                               // ref :429-430
+        if (lane == 0) {
+            os[n] = last_s;
+            ol[n] = last_l;
+        }
         ++n;
     } else {
         trunc = true;
     }
-    path_len[b] = n;
-    for (int k = n; k < max_pts; ++k) {                                  // padding reads as 0
+    n = min(n, max_pts);
+    for (int k = n + lane; k < max_pts; k += 64) {                                   // padding reads as 0
         os[k] = 0.0;
         ol[k] = 0.0;
     }
-    if (or_status) {
-        if (trunc) status[b] |= 32;                                      // EMP_ST_TRUNCATED
-    } else {
-        status[b] = trunc ? 32 : 0;
+    const bool any_trunc = __any(trunc);
+    if (lane == 0) {
+        path_len[b] = n;
+        if (or_status) {
+            if (any_trunc) status[b] |= 32;                                          // EMP_ST_TRUNCATED
+        } else {
+            status[b] = any_trunc ? 32 : 0;
+        }
     }
 }
 

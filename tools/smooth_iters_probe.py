@@ -20,3 +20,5 @@ txy, n_out, st = pl.frenet_path_to_xy(b.ref, sm, np.full(B, P, np.int32), bsl, r
 out, it, st2 = pl.smooth_line(smooth_params(), txy, n_out)
 sel = ok & (st2 == 0)
 print("smoothing iterations: mean %.1f max %d" % (it[sel].mean(), it[sel].max()), np.bincount(it[sel]))
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed("gpurun_out/smooth_cases.npz", txy=txy[sel], n=n_out[sel], iters=it[sel])
