@@ -79,6 +79,7 @@ PROTOTYPES = {
     "emp_copy_to_device": (C.c_int, [_vp, _vp, _vp, _u64]),
     "emp_copy_to_host": (C.c_int, [_vp, _vp, _vp, _u64]),
     "emp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "emp_set_timing_filter": (C.c_int, [_vp, C.c_char_p]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
     "emp_kernel_launches": (C.c_int, [_vp, C.c_char_p]),
     "emp_edge_tensor_elems": (_u64, [C.POINTER(DpParams), _i32, C.c_int]),

@@ -173,7 +173,10 @@ class Planner:
     def synchronize(self):
         self._check(self._lib.emp_synchronize(self._h))
 
-    def set_timing(self, enabled: bool):
+    def set_timing(self, enabled: bool, only: str | None = None):
+        """Bracket kernel launches with HIP events on the planner's stream; ``only`` restricts the events to one
+        named kernel (an event pair costs a few microseconds of stream time per launch)."""
+        self._check(self._lib.emp_set_timing_filter(self._h, only.encode() if only else None))
         self._check(self._lib.emp_set_timing(self._h, int(bool(enabled))))
 
     def kernel_ms(self, name: str) -> float:

@@ -283,6 +283,12 @@ int emp_set_timing(emp_ctx* ctx, int enabled) {
     return EMP_OK;
 }
 
+int emp_set_timing_filter(emp_ctx* ctx, const char* kernel) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    ctx->timing_filter = kernel ? kernel : "";
+    return EMP_OK;
+}
+
 int emp_kernel_launches(emp_ctx* ctx, const char* kernel) {
     if (!ctx || !kernel) return 0;
     auto it = ctx->events.find(kernel);

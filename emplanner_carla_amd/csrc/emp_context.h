@@ -27,6 +27,7 @@ struct emp_ctx {
     // persistent named scratch (survives across the staged buffers of one call)
     std::map<std::string, Buf> named;
     // lattice parameters the "dp_pair_table" scratch was built for (emp_api.hip: dev_dp_edge)
+    std::string timing_filter;   // non-empty: only this kernel name is bracketed by events
     double pair_table_key[8] = {0};
     bool pair_table_valid = false;
     // per-kernel timing
@@ -148,6 +149,7 @@ struct KernelTimer {
     hipEvent_t stop = nullptr;
     KernelTimer(emp_ctx* c, const char* name) : ctx(c) {
         if (!c->timing) return;
+        if (!c->timing_filter.empty() && c->timing_filter != name) return;
         emp_ctx::Ev& e = c->events[name];
         if (e.used == e.pairs.size()) {
             hipEvent_t a = nullptr, b = nullptr;

@@ -116,6 +116,10 @@ int emp_copy_to_host(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);
  * duration in milliseconds over the launches recorded since (it synchronises on their events), or a
  * negative value if there were none; emp_kernel_launches returns how many were recorded. */
 int emp_set_timing(emp_ctx* ctx, int enabled);
+/* Restrict the event pairs to ONE named kernel (NULL or "" = every kernel again).  An event pair costs a few
+ * microseconds of stream time per launch, so a benchmark that needs the live duration of one kernel should not
+ * pay for bracketing the others. */
+int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
 int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
 

@@ -41,7 +41,7 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 
 stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
 lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps 20 --warmup 5` on one MI355X ({scenes} scenes/GPU)", "",
-         "`rocprofv3 --kernel-trace --stats` (all 25 launches: 5 warm-up + 20 timed):", "",
+         "`rocprofv3 --kernel-trace --stats` (all launches: 5 warm-up + 20 timed + 5 of the per-kernel diagnostic pass):", "",
          "| kernel | calls | mean us | % of GPU time |", "|---|---|---|---|"]
 for r in stats:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
