@@ -88,7 +88,7 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
                         const int* n_obs, double* rows, double* min_cost, int* status) {
     if (d.B == 0) return EMP_OK;
     static const int variant = getenv("EMP_SWEEP_VARIANT") ? atoi(getenv("EMP_SWEEP_VARIANT")) : 0;
-    KernelTimer t(ctx, "dp_sweep");
+    KernelTimer t(ctx, "dp_sweep", true);   // the roofline kernel: events stamped by the dispatch itself
 #define EMP_SWEEP(R, PD, WPB)                                                                               \
     do {                                                                                                    \
         const size_t lds = (size_t)(WPB) * (d.col * 64 + 64 * sizeof(double));                              \
@@ -96,8 +96,8 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
         if (lds > 48 * 1024)                                                                                \
             EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-        hipLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
-                           ctx->stream, d, start_cost, edge, n_obs, rows, min_cost, status);                \
+        hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                              ctx->stream, t.start, t.stop, 0, d, start_cost, edge, n_obs, rows, min_cost, status); \
     } while (0)
     switch (d.row) {
         case 5: EMP_SWEEP(5, 12, 1); break;

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -146,8 +147,12 @@ class Stage {
 // stream.  emp_kernel_ms() later averages all pairs recorded since timing was (re-)enabled.
 struct KernelTimer {
     emp_ctx* ctx;
-    hipEvent_t stop = nullptr;
-    KernelTimer(emp_ctx* c, const char* name) : ctx(c) {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool attached = false;   // the launcher hands start / stop to hipExtLaunchKernelGGL itself
+    // attach = true: the events are NOT recorded on the stream here; the caller passes them to
+    // hipExtLaunchKernelGGL, which stamps the kernel's own begin and end (no extra stream packets, and the
+    // interval excludes the wait between the record and the kernel's start)
+    KernelTimer(emp_ctx* c, const char* name, bool attach = false) : ctx(c), attached(attach) {
         if (!c->timing) return;
         if (!c->timing_filter.empty() && c->timing_filter != name) return;
         emp_ctx::Ev& e = c->events[name];
@@ -157,11 +162,12 @@ struct KernelTimer {
             e.pairs.push_back({a, b});
         }
         auto& pr = e.pairs[e.used++];
-        (void)hipEventRecord(pr.first, c->stream);
+        start = pr.first;
         stop = pr.second;
+        if (!attached) (void)hipEventRecord(start, c->stream);
     }
     ~KernelTimer() {
-        if (stop) (void)hipEventRecord(stop, ctx->stream);
+        if (stop && !attached) (void)hipEventRecord(stop, ctx->stream);
     }
 };
 
