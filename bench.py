@@ -110,9 +110,11 @@ def main():
     ts = pl.torch_stream()
 
     def step():
-        res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
-        if world > 1:
-            with torch.cuda.stream(ts):     # RCCL gather ordered after the planner's kernels, same stream
+        # torch work of a step (output allocation, and for N > 1 the packing + RCCL gather of the records) runs on
+        # the planner's own stream: ordered after its kernels without any cross-stream event
+        with torch.cuda.stream(ts):
+            res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
+            if world > 1:
                 rec = emp_dist.pack_records(res, p.col, M)
                 return emp_dist.gather_records(rec, total)
         return res

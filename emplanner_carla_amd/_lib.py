@@ -109,6 +109,7 @@ PROTOTYPES = {
     "emp_dy_obs_deri": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
+    "emp_reference_line": (C.c_int, [_vp, C.POINTER(SmoothParams), _i32, _i32] + [_vp] * 10 + [C.c_int]),
     "emp_speed_dp_params_default": (None, [C.POINTER(SpeedDpParams)]),
     "emp_st_graph": (C.c_int, [_vp, _i32, _i32] + [_vp] * 8 + [C.c_int]),
     "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),

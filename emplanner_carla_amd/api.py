@@ -61,6 +61,9 @@ def speed_dp_params(reference_speed=50, w_cost_ref_speed=4000, w_cost_accel=100,
     return p
 
 
+#: nodes of the local reference line (reference planning_utils.py:244-246: 10 back + 40 forward + the match)
+REF_LINE_POINTS = 51
+
 #: shape of the reference's S-T tables (speed_planning_test.py:114-122)
 ST_ROWS, ST_COLS = 40, 16
 
@@ -83,18 +86,32 @@ def _is_torch(x):
 class _Args:
     """Collects array arguments of one call, checks they live in one memory space, makes outputs."""
 
-    def __init__(self, *inputs):
+    def __init__(self, *inputs, planner=None):
         self.torch = any(_is_torch(x) for x in inputs if x is not None)
         self.keep = []
+        self.planner = planner
+        self.same_stream = False
         if self.torch:
             import torch
             self.t = torch
             self.device = next(x.device for x in inputs if _is_torch(x))
             if self.device.type != "cuda":
                 raise ValueError("torch tensors passed to the planner must live on the GPU")
-            # inputs may still be in flight on torch's stream; our kernels run on the context's own stream
-            torch.cuda.current_stream(self.device).synchronize()
+            # inputs may still be in flight on torch's stream; our kernels run on the context's own stream:
+            # order the two streams on the device (no host block)
+            cur = torch.cuda.current_stream(self.device)
+            self.same_stream = planner is not None and int(cur.cuda_stream) == int(planner.stream or 0)
+            if planner is None:
+                cur.synchronize()
+            elif not self.same_stream:               # nothing to order when the caller already works on our stream
+                planner.torch_stream().wait_stream(cur)
         self.where = L.EMP_DEVICE if self.torch else L.EMP_HOST
+
+    def done(self):
+        """After the library call: torch's current stream waits for the planner's stream, so that reading an output
+        tensor from torch code (``.cpu()``, another kernel) sees the finished result."""
+        if self.torch and self.planner is not None and not self.same_stream:
+            self.t.cuda.current_stream(self.device).wait_stream(self.planner.torch_stream())
 
     def inp(self, x, dtype, shape=None):
         if x is None:
@@ -152,6 +169,8 @@ class Planner:
             raise EmpError(f"emp_create({device_id}) failed ({rc}): {msg.decode() if msg else ''}")
         self._h = h
         self.device_id = int(device_id)
+        self._torch_stream = None
+        self._cur = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -165,9 +184,12 @@ class Planner:
             pass
 
     def _check(self, rc):
+        cur, self._cur = self._cur, None
         if rc != 0:
             msg = self._lib.emp_last_error(self._h)
             raise EmpError(f"libemplanner call failed ({rc}): {msg.decode() if msg else ''}")
+        if cur is not None:
+            cur.done()
 
     # ---- housekeeping ------------------------------------------------------------------
     def synchronize(self):
@@ -194,8 +216,14 @@ class Planner:
     def torch_stream(self):
         """The context's stream as a torch stream: ``with torch.cuda.stream(pl.torch_stream()):`` orders torch
         work (e.g. an RCCL gather of the results) after the planner's kernels without a host sync."""
-        import torch
-        return torch.cuda.ExternalStream(int(self.stream), device=torch.device("cuda", self.device_id))
+        if self._torch_stream is None:
+            import torch
+            self._torch_stream = torch.cuda.ExternalStream(int(self.stream), device=torch.device("cuda", self.device_id))
+        return self._torch_stream
+
+    def _args(self, *inputs):
+        self._cur = _Args(*inputs, planner=self)
+        return self._cur
 
     # ---- DP ------------------------------------------------------------------------------
     def edge_tensor_elems(self, p: DpParams, B: int, layout=L.EMP_EDGE_CANONICAL) -> int:
@@ -204,7 +232,7 @@ class Planner:
     def dp_edge_costs(self, p: DpParams, obs_s, obs_l, n_obs, start, layout=L.EMP_EDGE_CANONICAL):
         """ref cal_start_cost / cal_neighbor_cost for all lattice edges.
         returns start_cost (B,row) and edge: canonical (B, col-1, row_i, row_k) or tiled (flat)."""
-        a = _Args(obs_s, obs_l, n_obs, start)
+        a = self._args(obs_s, obs_l, n_obs, start)
         B = int(start.shape[0])
         mo = int(obs_s.shape[1]) if obs_s is not None and len(obs_s.shape) == 2 else 0
         c0, c0p = a.out((B, p.row), np.float64)
@@ -219,7 +247,7 @@ class Planner:
 
     def dp_plan(self, p: DpParams, obs_s, obs_l, n_obs, start, mode=L.EMP_DP_FUSED):
         """ref DP_algorithm up to the backtrack: returns rows (B,col) f64, min_cost (B,), status (B,)."""
-        a = _Args(obs_s, obs_l, n_obs, start)
+        a = self._args(obs_s, obs_l, n_obs, start)
         B = int(start.shape[0])
         mo = int(obs_s.shape[1]) if obs_s is not None and len(obs_s.shape) == 2 else 0
         rows, rp = a.out((B, p.col), np.float64)
@@ -232,7 +260,7 @@ class Planner:
 
     def dp_sweep(self, p: DpParams, start_cost, edge_tiled):
         """Min-plus sweep + backtrack on a caller-provided tiled edge tensor."""
-        a = _Args(start_cost, edge_tiled)
+        a = self._args(start_cost, edge_tiled)
         B = int(start_cost.shape[0])
         rows, rp = a.out((B, p.col), np.float64)
         mc, mp = a.out((B,), np.float64)
@@ -244,7 +272,7 @@ class Planner:
 
     def dp_enrich(self, p: DpParams, rows, start, max_pts: int):
         """ref enrich_DP_s_l: rows -> (path_s, path_l) padded to max_pts, path_len, status."""
-        a = _Args(rows, start)
+        a = self._args(rows, start)
         B = int(start.shape[0])
         ps, psp = a.out((B, max_pts), np.float64)
         pl, plp = a.out((B, max_pts), np.float64)
@@ -257,7 +285,7 @@ class Planner:
 
     def enrich_nodes(self, node_s, node_l, n_nodes, start, resolution, max_pts: int):
         """ref enrich_DP_s_l on explicit node lists: returns path_s, path_l (B,max_pts), path_len, status."""
-        a = _Args(node_s, node_l, start)
+        a = self._args(node_s, node_l, start)
         B, K = int(node_s.shape[0]), int(node_s.shape[1])
         ps, psp = a.out((B, max_pts), np.float64)
         pl, plp = a.out((B, max_pts), np.float64)
@@ -272,7 +300,7 @@ class Planner:
     def frenet_project(self, ref_line, n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs):
         """ref cal_s_map_fun + cal_s_l_fun (obstacles, start) + cal_s_l_deri_fun (start): test_9.py:113-177.
         returns s_map (B,P), obs_s (B,mo), obs_l (B,mo), begin_sl (B,2), start (B,4)."""
-        a = _Args(ref_line, origin_xy)
+        a = self._args(ref_line, origin_xy)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         sm, smp = a.out((B, P), np.float64)
@@ -290,7 +318,7 @@ class Planner:
 
     def match_projection(self, ref_line, n_ref, xy, n_pts):
         """ref match_projection_points: returns match_index (B,K) int32, proj (B,K,4)."""
-        a = _Args(ref_line, xy)
+        a = self._args(ref_line, xy)
         B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
         mi, mip = a.out((B, K), np.int32)
         pr, prp = a.out((B, K, 4), np.float64)
@@ -301,7 +329,7 @@ class Planner:
 
     def find_match_points(self, ref_line, n_ref, xy, n_pts, is_first_run, pre_match_index):
         """ref find_match_points: returns match_index (B,K) int32, proj (B,K,4)."""
-        a = _Args(ref_line, xy)
+        a = self._args(ref_line, xy)
         B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
         mi, mip = a.out((B, K), np.int32)
         pr, prp = a.out((B, K, 4), np.float64)
@@ -313,7 +341,7 @@ class Planner:
 
     def heading_kappa(self, xy, n_pts):
         """ref cal_heading_kappa: xy (B,M,2) -> theta, kappa (B,M)."""
-        a = _Args(xy)
+        a = self._args(xy)
         B, M = int(xy.shape[0]), int(xy.shape[1])
         th, thp = a.out((B, M), np.float64)
         kp, kpp = a.out((B, M), np.float64)
@@ -323,7 +351,7 @@ class Planner:
 
     def s_map(self, ref_line, n_ref, origin_xy):
         """ref cal_s_map_fun: returns s_map (B,P)."""
-        a = _Args(ref_line, origin_xy)
+        a = self._args(ref_line, origin_xy)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         sm, smp = a.out((B, P), np.float64)
         self._check(self._lib.emp_s_map(self._h, B, P, a.inp(ref_line, np.float64, (B, P, 4)),
@@ -332,7 +360,7 @@ class Planner:
 
     def s_l(self, ref_line, s_map, n_ref, xy, n_pts, match_index=None, want_l=True):
         """ref cal_s_l_fun (or cal_projection_s_fun when match_index is given): returns s, l (B,K)."""
-        a = _Args(ref_line, xy)
+        a = self._args(ref_line, xy)
         B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
         s_, sp_ = a.out((B, K), np.float64)
         l_, lp_ = a.out((B, K), np.float64) if want_l else (None, None)
@@ -344,7 +372,7 @@ class Planner:
 
     def s_l_deri(self, ref_line, n_ref, xy, v_xy, a_xy, n_pts, origin_xy):
         """ref cal_s_l_deri_fun: returns (B,K,7) = l, dl/dt, ds/dt, d2l/dt2, dl/ds, d2s/dt2, d2l/ds2."""
-        a = _Args(ref_line, xy)
+        a = self._args(ref_line, xy)
         B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(xy.shape[1])
         o, op_ = a.out((B, K, 7), np.float64)
         self._check(self._lib.emp_s_l_deri(
@@ -355,7 +383,7 @@ class Planner:
 
     def proj_point(self, ref_line, s_map, n_ref, s, pre_match_index):
         """ref cal_proj_point for n independent queries: returns out (n,4), index (n,), status (n,)."""
-        a = _Args(ref_line, s)
+        a = self._args(ref_line, s)
         n, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         o, op_ = a.out((n, 4), np.float64)
         ix, ixp = a.out((n,), np.int32)
@@ -367,7 +395,7 @@ class Planner:
         return o, ix, st
 
     def trajectory_index2s(self, x, y, n_pts):
-        a = _Args(x, y)
+        a = self._args(x, y)
         B, M = int(x.shape[0]), int(x.shape[1])
         o, op_ = a.out((B, M), np.float64)
         self._check(self._lib.emp_trajectory_index2s(self._h, B, M, a.inp(x, np.float64, (B, M)),
@@ -377,7 +405,7 @@ class Planner:
 
     def frenet2cartesian(self, ref_line, index2s, n_ref, sl, n_pts, proj_only=False):
         """ref Frenet2Cartesian / CalcProjPoint: sl (B,K,4) = s,l,dl,ddl -> out (B,K,4), status (B,)."""
-        a = _Args(ref_line, sl)
+        a = self._args(ref_line, sl)
         B, P, K = int(ref_line.shape[0]), int(ref_line.shape[1]), int(sl.shape[1])
         o, op_ = a.out((B, K, 4), np.float64)
         st, stp = a.out((B,), np.int32)
@@ -389,16 +417,34 @@ class Planner:
 
     def dy_obs_deri(self, rows):
         """ref cal_dy_obs_deri: rows (n,5) = l, vx, vy, heading, kappa -> (n,3) = s_dot, l_dot, dl."""
-        a = _Args(rows)
+        a = self._args(rows)
         n = int(rows.shape[0])
         o, op_ = a.out((n, 3), np.float64)
         self._check(self._lib.emp_dy_obs_deri(self._h, n, a.inp(rows, np.float64, (n, 5)), op_, a.where))
         return o
 
+    # ---- front end of the cycle (reference test_9.py:99-110) --------------------------------------
+    def reference_line(self, sp: SmoothParams, global_path, n_global, pred_xy, pre_match_index, is_first_run=None):
+        """find_match_points (one point, windowed) -> sampling -> smooth_reference_line.  global_path (B,G,4),
+        pred_xy (B,2), pre_match_index (B,) -> ref_line (B,51,4), n_ref (B,), match_index (B,), iters, status."""
+        a = self._args(global_path, pred_xy)
+        B, G = int(global_path.shape[0]), int(global_path.shape[1])
+        ref, refp = a.out((B, REF_LINE_POINTS, 4), np.float64)
+        nr, nrp = a.out((B,), np.int32)
+        mi, mip = a.out((B,), np.int32)
+        it, itp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        first = a.inp(is_first_run, np.int32, (B,)) if is_first_run is not None else None
+        self._check(self._lib.emp_reference_line(
+            self._h, C.byref(sp), B, G, a.inp(global_path, np.float64, (B, G, 4)), a.inp(n_global, np.int32, (B,)),
+            a.inp(pred_xy, np.float64, (B, 2)), first, a.inp(pre_match_index, np.int32, (B,)), refp, nrp, mip, itp, stp,
+            a.where))
+        return ref, nr, mi, it, st
+
     # ---- S-T speed DP (reference planner/speed_planning_test.py) ------------------------------
     def st_graph(self, obs_s, obs_l, obs_s_dot, obs_l_dot):
         """ref generate_st_graph: four (B, K) arrays (NaN = empty slot) -> s_in, s_out, t_in, t_out (B, K)."""
-        a = _Args(obs_s, obs_l, obs_s_dot, obs_l_dot)
+        a = self._args(obs_s, obs_l, obs_s_dot, obs_l_dot)
         B, K = int(obs_s.shape[0]), int(obs_s.shape[1])
         outs = [a.out((B, K), np.float64) for _ in range(4)]
         self._check(self._lib.emp_st_graph(
@@ -409,7 +455,7 @@ class Planner:
 
     def speed_dp(self, p: SpeedDpParams, s_in, s_out, t_in, t_out, plan_start_s_dot, tables=True) -> SpeedDpResult:
         """ref speed_DP: S-T segments (B, K) + start speed (B,) -> tables, terminal node, chosen (s, t) per column."""
-        a = _Args(s_in, s_out, t_in, t_out, plan_start_s_dot)
+        a = self._args(s_in, s_out, t_in, t_out, plan_start_s_dot)
         B, K = int(s_in.shape[0]), int(s_in.shape[1])
         shape = (B, ST_ROWS, ST_COLS)
         cost, cp = a.out(shape, np.float64) if tables else (None, None)
@@ -426,7 +472,7 @@ class Planner:
 
     def st_edge_costs(self, p: SpeedDpParams, edges, s_in, s_out, t_in, t_out):
         """ref CalcDpCost / CalcObsCost: edges (B, E, 5) = s0, t0, s_dot0, s1, t1 -> total (B, E), obstacle term (B, E)."""
-        a = _Args(edges, s_in)
+        a = self._args(edges, s_in)
         B, E, K = int(edges.shape[0]), int(edges.shape[1]), int(s_in.shape[1])
         tot, tp = a.out((B, E), np.float64)
         obs, op_ = a.out((B, E), np.float64)
@@ -438,7 +484,7 @@ class Planner:
 
     def st_collision_cost(self, w_cost_obs, min_dis):
         """ref CalcCollisionCost: distances (n,) -> costs (n,)."""
-        a = _Args(min_dis)
+        a = self._args(min_dis)
         n = int(min_dis.shape[0])
         c, cp = a.out((n,), np.float64)
         self._check(self._lib.emp_st_collision_cost(self._h, n, float(w_cost_obs), a.inp(min_dis, np.float64, (n,)), cp,
@@ -448,7 +494,7 @@ class Planner:
     # ---- QP stages ------------------------------------------------------------------------
     def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):
         """ref cal_lmin_lmax: returns l_min, l_max (B,M), status (B,)."""
-        a = _Args(dp_s, obs_s)
+        a = self._args(dp_s, obs_s)
         B, M = int(dp_s.shape[0]), int(dp_s.shape[1])
         mo = int(obs_s.shape[1])
         lo, lop = a.out((B, M), np.float64)
@@ -462,7 +508,7 @@ class Planner:
 
     def path_qp(self, q: QpParams, l_min, l_max, n_pts, start_l3):
         """ref Quadratic_planning: returns qp_l, qp_dl, qp_ddl (B,M), iters (B,), status (B,)."""
-        a = _Args(l_min, l_max, start_l3)
+        a = self._args(l_min, l_max, start_l3)
         B, M = int(l_min.shape[0]), int(l_min.shape[1])
         outs = [a.out((B, M), np.float64) for _ in range(3)]
         it, itp = a.out((B,), np.int32)
@@ -475,7 +521,7 @@ class Planner:
 
     def smooth_line(self, sp: SmoothParams, xy, n_pts):
         """ref smooth_reference_line: xy (B,M,2) -> out (B,M,4) x,y,theta,kappa; iters, status."""
-        a = _Args(xy)
+        a = self._args(xy)
         B, M = int(xy.shape[0]), int(xy.shape[1])
         out, outp = a.out((B, M, 4), np.float64)
         it, itp = a.out((B,), np.int32)
@@ -486,7 +532,7 @@ class Planner:
 
     def frenet_path_to_xy(self, ref_line, s_map, n_ref, begin_sl, path_s, path_l, n_pts):
         """ref frenet_2_x_y_theta_kappa before its smoothing call: returns target_xy (B,M+1,2), n_out, status."""
-        a = _Args(ref_line, path_s)
+        a = self._args(ref_line, path_s)
         B, P, M = int(ref_line.shape[0]), int(ref_line.shape[1]), int(path_s.shape[1])
         t, tp = a.out((B, M + 1, 2), np.float64)
         no, nop = a.out((B,), np.int32)
@@ -501,7 +547,7 @@ class Planner:
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
                    start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_FUSED) -> CycleResult:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes."""
-        a = _Args(ref_line, origin_xy)
+        a = self._args(ref_line, origin_xy)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         M = int(max_pts) if max_pts else max_path_points(p)
@@ -530,7 +576,7 @@ class Planner:
     # ---- scalar utilities -------------------------------------------------------------------
     def quintic_coefficients(self, bc):
         """ref cal_quintic_coefficient: bc (n,8) -> coeff (n,6) in the absolute-s basis."""
-        a = _Args(bc)
+        a = self._args(bc)
         n = int(bc.shape[0])
         c, cp = a.out((n, 6), np.float64)
         self._check(self._lib.emp_quintic_coefficients(self._h, n, a.inp(bc, np.float64, (n, 8)), cp, a.where))
@@ -538,7 +584,7 @@ class Planner:
 
     def obs_cost(self, square_d, w_collision, danger_dis=4, safe_dis=6):
         """ref cal_obs_cost: square_d (n,10) -> cost (n,)."""
-        a = _Args(square_d)
+        a = self._args(square_d)
         n = int(square_d.shape[0])
         c, cp = a.out((n,), np.float64)
         self._check(self._lib.emp_obs_cost(self._h, n, float(w_collision), float(danger_dis), float(safe_dis),

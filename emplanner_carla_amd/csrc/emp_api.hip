@@ -712,6 +712,45 @@ int emp_smooth_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_
     return st.finish();
 }
 
+int emp_reference_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_t max_global,
+                       const double* global_path, const int32_t* n_global, const double* pred_xy,
+                       const int32_t* is_first_run, const int32_t* pre_match_index, double* ref_line, int32_t* n_ref,
+                       int32_t* match_index, int32_t* iters, int32_t* status, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, sp && B >= 0 && max_global >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, global_path && n_global && pred_xy && pre_match_index && ref_line && n_ref && match_index && status,
+                "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_g, *d_xy;
+    const int *d_ng, *d_first = nullptr, *d_pre;
+    double* d_ref;
+    int *d_nr, *d_m, *d_it = nullptr, *d_st;
+    if ((rc = st.in(global_path, (size_t)B * max_global * 4, &d_g))) return rc;
+    if ((rc = st.in(n_global, (size_t)B, &d_ng))) return rc;
+    if ((rc = st.in(pred_xy, (size_t)B * 2, &d_xy))) return rc;
+    if (is_first_run && (rc = st.in(is_first_run, (size_t)B, &d_first))) return rc;
+    if ((rc = st.in(pre_match_index, (size_t)B, &d_pre))) return rc;
+    if ((rc = st.out(ref_line, (size_t)B * kRefLinePoints * 4, &d_ref, false))) return rc;
+    if ((rc = st.out(n_ref, (size_t)B, &d_nr, false))) return rc;
+    if ((rc = st.out(match_index, (size_t)B, &d_m, false))) return rc;
+    if (iters && (rc = st.out(iters, (size_t)B, &d_it, false))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
+        const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
+        const size_t lds = (2 * (size_t)kRefLinePoints + 2 * (size_t)BoxRangeQp::words(kRefLinePoints, kRefLinePoints) +
+                            (size_t)kRefLinePoints) * sizeof(double);
+        if ((rc = set_lds(ctx, reference_line_wave_kernel, lds))) return rc;
+        KernelTimer t(ctx, "reference_line");
+        hipLaunchKernelGGL(reference_line_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_global, sx, sy, d_g, d_ng,
+                           d_xy, d_first, d_pre, d_ref, d_nr, d_m, d_it, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
 int emp_frenet_path_to_xy(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_pts, const double* ref_line,
                           const double* s_map, const int32_t* n_ref, const double* begin_sl, const double* path_s,
                           const double* path_l, const int32_t* n_pts, double* target_xy, int32_t* n_out,

@@ -380,6 +380,83 @@ __global__ __launch_bounds__(64) void smooth_wave_kernel(int B, int max_pts, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Front end of one planning cycle (ref test_9.py:99-110): find_match_points for the predicted location on the
+// GLOBAL path (planning_utils.py:49-182: windowed from the previous match unless is_first_run) -> sampling
+// (:231-259: 10 nodes back, 40 forward, shifted at either end of the path, 51 nodes) -> smooth_reference_line
+// (:262-361) -> the reference line of the cycle.  One wavefront per scene.
+// dynamic LDS: 2 * kRefLinePoints (gathered xy) + 2 * BoxRangeQp::words(51, 51) + 51 doubles
+// ---------------------------------------------------------------------------------------------
+constexpr int kRefLinePoints = 51;
+
+__global__ __launch_bounds__(64) void reference_line_wave_kernel(int B, int max_global, SmoothQpParams sx, SmoothQpParams sy,
+                                                                 const double* __restrict__ global_path,
+                                                                 const int* __restrict__ n_global,
+                                                                 const double* __restrict__ pred_xy,
+                                                                 const int* __restrict__ is_first_run,
+                                                                 const int* __restrict__ pre_match_index,
+                                                                 double* __restrict__ ref_line, int* __restrict__ n_ref,
+                                                                 int* __restrict__ match_index, int* __restrict__ iters,
+                                                                 int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const double* line = global_path + (size_t)b * max_global * 4;
+    const int P = n_global[b];
+    double* gxy = lds;                                   // [51][2]
+    double* qmem = gxy + 2 * kRefLinePoints;
+    double* out = ref_line + (size_t)b * kRefLinePoints * 4;
+    int m = 0, first = 0, fail = 0;
+    if (lane == 0) {
+        const double x = pred_xy[2 * b], y = pred_xy[2 * b + 1];
+        const int st = pre_match_index[b];
+        if (P < 1 || ((!is_first_run || !is_first_run[b]) && (st < 0 || st >= P))) {
+            fail = kStSOutOfRange;                       // the reference raises IndexError
+        } else if (is_first_run && is_first_run[b]) {
+            m = match_scan(line, P, x, y, 0, 1, 50);     // ref :72-92
+        } else {
+            const Node pm = node_at(line, st);           // ref :123-167
+            const double flag = (x - pm.x) * cos(pm.theta) + (y - pm.y) * sin(pm.theta);
+            m = match_scan(line, P, x, y, st, flag > 0.0 ? 1 : -1, 5);
+        }
+        // sampling (ref :244-259): the arguments are overwritten with 10 back / 40 forward
+        int back = 10, fwd = 40;
+        if (m < back) {
+            back = m;
+            fwd = 50 - back;
+        }
+        if (P - m - 1 < fwd) {
+            fwd = P - m - 1;
+            back = 50 - fwd;
+        }
+        first = m - back;
+        if (!fail && (first < 0 || m + fwd + 1 > P)) fail = kStSOutOfRange;   // path shorter than 51 nodes: the
+                                                                              // reference's slice wraps around
+    }
+    m = __shfl(m, 0, 64);
+    first = __shfl(first, 0, 64);
+    fail = __shfl(fail, 0, 64);
+    int it = 0;
+    if (!fail) {
+        if (lane < kRefLinePoints) {
+            gxy[2 * lane] = line[4 * (first + lane)];
+            gxy[2 * lane + 1] = line[4 * (first + lane) + 1];
+        }
+        __syncthreads();
+        double *px = nullptr, *py = nullptr;
+        const int rc = smooth_pair_wave<true>(qmem, gxy, 2, kRefLinePoints, sx, sy, &px, &py, &it);
+        if (rc) fail = kStSmoothFailed;
+        else heading_kappa_wave(px, py, kRefLinePoints, qmem + 2 * BoxRangeQp::words(kRefLinePoints, kRefLinePoints), out, 4);
+    }
+    if (fail)
+        for (int i = lane; i < kRefLinePoints * 4; i += 64) out[i] = 0.0;
+    if (lane == 0) {
+        n_ref[b] = fail ? 0 : kRefLinePoints;
+        match_index[b] = m;
+        if (iters) iters[b] = it;
+        status[b] = fail;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // ref: frenet_2_x_y_theta_kappa without its smoothing call, path_planning.py:29-46
 // ---------------------------------------------------------------------------------------------
 __device__ inline int frenet_path_to_xy(const double* line, const double* s_map, int P, double begin_s, double begin_l,

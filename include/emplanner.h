@@ -295,6 +295,20 @@ int emp_frenet2cartesian(emp_ctx* ctx, int32_t B, int32_t max_ref, int32_t max_p
 /* ref: cal_dy_obs_deri (planning_utils.py:783-808): in [n][5] = l, vx, vy, heading, kappa -> out [n][3] */
 int emp_dy_obs_deri(emp_ctx* ctx, int32_t n, const double* in, double* out, emp_mem where);
 
+/* ---- front end of the cycle ----------------------------------
+ * ref: motion_planning, test_9.py:99-110: find_match_points (planning_utils.py:49-182) for the predicted
+ * location on the GLOBAL path [B][max_global][4] (x, y, heading, kappa; windowed search from pre_match_index
+ * unless is_first_run) -> sampling (:231-259; 10 nodes back / 40 forward, shifted at the ends of the path) ->
+ * smooth_reference_line (:262-361).  ref_line [B][EMP_REF_LINE_POINTS][4] is what emp_plan_cycle takes;
+ * match_index [B] is the next cycle's pre_match_index.  status: EMP_ST_S_OUT_OF_RANGE where the reference raises
+ * IndexError or slices past the path (fewer than 51 nodes), EMP_ST_SMOOTH_FAILED for the QP.
+ * is_first_run and iters may be NULL. */
+#define EMP_REF_LINE_POINTS 51
+int emp_reference_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int32_t max_global,
+                       const double* global_path, const int32_t* n_global, const double* pred_xy,
+                       const int32_t* is_first_run, const int32_t* pre_match_index, double* ref_line, int32_t* n_ref,
+                       int32_t* match_index, int32_t* iters, int32_t* status, emp_mem where);
+
 /* ---- S-T speed DP (BASELINE config 5; reference planner/speed_planning_test.py) ----------------
  * The S-T grid is hard-coded in the reference (40 non-uniform s samples :114, 16 t samples :116); tables are
  * [B][EMP_ST_ROWS][EMP_ST_COLS], row 0 = largest s (CalcSTCoordinate, :287-305).  Obstacle slots hold NaN when

@@ -301,3 +301,111 @@ def test_cycle_edge_cases(planner):
     # capacity too small -> flagged, nothing written out of bounds
     r = planner.plan_cycle(p, q, sp, max_pts=20, **base)
     assert (r.status & 32).all() and (r.traj_len == 0).all()
+
+
+def _global_path(rng, n, ds=2.0):
+    """A long noisy S-curve with heading / curvature from the port's cal_heading_kappa (what global_planning feeds)."""
+    t = np.arange(n) * ds
+    xy = np.stack([t + rng.normal(0, 0.05, n), 25.0 * np.sin(t / 60.0) + rng.normal(0, 0.05, n)], axis=1)
+    th, ka = op.cal_heading_kappa([tuple(p) for p in xy])
+    return np.column_stack([xy, th, ka])
+
+
+def test_reference_line_front_end_vs_port(planner):
+    """emp_reference_line == find_match_points -> sampling -> smooth_reference_line (test_9.py:99-110), including
+    matches near both ends of the global path, a first run, a backward search and a path that is too short."""
+    from emplanner_carla_amd.api import smooth_params
+    rng = np.random.default_rng(5)
+    G = 220
+    cases = [(220, 60, 57, 0), (220, 3, 5, 0), (220, 214, 210, 0), (220, 100, 0, 1), (220, 80, 90, 0), (51, 20, 18, 0),
+             (40, 20, 18, 0)]
+    B = len(cases)
+    gp = np.zeros((B, G, 4))
+    n_global = np.zeros(B, np.int32)
+    pred = np.zeros((B, 2))
+    pre = np.zeros(B, np.int32)
+    first = np.zeros(B, np.int32)
+    want = []
+    for b, (n, at, pre_idx, is_first) in enumerate(cases):
+        path = _global_path(rng, n)
+        gp[b, :n] = path
+        n_global[b], pre[b], first[b] = n, pre_idx, is_first
+        pred[b] = path[at, :2] + np.array([0.4, -0.7])
+        nodes = [tuple(r) for r in path]
+        match, _ = op.find_match_points([tuple(pred[b])], nodes, bool(is_first), int(pre_idx))
+        if n >= 51:
+            local = op.sampling(int(match[0]), nodes)
+            assert len(local) == 51
+            want.append((int(match[0]), np.asarray(op.smooth_reference_line(local), dtype=np.float64)))
+        else:
+            want.append((int(match[0]), None))
+    ref, n_ref, mi, it, st = planner.reference_line(smooth_params(), gp, n_global, pred, pre, first)
+    for b in range(B):
+        assert mi[b] == want[b][0], f"match index of case {b}"
+        if want[b][1] is None:
+            assert st[b] != 0 and n_ref[b] == 0
+            continue
+        assert st[b] == 0 and n_ref[b] == 51 and it[b] > 0
+        assert_rel(ref[b, :, :2], want[b][1][:, :2], RTOL, 1.0, "reference line xy")
+        assert_rel(ref[b, :, 2], want[b][1][:, 2], RTOL, 1.0, "theta")
+        assert_rel(ref[b, :, 3], want[b][1][:, 3], RTOL, 1e-2, "kappa")
+
+
+def test_reference_line_feeds_the_cycle(planner):
+    """Front end and cycle chained on the device: the cycle run on emp_reference_line's output equals the cycle run on
+    the port's smoothed reference line."""
+    import torch
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params, max_path_points
+    rng = np.random.default_rng(9)
+    # 60 m horizon: the 51-node local line reaches 80 m ahead of the match (40 nodes, 2 m apart)
+    cfg = S.LatticeConfig("front_end_24x9", row=9, col=24, sample_s=2.5, sample_l=1.5, sampling_res=2, n_obs=8)
+    B, G = 4, 200
+    gp = np.stack([_global_path(rng, G) for _ in range(B)])
+    at = np.array([30, 60, 90, 120])
+    pred = gp[np.arange(B), at + 1, :2] + rng.normal(0, 0.2, (B, 2))
+    origin = gp[np.arange(B), at, :2] + rng.normal(0, 0.2, (B, 2))
+    pre = (at - 2).astype(np.int32)
+    layout = [(8, 4.5), (15, -4.5), (21, 5.0)]                   # (nodes ahead of the match, lateral offset)
+    obs = np.zeros((B, 8, 2))
+    for b in range(B):
+        for k, (di, off) in enumerate(layout):
+            th = gp[b, at[b] + di, 2]
+            obs[b, k] = gp[b, at[b] + di, :2] + off * np.array([-np.sin(th), np.cos(th)])
+    n_obs = np.full(B, len(layout), np.int32)
+    v = np.tile([8.0, 0.5], (B, 1))
+    a0 = np.zeros((B, 2))
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    sp = smooth_params()
+    ref, n_ref, mi, it, st = planner.reference_line(sp, t(gp), t(np.full(B, G, np.int32)), t(pred), t(pre))
+    planner.synchronize()                      # outputs are produced on the planner's stream
+    assert (st.cpu().numpy() == 0).all()
+    p, q = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width)
+    res = planner.plan_cycle(p, q, sp, max_pts=max_path_points(p), ref_line=ref, n_ref=n_ref, origin_xy=t(origin), start_xy=t(pred),
+                             start_v=t(v), start_a=t(a0), obs_xy=t(obs), n_obs=t(n_obs))
+    planner.synchronize()
+    status = res.status.cpu().numpy()
+    traj = res.traj.cpu().numpy()
+    tl = res.traj_len.cpu().numpy()
+    checked = 0
+    for b in range(B):
+        nodes = [tuple(r) for r in gp[b]]
+        match, _ = op.find_match_points([tuple(pred[b])], nodes, False, int(pre[b]))
+        line = op.smooth_reference_line(op.sampling(int(match[0]), nodes))
+        try:
+            out = op.plan_cycle(line, tuple(origin[b]), tuple(pred[b]), tuple(v[b]), tuple(a0[b]), [tuple(o) for o in obs[b, :len(layout)]],
+                                dp_kwargs=dict(row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l,
+                                               sampling_res=cfg.sampling_res), obs_length=cfg.obs_length,
+                                obs_width=cfg.obs_width, verbose=False)
+            port_ok = bool(out["dp_feasible"]) and out.get("qp_status", "optimal") == "optimal" and out["smooth_status"] == "optimal"
+        except IndexError:
+            port_ok = False
+        assert port_ok == (status[b] == 0), f"scene {b}: port ok {port_ok}, device status {status[b]}"
+        if not port_ok:
+            continue
+        want = np.asarray(out["trajectory"], dtype=np.float64)
+        assert tl[b] == len(want)
+        assert_rel(traj[b, :tl[b], :2], want[:, :2], RTOL, 1.0, "trajectory xy")
+        assert_rel(traj[b, :tl[b], 2], want[:, 2], RTOL, 1.0, "trajectory theta")
+        checked += 1
+    assert checked >= 2
