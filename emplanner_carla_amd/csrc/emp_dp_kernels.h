@@ -264,37 +264,46 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
 #pragma unroll
             for (int k = 0; k < ROW; ++k) dst[k] = src[k * 64];
         };
+        // The predecessor of column j is extracted one column late: its 2 * ROW compare / select instructions
+        // would otherwise sit, in program order, between the new cost and the next column's LDS exchange.  Issued
+        // after the next column's front reads they fill that round trip instead.
+        double held[ROW], held_best = INF;     // candidates of the previous column and their minimum
+        int held_j = 0;                        // 0: nothing pending
+#pragma unroll
+        for (int k = 0; k < ROW; ++k) held[k] = INF;
+        auto settle = [&]() {
+            // the LOWEST k that attains the minimum: what the reference's strict '<' with k ascending keeps (:344).
+            // ref :301/:304: cost starts at +inf and the predecessor at 1; NaN / +inf candidates leave it there.
+            int arg = ROW - 1;
+#pragma unroll
+            for (int k = ROW - 2; k >= 0; --k) arg = (held[k] == held_best) ? k : arg;
+            if (held_j > 0) pre[held_j * 64 + lane] = (unsigned char)((held_best < INF) ? arg : 1);
+        };
         auto relax_col = [&](const double (&e)[ROW], int j) {
             publish();
-            // all `row` front values first (one LDS round trip), then the candidates, then a lexicographic
-            // (cost, k) tournament: strict '<' with k ascending == lowest k wins ties
             double cand[ROW];
 #pragma unroll
-            for (int k = 0; k < ROW; ++k) cand[k] = front[base + k];
+            for (int k = 0; k < ROW; ++k) cand[k] = front[base + k];      // one LDS round trip for the whole front
+            settle();                                                       // previous column's predecessor
 #pragma unroll
-            for (int k = 0; k < ROW; ++k) {
-                // ref :340, :342.  `pen` is 0.0 off the penalty rows: x + 0.0 == x bit for bit.  The reference's
-                // `<` never accepts a NaN candidate; fmin(NaN, inf) = inf makes it lose every comparison below.
-                cand[k] = __builtin_fmin((cand[k] + e[k]) + pen, INF);
-            }
-            int idx[ROW];
+            for (int k = 0; k < ROW; ++k) cand[k] = (cand[k] + e[k]) + pen;   // ref :340, :342; pen is 0.0 off the
+                                                                            // penalty rows: x + 0.0 == x bit for bit
+            // The new cost is the plain minimum: a v_min_f64 tree, the only thing the next column waits for.
+            // fmin (IEEE minNum) skips NaN operands, like the reference's `<`, which never accepts a NaN candidate;
+            // the last fmin against +inf covers the all-NaN case (the reference's cost then stays +inf).
+            double tree[ROW];
 #pragma unroll
-            for (int k = 0; k < ROW; ++k) idx[k] = k;
+            for (int k = 0; k < ROW; ++k) tree[k] = cand[k];
 #pragma unroll
             for (int span = 1; span < ROW; span <<= 1) {
 #pragma unroll
-                for (int k = 0; k + span < ROW; k += 2 * span) {
-                    // the right operand has the larger k: it wins only when strictly smaller
-                    const bool take = cand[k + span] < cand[k];
-                    cand[k] = take ? cand[k + span] : cand[k];
-                    idx[k] = take ? idx[k + span] : idx[k];
-                }
+                for (int k = 0; k + span < ROW; k += 2 * span) tree[k] = __builtin_fmin(tree[k], tree[k + span]);
             }
-            // ref :301/:304/:344: cost starts at +inf and the predecessor at 1; a candidate replaces them only if
-            // it is < inf (NaN and +inf candidates leave predecessor 1 in place)
-            const bool any = cand[0] < INF;
-            cost = any ? cand[0] : INF;
-            pre[j * 64 + lane] = (unsigned char)(any ? idx[0] : 1);
+            cost = __builtin_fmin(tree[0], INF);
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) held[k] = cand[k];
+            held_best = cost;
+            held_j = j;
         };
 #pragma unroll
         for (int d = 0; d < PD; ++d) load_col(ring[d], 1 + d);
@@ -305,6 +314,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
                 load_col(ring[d], j0 + d + PD);
             }
         }
+        settle();                                                           // the last column's predecessor
     } else {
         for (int j = 1; j < P.col; ++j) {
             double best = INF;
