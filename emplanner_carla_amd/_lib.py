@@ -49,6 +49,11 @@ class SmoothParams(C.Structure):
                 ("x_thre", C.c_double), ("y_thre", C.c_double)]
 
 
+class MpcParams(C.Structure):
+    _fields_ = [("a", C.c_double), ("b", C.c_double), ("Cf", C.c_double), ("Cr", C.c_double), ("m", C.c_double),
+                ("Iz", C.c_double), ("q_diag", C.c_double * 4), ("f_diag", C.c_double * 4), ("r", C.c_double)]
+
+
 class SpeedDpParams(C.Structure):
     _fields_ = [("reference_speed", C.c_double), ("w_cost_ref_speed", C.c_double), ("w_cost_accel", C.c_double),
                 ("w_cost_obs", C.c_double)]
@@ -110,6 +115,8 @@ PROTOTYPES = {
     "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
     "emp_reference_line": (C.c_int, [_vp, C.POINTER(SmoothParams), _i32, _i32] + [_vp] * 10 + [C.c_int]),
+    "emp_mpc_params_default": (None, [C.POINTER(MpcParams)]),
+    "emp_mpc_lateral": (C.c_int, [_vp, C.POINTER(MpcParams), _i32, _i32] + [_vp] * 15 + [C.c_int]),
     "emp_speed_dp_params_default": (None, [C.POINTER(SpeedDpParams)]),
     "emp_st_graph": (C.c_int, [_vp, _i32, _i32] + [_vp] * 8 + [C.c_int]),
     "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from ._lib import DpParams, QpParams, SmoothParams, SpeedDpParams, EmpError
+from ._lib import DpParams, QpParams, SmoothParams, SpeedDpParams, MpcParams, EmpError
 
 
 def dp_params(row=12, col=6, sample_s=15, sample_l=1.5, sampling_res=2, w_collision_cost=1e12,
@@ -51,6 +51,33 @@ def smooth_params(w_cost_smooth=0.4, w_cost_length=0.3, w_cost_ref=0.3, x_thre=0
     s.w_smooth, s.w_length, s.w_ref = float(w_cost_smooth), float(w_cost_length), float(w_cost_ref)
     s.x_thre, s.y_thre = float(x_thre), float(y_thre)
     return s
+
+
+def mpc_params(vehicle_para=(1.015, 2.910 - 1.015, 1412, -148970, -82204, 1537), q_diag=(250.0, 1.0, 50.0, 1.0),
+               f_diag=(1.0, 1.0, 1.0, 1.0), r=1.0) -> MpcParams:
+    """vehicle_para is unpacked exactly as the reference does, ``(a, b, Cf, Cr, m, Iz) = vehicle_para``
+    (controller.py:132); the default is the tuple the reference's drivers pass (test_9.py:316).  q_diag / f_diag / r
+    are the Q, F, R of Lateral_MPC_controller._control (controller.py:321-328)."""
+    p = MpcParams()
+    p.a, p.b, p.Cf, p.Cr, p.m, p.Iz = (float(v) for v in vehicle_para)
+    for i in range(4):
+        p.q_diag[i], p.f_diag[i] = float(q_diag[i]), float(f_diag[i])
+    p.r = float(r)
+    return p
+
+
+@dataclass
+class MpcResult:
+    steer: object        # (B,) first control of the horizon (the reference's res['x'][0])
+    u: object            # (B, 12)
+    e_rr: object         # (B, 4) e_d, e_d_dot, e_fi, e_fi_dot
+    k_r: object          # (B,)
+    min_index: object    # (B,) int32 match index (next call's min_index)
+    pre_pro: object      # (B, 4) predicted x, y and projected x, y
+    H: object            # (B, 12, 12) or None
+    f: object            # (B, 12) or None
+    iters: object
+    status: object
 
 
 def speed_dp_params(reference_speed=50, w_cost_ref_speed=4000, w_cost_accel=100, w_cost_obs=10000000) -> SpeedDpParams:
@@ -440,6 +467,28 @@ class Planner:
             a.inp(pred_xy, np.float64, (B, 2)), first, a.inp(pre_match_index, np.int32, (B,)), refp, nrp, mip, itp, stp,
             a.where))
         return ref, nr, mi, it, st
+
+    # ---- lateral MPC controller (reference controller/controller.py:65-337) -----------------------
+    def mpc_lateral(self, p: MpcParams, target_path, n_path, state, vx, min_index, qp_matrices=False) -> MpcResult:
+        """ref Lateral_MPC_controller._control for B vehicles: target_path (B,M,4), state (B,5) = x, y, fi, Vy, fi_dot,
+        vx (B,), min_index (B,)."""
+        a = self._args(target_path, state)
+        B, M = int(target_path.shape[0]), int(target_path.shape[1])
+        steer, sp_ = a.out((B,), np.float64)
+        u, up = a.out((B, 12), np.float64)
+        e, ep = a.out((B, 4), np.float64)
+        k, kp = a.out((B,), np.float64)
+        mi, mip = a.out((B,), np.int32)
+        pp, ppp = a.out((B, 4), np.float64)
+        H, Hp = a.out((B, 12, 12), np.float64) if qp_matrices else (None, None)
+        f, fp = a.out((B, 12), np.float64) if qp_matrices else (None, None)
+        it, itp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_mpc_lateral(
+            self._h, C.byref(p), B, M, a.inp(target_path, np.float64, (B, M, 4)), a.inp(n_path, np.int32, (B,)),
+            a.inp(state, np.float64, (B, 5)), a.inp(vx, np.float64, (B,)), a.inp(min_index, np.int32, (B,)), sp_, up, ep, kp,
+            mip, ppp, Hp, fp, itp, stp, a.where))
+        return MpcResult(steer, u, e, k, mi, pp, H, f, it, st)
 
     # ---- S-T speed DP (reference planner/speed_planning_test.py) ------------------------------
     def st_graph(self, obs_s, obs_l, obs_s_dot, obs_l_dot):

@@ -7,6 +7,7 @@
 #include "emp_dp_kernels.h"
 #include "emp_st_kernels.h"
 #include "emp_tail_kernels.h"
+#include "emp_mpc_kernels.h"
 
 namespace emp {
 thread_local std::string g_create_error;
@@ -1243,6 +1244,76 @@ int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const doub
         EMP_LAUNCH_CHECK(ctx);
     }
     return stg.finish();
+}
+
+}  // extern "C"
+
+// ---- lateral MPC controller (reference controller/controller.py:65-337) -------------------------
+extern "C" {
+
+void emp_mpc_params_default(emp_mpc_params* p) {
+    if (!p) return;
+    // the driver's tuple (1.015, 2.910 - 1.015, 1412, -148970, -82204, 1537) (ref test_9.py:316) as the controller
+    // unpacks it: (a, b, Cf, Cr, m, Iz) = vehicle_para (ref controller.py:132)
+    p->a = 1.015;
+    p->b = 2.910 - 1.015;
+    p->Cf = 1412.0;
+    p->Cr = -148970.0;
+    p->m = -82204.0;
+    p->Iz = 1537.0;
+    const double q[4] = {250.0, 1.0, 50.0, 1.0};
+    for (int i = 0; i < 4; ++i) {
+        p->q_diag[i] = q[i];
+        p->f_diag[i] = 1.0;
+    }
+    p->r = 1.0;
+}
+
+int emp_mpc_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t max_path, const double* target_path,
+                    const int32_t* n_path, const double* state, const double* vx, const int32_t* min_index,
+                    double* steer, double* u, double* e_rr, double* k_r, int32_t* min_index_out, double* pre_pro,
+                    double* H, double* f, int32_t* iters, int32_t* status, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p && B >= 0 && max_path >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, target_path && n_path && state && vx && min_index && steer && min_index_out && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_path, *d_state, *d_vx;
+    const int *d_np, *d_mi;
+    double *d_steer, *d_u = nullptr, *d_e = nullptr, *d_k = nullptr, *d_pp = nullptr, *d_H = nullptr, *d_f = nullptr;
+    int *d_mo, *d_it = nullptr, *d_st;
+    if ((rc = st.in(target_path, (size_t)B * max_path * 4, &d_path))) return rc;
+    if ((rc = st.in(n_path, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(state, (size_t)B * 5, &d_state))) return rc;
+    if ((rc = st.in(vx, (size_t)B, &d_vx))) return rc;
+    if ((rc = st.in(min_index, (size_t)B, &d_mi))) return rc;
+    if ((rc = st.out(steer, (size_t)B, &d_steer, false))) return rc;
+    if (u && (rc = st.out(u, (size_t)B * mpc::kNu, &d_u, false))) return rc;
+    if (e_rr && (rc = st.out(e_rr, (size_t)B * 4, &d_e, false))) return rc;
+    if (k_r && (rc = st.out(k_r, (size_t)B, &d_k, false))) return rc;
+    if ((rc = st.out(min_index_out, (size_t)B, &d_mo, false))) return rc;
+    if (pre_pro && (rc = st.out(pre_pro, (size_t)B * 4, &d_pp, false))) return rc;
+    if (H && (rc = st.out(H, (size_t)B * mpc::kNu * mpc::kNu, &d_H, false))) return rc;
+    if (f && (rc = st.out(f, (size_t)B * mpc::kNu, &d_f, false))) return rc;
+    if (iters && (rc = st.out(iters, (size_t)B, &d_it, false))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        mpc::Params prm;
+        prm.a = p->a; prm.b = p->b; prm.Cf = p->Cf; prm.Cr = p->Cr; prm.m = p->m; prm.Iz = p->Iz;
+        for (int i = 0; i < 4; ++i) {
+            prm.q[i] = p->q_diag[i];
+            prm.f[i] = p->f_diag[i];
+        }
+        prm.r = p->r;
+        KernelTimer t(ctx, "mpc_lateral");
+        hipLaunchKernelGGL(mpc::mpc_lateral_kernel, dim3((B + mpc::kGroupsPerWave - 1) / mpc::kGroupsPerWave), dim3(64), 0,
+                           ctx->stream, B, max_path, prm, d_path, d_np, d_state, d_vx, d_mi, d_steer, d_u, d_e, d_k, d_mo, d_pp,
+                           d_H, d_f, d_it, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
 }
 
 }  // extern "C"

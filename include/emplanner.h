@@ -309,6 +309,28 @@ int emp_reference_line(emp_ctx* ctx, const emp_smooth_params* sp, int32_t B, int
                        const int32_t* is_first_run, const int32_t* pre_match_index, double* ref_line, int32_t* n_ref,
                        int32_t* match_index, int32_t* iters, int32_t* status, emp_mem where);
 
+/* ---- lateral MPC controller ------------------------------------
+ * ref: controller/controller.py class Lateral_MPC_controller (:65-337), `_control` from explicit inputs: the reference
+ * reads the vehicle state from a live carla.Vehicle (cal_vehicle_info, :90-113); here the caller supplies
+ * state [B][5] = x, y, yaw fi (rad), lateral velocity Vy, yaw rate fi_dot (rad/s) and vx [B] (the caller applies the
+ * reference's |Vx| >= 0.005 clamp, :107-110).  target_path [B][max_path][4] = x, y, theta, kappa is the planner's
+ * trajectory; min_index [B] the previous match (the search window is 50 points from it, :204).
+ * Chain: cal_A_B_C_fun (:115-148) -> cal_error_k_fun(ts = 0.1) (:170-251) -> cal_coefficient_of_discretion_fun (:151-168)
+ * -> cal_control_para_fun (:253-311): condensed MPC with N = 6 steps x P = 2 controls, box |u| <= 1.
+ * steer [B] = first control (res['x'][0]); optional outputs (NULL to skip): u [B][12], e_rr [B][4], k_r [B],
+ * pre_pro [B][4] = predicted x, y and projected x, y, H [B][12][12] and f [B][12] of the QP, iters [B].
+ * status: EMP_ST_S_OUT_OF_RANGE for a bad min_index / empty path (IndexError in the reference), EMP_ST_QP_FAILED. */
+typedef struct emp_mpc_params {
+    double a, b, Cf, Cr, m, Iz;            /* (a, b, Cf, Cr, m, Iz) = vehicle_para (controller.py:132); the drivers pass
+                                            * (1.015, 1.895, 1412, -148970, -82204, 1537) (test_9.py:316) in THIS order */
+    double q_diag[4], f_diag[4], r;        /* controller.py:321-328: (250, 1, 50, 1), (1, 1, 1, 1), 1 */
+} emp_mpc_params;
+void emp_mpc_params_default(emp_mpc_params* p);
+int emp_mpc_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t max_path, const double* target_path,
+                    const int32_t* n_path, const double* state, const double* vx, const int32_t* min_index,
+                    double* steer, double* u, double* e_rr, double* k_r, int32_t* min_index_out, double* pre_pro,
+                    double* H, double* f, int32_t* iters, int32_t* status, emp_mem where);
+
 /* ---- S-T speed DP (BASELINE config 5; reference planner/speed_planning_test.py) ----------------
  * The S-T grid is hard-coded in the reference (40 non-uniform s samples :114, 16 t samples :116); tables are
  * [B][EMP_ST_ROWS][EMP_ST_COLS], row 0 = largest s (CalcSTCoordinate, :287-305).  Obstacle slots hold NaN when

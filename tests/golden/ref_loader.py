@@ -129,3 +129,22 @@ def load_speed_reference():
         sys.path.remove(REFERENCE_ROOT)
         sys.modules.pop("planner", None)
     return sp
+
+
+def load_controller_reference():
+    """Return the reference's ``controller.controller`` module (lateral MPC / LQR, longitudinal PID).  It imports
+    ``carla`` and ``cvxopt`` (both stubbed above) and ``planner.planning_utils`` (the reference's own)."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        for name in ("planner", "planner.planning_utils", "controller", "controller.controller"):
+            sys.modules.pop(name, None)
+        mod = importlib.import_module("controller.controller")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for name in ("planner", "planner.planning_utils", "controller"):
+            sys.modules.pop(name, None)
+    return mod

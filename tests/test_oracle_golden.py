@@ -366,3 +366,32 @@ def test_st_port_sweep_matches_reference_tables():
         np.testing.assert_array_equal(res["cost"], cost)
         np.testing.assert_array_equal(res["s_dot"], s_dot)
         np.testing.assert_array_equal(res["node"], node)
+
+
+# --------------------------------------------------------------------------------------
+# lateral MPC controller (reference controller/controller.py:65-337) - oracle/mpc_lateral.py vs the reference class
+# --------------------------------------------------------------------------------------
+def test_mpc_port_matches_reference_class():
+    from oracle import mpc_lateral as mpc
+    g = load_golden("mpc.npz")
+    para = tuple(g["vehicle_para"])
+    for c in range(len(g["n"])):
+        n = int(g["n"][c])
+        path = [tuple(r) for r in g["path"][c, :n]]
+        out = mpc.lateral_mpc(path, tuple(g["state"][c]), float(g["Vx"][c]), int(g["min_index_in"][c]), para)
+        np.testing.assert_array_equal(out["A"], g["A"][c])
+        np.testing.assert_array_equal(out["B"], g["B"][c])
+        np.testing.assert_array_equal(out["C"], g["C"][c])
+        assert out["min_index"] == g["min_index_out"][c] and out["k_r"] == g["k_r"][c]
+        np.testing.assert_array_equal(out["e_rr"], g["e_rr"][c])
+        np.testing.assert_array_equal(np.array(out["pre"]), g["pre"][c])
+        np.testing.assert_array_equal(np.array(out["pro"]), g["pro"][c])
+        np.testing.assert_array_equal(out["A_bar"], g["A_bar"][c])
+        np.testing.assert_array_equal(out["H"], g["H"][c])
+        np.testing.assert_array_equal(out["f"].reshape(-1), g["f"][c])
+        assert out["qp"].status == "optimal"
+        assert_rel(out["u"], g["u"][c], 1e-9, scale=1.0)
+        assert abs(out["steering"] - g["steer"][c]) < 1e-9
+        # the recorded constraint set is the +-1 box (controller.py:300-304)
+        np.testing.assert_array_equal(g["G"][c], np.concatenate((np.identity(12), -np.identity(12))))
+        np.testing.assert_array_equal(g["h"][c], np.ones(24))
