@@ -1086,6 +1086,125 @@ __device__ inline int box_qp_setup_group(BoxRangeQp& Q, const double* ref, int s
 }
 
 // ---------------------------------------------------------------------------------------------
+// One smoothing (box) QP of m <= G points per GROUP of G lanes, one point per lane, registers only.  G = 32: the x
+// problem of a polyline on lanes 0-31 and its y problem on lanes 32-63.  The box QP has G = I (W = 1, F = 1,
+// off0 = 0): a station IS its unknown, so nothing is exchanged through LDS - neighbours for P u and for the
+// Cholesky / substitution sweeps come from lane shifts (a shift that crosses into the other group meets a band
+// entry that is exactly 0), norms and ratio tests from the group reductions.  Same algorithm, stopping rule and
+// constants as range_qp_solve_wave_fast with BoxRangeQp (emp_qp_core.h: box_qp_forms / box_qp_setup).
+// r: this lane's reference coordinate (lanes >= m of the group: anything).  Returns 0 ok / 2 failed per group.
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__device__ inline int box_qp_lanes(double r, int m, const SmoothQpParams& prm, double* out_u, int* iters_out) {
+    constexpr int KD = 2;
+    const int gl = (threadIdx.x & 63) & (G - 1);
+    const bool has = gl < m;
+    *iters_out = 0;
+    *out_u = r;
+    if (m < 2 || !(prm.thr > 0.0)) return 2;
+    const double eps_p = 1e-10, eps_mu = 1e-13, eps_d_rel = 1e-10;   // box_qp_forms
+    double Prow[KD + 1], Plow[KD + 1];
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) {                      // ref planning_utils.py:262-361 cost matrices, as box_qp_setup_group
+        double e = 0.0;
+        if (has && gl + d < m) {
+            for (int rr = max(0, gl + d - 2); rr <= min(m - 3, gl); ++rr) {
+                const double a = (gl - rr == 1) ? -2.0 : 1.0, b = (gl + d - rr == 1) ? -2.0 : 1.0;
+                e += 2.0 * prm.w_smooth * a * b;
+            }
+            for (int rr = max(0, gl + d - 1); rr <= min(m - 2, gl); ++rr) {
+                const double a = (gl - rr == 0) ? 1.0 : -1.0, b = (gl + d - rr == 0) ? 1.0 : -1.0;
+                e += 2.0 * prm.w_length * a * b;
+            }
+            if (d == 0) e += 2.0 * prm.w_ref;
+        }
+        Prow[d] = e;
+    }
+    {
+        const double t1 = lane_up1(Prow[1]), t2 = lane_up1(lane_up1(Prow[2]));
+        Plow[0] = 0.0;
+        Plow[1] = (gl >= 1) ? t1 : 0.0;                  // P[gl-1][gl]
+        Plow[2] = (gl >= 2) ? t2 : 0.0;                  // P[gl-2][gl]
+    }
+    const double q = has ? -2.0 * prm.w_ref * r : 0.0;   // ref :346
+    const double lo = has ? r - prm.thr : -1e300;        // ref :308-311
+    const double hi = has ? r + prm.thr : 1e300;
+    double u = has ? r : 0.0, zu = 1.0, zl = 1.0;
+    double su = hi - u, sl = u - lo;
+    {
+        const double smin = group_min<G>(has ? fmin(su, sl) : 1e300);
+        const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;
+        su += shift;
+        sl += shift;
+    }
+    const double qscale = fmax(group_max<G>(has ? fabs(q) : 0.0), 1.0);
+    const int rows = m * 2;
+    int state = 1, iters = 0;
+    bool acceptable = false;
+    while (__any(state == 1)) {
+        const double rpu = u - hi + su, rpl = lo - u + sl;
+        const double isu = fast_rcp(su), isl = fast_rcp(sl), izu = fast_rcp(zu), izl = fast_rcp(zl);
+        const double wu = zu * isu, wl = zl * isl;
+        const double u1 = lane_dn1(u), u2 = lane_dn1(u1), d1 = lane_up1(u), d2 = lane_up1(d1);
+        double acc = q + Prow[0] * u;
+        acc += Prow[1] * u1 + Prow[2] * u2 + Plow[1] * d1 + Plow[2] * d2;
+        const double rd = has ? acc + (zu - zl) : 0.0;
+        const double rd_max = group_max<G>(fabs(rd));
+        const double rp_max = group_max<G>(has ? fmax(fabs(rpu), fabs(rpl)) : 0.0);
+        const double zmax = group_max<G>(has ? fmax(zu, zl) : 0.0);
+        const double mu = group_sum<G>(has ? su * zu + sl * zl : 0.0) / (double)rows;
+        if (state == 1) {
+            const double dscale = fmax(qscale, zmax);
+            if (rd_max <= eps_d_rel * dscale && rp_max <= eps_p && mu <= eps_mu) state = 0;
+            else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
+            else if (iters >= kQpMaxIter) state = acceptable ? 0 : 2;
+            if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu <= 1000.0 * eps_mu) acceptable = true;
+        }
+        const bool go = state == 1;
+        double fa[KD + 1], flow[KD + 1], frinv = 1.0;
+        fa[0] = (go && has) ? Prow[0] + (wu + wl) : 0.0;
+        fa[1] = go ? Prow[1] : 0.0;
+        fa[2] = go ? Prow[2] : 0.0;
+        const bool okf = band_chol_group<G, KD>(fa, frinv, flow, m, gl, go);
+        if (go && !okf) state = acceptable ? 0 : 2;
+        const bool go2 = state == 1;
+        double dua = (go2 && has) ? -rd - ((wu * rpu - zu) - (wl * rpl - zl)) : 0.0;
+        band_solve_group<G, KD>(fa, frinv, flow, dua, m, gl);
+        const double dsua = -rpu - dua, dsla = -rpl + dua;
+        const double dzua = -zu - wu * dsua, dzla = -zl - wl * dsla;
+        double ratio = (go2 && has) ? fmax(fmax(-dsua * isu, -dsla * isl), fmax(-dzua * izu, -dzla * izl)) : 0.0;
+        ratio = group_max<G>(ratio);
+        const double a_aff = (ratio > 1.0) ? fast_rcp(ratio) : 1.0;
+        double mu_aff = (go2 && has) ? (su + a_aff * dsua) * (zu + a_aff * dzua) + (sl + a_aff * dsla) * (zl + a_aff * dzla) : 0.0;
+        mu_aff = group_sum<G>(mu_aff) / (double)rows;
+        double sigma = (mu > 0.0) ? mu_aff * fast_rcp(mu) : 0.0;
+        sigma = sigma * sigma * sigma;
+        const double rcu = su * zu + dsua * dzua - sigma * mu, rcl = sl * zl + dsla * dzla - sigma * mu;
+        double du = (go2 && has) ? -rd - ((zu * rpu - rcu) * isu - (zl * rpl - rcl) * isl) : 0.0;
+        band_solve_group<G, KD>(fa, frinv, flow, du, m, gl);
+        const double dsu = -rpu - du, dsl = -rpl + du;
+        const double dzu = -(rcu + zu * dsu) * isu, dzl = -(rcl + zl * dsl) * isl;
+        ratio = (go2 && has) ? fmax(fmax(-dsu * isu, -dsl * isl), fmax(-dzu * izu, -dzl * izl)) : 0.0;
+        ratio = group_max<G>(ratio);
+        const double tau = qp_step_fraction(mu);
+        const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
+        if (go2) {
+            if (has) {
+                su += alpha * dsu;
+                sl += alpha * dsl;
+                zu += alpha * dzu;
+                zl += alpha * dzl;
+                u += alpha * du;
+            }
+            ++iters;
+        }
+    }
+    *iters_out = iters;
+    *out_u = u;
+    return state;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Smoothing QPs of one polyline of m <= 64 points on one wavefront, one POINT per lane; the x and the y
 // problem (same structure, independent data) run side by side in the same lanes so that their two serial
 // chains interleave.  The box QP has G = I (W = 1, F = 1, off0 = 0): a station IS its unknown, so the whole
@@ -1308,6 +1427,21 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
         *out_x = lds;
         *out_y = lds + m;
         return rc;
+    }
+#endif
+#ifndef EMP_SMOOTH_FORCE_LDS
+    if (m <= 32) {                                      // x on lanes 0-31, y on lanes 32-63, registers only
+        const double r = gl < m ? xy[(size_t)gl * stride + grp] : 0.0;
+        double uu = 0.0;
+        int it_mine = 0;
+        const int rc = box_qp_lanes<32>(r, m, grp ? sy : sx, &uu, &it_mine);
+        __syncthreads();
+        if (gl < m) lds[grp * m + gl] = uu;
+        __syncthreads();
+        *iters_out = max(__shfl(it_mine, 0, 64), __shfl(it_mine, 32, 64));
+        *out_x = lds;
+        *out_y = lds + m;
+        return __any(rc != 0) ? 2 : 0;
     }
 #endif
     BoxRangeQp Q;
