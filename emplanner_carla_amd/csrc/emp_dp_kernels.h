@@ -12,7 +12,7 @@
 //   dp_edge_kernel     edge costs (ref: cal_start_cost / cal_neighbor_cost, path_planning.py:435-585),
 //                      FP64 VALU bound; writes the tiled (or canonical) tensor, 8 B per lane coalesced.
 //   dp_sweep_kernel    min-plus sweep + argmin + backtrack (ref: path_planning.py:301-361), HBM bound:
-//                      streams the tiled tensor once with a register double buffer of PD columns.
+//                      streams the tiled tensor once through a register ring of PD prefetched columns.
 //   dp_enrich_wave_kernel   row indices -> densified (s, l) path (ref: path_planning.py:364-432).
 #pragma once
 

@@ -1,14 +1,19 @@
-// emp_qp_wave.h - wave-cooperative solver for the banded range QP of emp_qp_core.h (device only).
+// emp_qp_wave.h - wave-cooperative solvers for the banded range QP of emp_qp_core.h (device only).
 //
-// One problem per GROUP of G lanes (G = 64: one problem per wavefront; G = 32: two problems side by side,
-// e.g. the x and y smoothing problems of one scene).  All problem arrays live in LDS.  The O(n) parts of an
-// interior-point iteration (residuals, normal-matrix assembly, ratio tests, updates) run one station /
-// unknown per lane with butterfly reductions; only the banded Cholesky and the two triangular solves are a
-// serial recurrence, run by lane 0 of the group out of LDS.  The block must consist of exactly one
-// wavefront so that __syncthreads() is a cheap wave-level LDS fence.
+// One problem per GROUP of G lanes (G = 64: one problem per wavefront; G = 32: two problems side by side - two
+// scenes of the path QP, or the x and y smoothing problems of one polyline).  Three tiers, same algorithm
+// (Mehrotra predictor-corrector on the reduced normal equations) and stopping rule as RangeQp::solve_scalar:
+//   * range_qp_solve_wave_fast - one station and one unknown per lane (N, ns <= G): per-station and per-unknown
+//     state, the normal matrix and its factor in registers; vectors that lanes of different roles exchange go
+//     through LDS.  The path QP of the cycle runs here.
+//   * box_qp_lanes / smooth_pair_lanes - the smoothing QP (G = I): registers only.
+//   * range_qp_solve_wave - any size: arrays in LDS, serial factorisation by lane 0 of the group.
+// The banded Cholesky and the substitutions of the first two tiers are lane-shift sweeps (band_chol_group /
+// band_solve_group); norms and ratio tests are group reductions without LDS traffic (group_reduce).
+// Blocks must consist of exactly one wavefront so that __syncthreads() is a cheap wave-level LDS fence.
 //
-// Same algorithm and stopping rule as RangeQp::solve_scalar (emp_qp_core.h); different summation order, so
-// results agree to round-off, not bitwise (QP outputs are compared at 1e-6).
+// Different summation order than the scalar solver, so results agree to round-off, not bitwise (QP outputs are
+// compared at 1e-6).
 #pragma once
 
 #include <hip/hip_runtime.h>

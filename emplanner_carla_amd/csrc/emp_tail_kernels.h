@@ -1,9 +1,9 @@
 // emp_tail_kernels.h - everything of one planning cycle around the DP: Cartesian->Frenet projection,
 // QP bounds, path QP, midpoint re-interleave, Frenet->Cartesian, smoothing QP, heading/curvature.
 //
-// Mapping: one scene per lane (the per-scene work is a chain of short sequential recurrences: banded
-// Cholesky, monotone index walks, ordered scans with early exits).  State lives in private arrays.
-// "ref:" cites the reference (paths relative to the reference tree).
+// Mapping: the kernels of emp_plan_cycle run one scene per wavefront (or per half wavefront) with the reference
+// line, the path and the QP state in LDS / registers; the stand-alone per-function kernels of the utilities keep
+// the simple one-scene-per-lane form.  "ref:" cites the reference (paths relative to the reference tree).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,45 +29,6 @@ struct QpDev {
 // ---------------------------------------------------------------------------------------------
 // ref: test_9.py:113-177 - s_map, obstacle (s, l), planning-start (s, l) and (l, dl/ds, d2l/ds2)
 // ---------------------------------------------------------------------------------------------
-__global__ void frenet_project_kernel(int B, int max_ref, int max_obs, const double* __restrict__ ref_line,
-                                      const int* __restrict__ n_ref, const double* __restrict__ origin_xy,
-                                      const double* __restrict__ start_xy, const double* __restrict__ start_v,
-                                      const double* __restrict__ start_a, const double* __restrict__ obs_xy,
-                                      const int* __restrict__ n_obs, double* __restrict__ s_map,
-                                      double* __restrict__ obs_s, double* __restrict__ obs_l,
-                                      double* __restrict__ begin_sl, double* __restrict__ start) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double* line = ref_line + (size_t)b * max_ref * 4;
-    const int P = n_ref[b];
-    double* sm = s_map + (size_t)b * max_ref;
-    s_map_build(line, P, origin_xy[2 * b], origin_xy[2 * b + 1], sm);            // ref :113
-    // obstacles (ref :122): s from each point's own match, l from the projection on the FIRST point's match
-    const int k = n_obs ? n_obs[b] : 0;
-    int m_first = 0;
-    for (int j = 0; j < k; ++j) {
-        const double x = obs_xy[((size_t)b * max_obs + j) * 2], y = obs_xy[((size_t)b * max_obs + j) * 2 + 1];
-        const int m = match_scan(line, P, x, y, 0, 1, 50);
-        if (j == 0) m_first = m;
-        obs_s[(size_t)b * max_obs + j] = projection_s(node_at(line, m), sm[m], x, y);
-        obs_l[(size_t)b * max_obs + j] = lateral_offset(project_on(node_at(line, m_first), x, y), x, y);
-    }
-    // planning start (ref :134 and :172-177; single-point lists, so "first match" is its own)
-    const double px = start_xy[2 * b], py = start_xy[2 * b + 1];
-    const int m = match_scan(line, P, px, py, 0, 1, 50);
-    const Node proj = project_on(node_at(line, m), px, py);
-    const double bs = projection_s(node_at(line, m), sm[m], px, py);
-    if (begin_sl) {
-        begin_sl[2 * b] = bs;
-        begin_sl[2 * b + 1] = lateral_offset(proj, px, py);
-    }
-    const FrenetState fs = frenet_state(proj, px, py, start_v[2 * b], start_v[2 * b + 1], start_a[2 * b], start_a[2 * b + 1]);
-    start[4 * b + 0] = bs;
-    start[4 * b + 1] = fs.l;
-    start[4 * b + 2] = fs.dl_ds;
-    start[4 * b + 3] = fs.ddl_ds;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Wave-parallel form of the cycle front (one wavefront per scene, one reference-line node per lane).
 // The reference's nearest-node scan (planning_utils.py:383-402) is an ordered scan with an early exit after
