@@ -117,6 +117,8 @@ PROTOTYPES = {
     "emp_reference_line": (C.c_int, [_vp, C.POINTER(SmoothParams), _i32, _i32] + [_vp] * 10 + [C.c_int]),
     "emp_mpc_params_default": (None, [C.POINTER(MpcParams)]),
     "emp_mpc_lateral": (C.c_int, [_vp, C.POINTER(MpcParams), _i32, _i32] + [_vp] * 15 + [C.c_int]),
+    "emp_lqr_params_default": (None, [C.POINTER(MpcParams)]),
+    "emp_lqr_lateral": (C.c_int, [_vp, C.POINTER(MpcParams), _i32, _i32] + [_vp] * 13 + [C.c_int]),
     "emp_speed_dp_params_default": (None, [C.POINTER(SpeedDpParams)]),
     "emp_st_graph": (C.c_int, [_vp, _i32, _i32] + [_vp] * 8 + [C.c_int]),
     "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),

@@ -66,6 +66,24 @@ def mpc_params(vehicle_para=(1.015, 2.910 - 1.015, 1412, -148970, -82204, 1537),
     return p
 
 
+def lqr_params(vehicle_para=(1.015, 2.910 - 1.015, 1412, -148970, -82204, 1537), q_diag=(200.0, 1.0, 50.0, 1.0),
+               r=1.0) -> MpcParams:
+    """Parameters of Lateral_LQR_controller._control (controller.py:592-598); vehicle_para unpacked as in mpc_params."""
+    return mpc_params(vehicle_para=vehicle_para, q_diag=q_diag, r=r)
+
+
+@dataclass
+class LqrResult:
+    steer: object        # (B,) raw steering command -K e_rr + delta_f (not clipped, as in the reference)
+    K: object            # (B, 4)
+    e_rr: object         # (B, 4)
+    k_r: object          # (B,)
+    min_index: object    # (B,) int32
+    pre_pro: object      # (B, 4)
+    sweeps: object       # (B,) int32 Riccati sweeps performed
+    status: object
+
+
 @dataclass
 class MpcResult:
     steer: object        # (B,) first control of the horizon (the reference's res['x'][0])
@@ -489,6 +507,24 @@ class Planner:
             a.inp(state, np.float64, (B, 5)), a.inp(vx, np.float64, (B,)), a.inp(min_index, np.int32, (B,)), sp_, up, ep, kp,
             mip, ppp, Hp, fp, itp, stp, a.where))
         return MpcResult(steer, u, e, k, mi, pp, H, f, it, st)
+
+    def lqr_lateral(self, p: MpcParams, target_path, n_path, state, vx, min_index) -> LqrResult:
+        """ref Lateral_LQR_controller._control for B vehicles (same inputs as mpc_lateral)."""
+        a = self._args(target_path, state)
+        B, M = int(target_path.shape[0]), int(target_path.shape[1])
+        steer, sp_ = a.out((B,), np.float64)
+        K, Kp = a.out((B, 4), np.float64)
+        e, ep = a.out((B, 4), np.float64)
+        k, kp = a.out((B,), np.float64)
+        mi, mip = a.out((B,), np.int32)
+        pp, ppp = a.out((B, 4), np.float64)
+        sw, swp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_lqr_lateral(
+            self._h, C.byref(p), B, M, a.inp(target_path, np.float64, (B, M, 4)), a.inp(n_path, np.int32, (B,)),
+            a.inp(state, np.float64, (B, 5)), a.inp(vx, np.float64, (B,)), a.inp(min_index, np.int32, (B,)), sp_, Kp, ep, kp,
+            mip, ppp, swp, stp, a.where))
+        return LqrResult(steer, K, e, k, mi, pp, sw, st)
 
     # ---- S-T speed DP (reference planner/speed_planning_test.py) ------------------------------
     def st_graph(self, obs_s, obs_l, obs_s_dot, obs_l_dot):

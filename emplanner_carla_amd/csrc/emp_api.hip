@@ -1316,4 +1316,54 @@ int emp_mpc_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t ma
     return st.finish();
 }
 
+void emp_lqr_params_default(emp_mpc_params* p) {
+    if (!p) return;
+    emp_mpc_params_default(p);
+    p->q_diag[0] = 200.0;                                    // ref controller.py:593-597
+}
+
+int emp_lqr_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t max_path, const double* target_path,
+                    const int32_t* n_path, const double* state, const double* vx, const int32_t* min_index,
+                    double* steer, double* K, double* e_rr, double* k_r, int32_t* min_index_out, double* pre_pro,
+                    int32_t* sweeps, int32_t* status, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p && B >= 0 && max_path >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, target_path && n_path && state && vx && min_index && steer && min_index_out && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage st(ctx, where);
+    int rc;
+    const double *d_path, *d_state, *d_vx;
+    const int *d_np, *d_mi;
+    double *d_steer, *d_K = nullptr, *d_e = nullptr, *d_k = nullptr, *d_pp = nullptr;
+    int *d_mo, *d_sw = nullptr, *d_st;
+    if ((rc = st.in(target_path, (size_t)B * max_path * 4, &d_path))) return rc;
+    if ((rc = st.in(n_path, (size_t)B, &d_np))) return rc;
+    if ((rc = st.in(state, (size_t)B * 5, &d_state))) return rc;
+    if ((rc = st.in(vx, (size_t)B, &d_vx))) return rc;
+    if ((rc = st.in(min_index, (size_t)B, &d_mi))) return rc;
+    if ((rc = st.out(steer, (size_t)B, &d_steer, false))) return rc;
+    if (K && (rc = st.out(K, (size_t)B * 4, &d_K, false))) return rc;
+    if (e_rr && (rc = st.out(e_rr, (size_t)B * 4, &d_e, false))) return rc;
+    if (k_r && (rc = st.out(k_r, (size_t)B, &d_k, false))) return rc;
+    if ((rc = st.out(min_index_out, (size_t)B, &d_mo, false))) return rc;
+    if (pre_pro && (rc = st.out(pre_pro, (size_t)B * 4, &d_pp, false))) return rc;
+    if (sweeps && (rc = st.out(sweeps, (size_t)B, &d_sw, false))) return rc;
+    if ((rc = st.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        mpc::Params prm;
+        prm.a = p->a; prm.b = p->b; prm.Cf = p->Cf; prm.Cr = p->Cr; prm.m = p->m; prm.Iz = p->Iz;
+        for (int i = 0; i < 4; ++i) {
+            prm.q[i] = p->q_diag[i];
+            prm.f[i] = p->f_diag[i];
+        }
+        prm.r = p->r;
+        KernelTimer t(ctx, "lqr_lateral");
+        hipLaunchKernelGGL(lqr::lqr_lateral_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, max_path, prm, d_path, d_np,
+                           d_state, d_vx, d_mi, d_steer, d_K, d_e, d_k, d_mo, d_pp, d_sw, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
 }  // extern "C"

@@ -387,4 +387,182 @@ __global__ __launch_bounds__(64) void mpc_lateral_kernel(int B, int max_path, Pa
 }
 
 }  // namespace mpc
+
+// ---------------------------------------------------------------------------------------------
+// Lateral LQR controller, ref controller/controller.py class Lateral_LQR_controller (:374-611): `_control` from
+// explicit inputs.  One vehicle per lane: the 4 x 4 algebra lives in registers and the Riccati iteration
+// (:470-481: until max|dP| < 0.1, at most 5000 sweeps - a slowly creeping vehicle needs all of them) is a private
+// loop; lanes of a wavefront simply run as long as their slowest vehicle.  Products are associated as NumPy
+// evaluates the reference's expression (left to right).
+// ---------------------------------------------------------------------------------------------
+namespace lqr {
+
+using mpc::M4;
+using mpc::V4;
+
+__device__ __forceinline__ M4 matmul(const M4& A, const M4& B) {
+    M4 C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            C.a[i][j] = ((A.a[i][0] * B.a[0][j] + A.a[i][1] * B.a[1][j]) + A.a[i][2] * B.a[2][j]) + A.a[i][3] * B.a[3][j];
+    return C;
+}
+
+__global__ void lqr_lateral_kernel(int B, int max_path, mpc::Params prm, const double* __restrict__ target_path,
+                                   const int* __restrict__ n_path, const double* __restrict__ state,
+                                   const double* __restrict__ vx, const int* __restrict__ min_index_in,
+                                   double* __restrict__ steer, double* __restrict__ K_out, double* __restrict__ e_rr_out,
+                                   double* __restrict__ k_r_out, int* __restrict__ min_index_out,
+                                   double* __restrict__ pre_pro, int* __restrict__ sweeps_out, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x = state[5 * b], y = state[5 * b + 1], fi = state[5 * b + 2];
+    const double Vy = state[5 * b + 3], fi_dot = state[5 * b + 4], Vx = vx[b];
+    // ---- continuous model (ref :424-455): Vx + 0.0001 guards the divisions
+    const double Vg = Vx + 0.0001;
+    M4 A;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) A.a[i][j] = 0.0;
+    A.a[0][1] = 1.0;
+    A.a[1][1] = (prm.Cf + prm.Cr) / (prm.m * Vg);
+    A.a[1][2] = -(prm.Cf + prm.Cr) / prm.m;
+    A.a[1][3] = (prm.a * prm.Cf - prm.b * prm.Cr) / (prm.m * Vg);
+    A.a[2][3] = 1.0;
+    A.a[3][1] = (prm.a * prm.Cf - prm.b * prm.Cr) / (prm.Iz * Vg);
+    A.a[3][2] = -(prm.a * prm.Cf - prm.b * prm.Cr) / prm.Iz;
+    A.a[3][3] = (prm.a * prm.a * prm.Cf + prm.b * prm.b * prm.Cr) / (prm.Iz * Vg);
+    const V4 Bc{{0.0, -prm.Cf / prm.m, 0.0, -prm.a * prm.Cf / prm.Iz}};
+    // ---- discretisation and Riccati iteration (ref :466-481)
+    M4 lhs, rhs, inv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double e = (i == j) ? 1.0 : 0.0;
+            lhs.a[i][j] = e - (mpc::kTs * A.a[i][j]) / 2.0;
+            rhs.a[i][j] = e + (mpc::kTs * A.a[i][j]) / 2.0;
+        }
+    const bool inv_ok = mpc::inverse4(lhs, &inv);
+    const M4 Ad = matmul(inv, rhs);
+    V4 Bd = mpc::matvec(inv, Bc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bd.v[i] = Bd.v[i] * mpc::kTs;
+    M4 AT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) AT.a[i][j] = Ad.a[j][i];
+    M4 P, Ppre;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P.a[i][j] = Ppre.a[i][j] = (i == j) ? prm.q[i] : 0.0;
+    int sweeps = 0;
+    for (int it = 0; it < 5000; ++it) {
+        const M4 ATP = matmul(AT, P);
+        const M4 ATPA = matmul(ATP, Ad);
+        const V4 ATPB = mpc::matvec(ATP, Bd);
+        V4 BTP;                                             // B' P (row vector)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) BTP.v[j] = ((Bd.v[0] * P.a[0][j] + Bd.v[1] * P.a[1][j]) + Bd.v[2] * P.a[2][j]) + Bd.v[3] * P.a[3][j];
+        V4 BTPA;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) BTPA.v[j] = ((BTP.v[0] * Ad.a[0][j] + BTP.v[1] * Ad.a[1][j]) + BTP.v[2] * Ad.a[2][j]) + BTP.v[3] * Ad.a[3][j];
+        const double BTPB = ((BTP.v[0] * Bd.v[0] + BTP.v[1] * Bd.v[1]) + BTP.v[2] * Bd.v[2]) + BTP.v[3] * Bd.v[3];
+        const double g = 1.0 / (prm.r + BTPB);
+        double delta = 0.0;
+        M4 Pn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Pn.a[i][j] = (ATPA.a[i][j] - (ATPB.v[i] * g) * BTPA.v[j]) + ((i == j) ? prm.q[i] : 0.0);
+                delta = fmax(delta, fabs(Pn.a[i][j] - Ppre.a[i][j]));
+            }
+        P = Pn;
+        sweeps = it + 1;
+        if (delta < 0.1) break;
+        Ppre = Pn;
+    }
+    V4 K;
+    {
+        V4 BTP;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) BTP.v[j] = ((Bd.v[0] * P.a[0][j] + Bd.v[1] * P.a[1][j]) + Bd.v[2] * P.a[2][j]) + Bd.v[3] * P.a[3][j];
+        const double BTPB = ((BTP.v[0] * Bd.v[0] + BTP.v[1] * Bd.v[1]) + BTP.v[2] * Bd.v[2]) + BTP.v[3] * Bd.v[3];
+        const double g = 1.0 / (BTPB + prm.r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            K.v[j] = g * (((BTP.v[0] * Ad.a[0][j] + BTP.v[1] * Ad.a[1][j]) + BTP.v[2] * Ad.a[2][j]) + BTP.v[3] * Ad.a[3][j]);
+    }
+    // ---- prediction and tracking error (ref :488-567, ts = 0.1): nearest point over the whole path
+    {
+        const double c = cos(fi), s = sin(fi);
+        const double xn = x + Vx * mpc::kTs * c - Vy * mpc::kTs * s;
+        const double yn = y + Vy * mpc::kTs * c + Vx * mpc::kTs * s;
+        x = xn;
+        y = yn;
+        fi = fi + fi_dot * mpc::kTs;
+    }
+    const double* path = target_path + (size_t)b * max_path * 4;
+    const int np_ = n_path[b];
+    int idx = min_index_in[b];
+    {
+        double min_d = 10000.0;
+        for (int i = 0; i < np_; ++i) {
+            const double dx = path[4 * i] - x, dy = path[4 * i + 1] - y;
+            const double d = dx * dx + dy * dy;
+            if (d < min_d) {
+                min_d = d;
+                idx = i;
+            }
+        }
+    }
+    const bool bad_index = np_ < 1 || idx < 0 || idx >= np_;          // IndexError in the reference
+    if (bad_index) idx = 0;
+    const double px = path[4 * idx], py = path[4 * idx + 1], pth = path[4 * idx + 2], pk = path[4 * idx + 3];
+    const double ct = cos(pth), st = sin(pth);
+    const double dvx = x - px, dvy = y - py;
+    const double e_d = -st * dvx + ct * dvy;
+    const double e_s = ct * dvx + st * dvy;
+    const double theta_r = pth + pk * e_s;
+    const double cd = cos(fi - theta_r), sd = sin(fi - theta_r);
+    const double e_d_dot = Vy * cd + Vx * sd;
+    const double e_fi = sd;
+    const double S_dot = (Vx * cd - Vy * sd) / (1.0 - pk * e_d);
+    const double e_fi_dot = fi_dot - pk * S_dot;
+    // ---- feed-forward (ref :569-583) and control (ref :606)
+    const double K3 = K.v[2];
+    double delta_f = pk * (prm.a + prm.b - prm.b * K3 -
+                           (prm.b / prm.Cf + prm.a * K3 / prm.Cr - prm.a / prm.Cr) * (prm.m * Vx * Vx) / (prm.a + prm.b));
+    delta_f = delta_f * 3.141592653589793 / 180.0;
+    const double u = -(((K.v[0] * e_d + K.v[1] * e_d_dot) + K.v[2] * e_fi) + K.v[3] * e_fi_dot) + delta_f;
+    const bool ok = inv_ok && !bad_index;
+    steer[b] = ok ? u : 0.0;
+    if (K_out)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) K_out[4 * b + j] = K.v[j];
+    if (e_rr_out) {
+        e_rr_out[4 * b] = e_d;
+        e_rr_out[4 * b + 1] = e_d_dot;
+        e_rr_out[4 * b + 2] = e_fi;
+        e_rr_out[4 * b + 3] = e_fi_dot;
+    }
+    if (k_r_out) k_r_out[b] = pk;
+    min_index_out[b] = idx;
+    if (pre_pro) {
+        pre_pro[4 * b] = x;
+        pre_pro[4 * b + 1] = y;
+        pre_pro[4 * b + 2] = px + e_s * ct;
+        pre_pro[4 * b + 3] = py + e_s * st;
+    }
+    if (sweeps_out) sweeps_out[b] = sweeps;
+    status[b] = bad_index ? kStSOutOfRange : (inv_ok ? 0 : kStQpFailed);
+}
+
+}  // namespace lqr
 }  // namespace emp

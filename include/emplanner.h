@@ -331,6 +331,19 @@ int emp_mpc_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t ma
                     double* steer, double* u, double* e_rr, double* k_r, int32_t* min_index_out, double* pre_pro,
                     double* H, double* f, int32_t* iters, int32_t* status, emp_mem where);
 
+/* ref: controller/controller.py class Lateral_LQR_controller (:374-611), `_control` from explicit inputs (same inputs as
+ * emp_mpc_lateral; min_index is only the fallback when no path point lies within 100 m: the search covers the whole
+ * path, :518).  Chain: cal_A_B_fun (:424-455) -> LQR_fun (:457-486: bilinear discretisation, Riccati iteration until
+ * max|dP| < 0.1 or 5000 sweeps) -> cal_error_k_fun(ts = 0.1) (:488-567) -> forward_control_fun (:569-583) ->
+ * steer = -K e_rr + delta_f (:606; the raw command, not clipped).  p->q_diag / p->r are Q and R (:592-598: (200, 1, 50,
+ * 1), 1; emp_lqr_params_default sets them), p->f_diag is unused.  Optional outputs (NULL to skip): K [B][4],
+ * e_rr [B][4], k_r [B], pre_pro [B][4], sweeps [B] (Riccati sweeps performed). */
+void emp_lqr_params_default(emp_mpc_params* p);
+int emp_lqr_lateral(emp_ctx* ctx, const emp_mpc_params* p, int32_t B, int32_t max_path, const double* target_path,
+                    const int32_t* n_path, const double* state, const double* vx, const int32_t* min_index,
+                    double* steer, double* K, double* e_rr, double* k_r, int32_t* min_index_out, double* pre_pro,
+                    int32_t* sweeps, int32_t* status, emp_mem where);
+
 /* ---- S-T speed DP (BASELINE config 5; reference planner/speed_planning_test.py) ----------------
  * The S-T grid is hard-coded in the reference (40 non-uniform s samples :114, 16 t samples :116); tables are
  * [B][EMP_ST_ROWS][EMP_ST_COLS], row 0 = largest s (CalcSTCoordinate, :287-305).  Obstacle slots hold NaN when

@@ -128,3 +128,73 @@ def test_dropin_controller_class(pl):
     ctl.min_index = n + 3
     with pytest.raises(IndexError):
         ctl._control()
+
+
+# ---- lateral LQR controller (reference controller/controller.py:374-611): fully pinned, no solver on that path ----
+def test_lqr_vs_reference_class(pl):
+    from emplanner_carla_amd.api import lqr_params
+    g = load_golden("mpc.npz")
+    p = lqr_params(vehicle_para=tuple(g["vehicle_para"]))
+    r = pl.lqr_lateral(p, g["path"], g["n"].astype(np.int32), g["state"], g["Vx"], g["min_index_in"].astype(np.int32))
+    assert (r.status == 0).all()
+    np.testing.assert_array_equal(r.min_index, g["lqr_min_index"])
+    np.testing.assert_array_equal(r.k_r, g["lqr_k_r"])
+    assert_rel(r.e_rr, g["lqr_e_rr"], 1e-12, scale=1.0)
+    # the Riccati iteration stops on an absolute threshold (max|dP| < 0.1): the sweep count must agree with the reference
+    for c in range(len(g["n"])):
+        scale = np.abs(g["lqr_K"][c]).max()
+        assert np.abs(r.K[c] - g["lqr_K"][c]).max() <= 1e-6 * scale, f"gain of case {c} (sweeps {r.sweeps[c]})"
+        assert abs(r.steer[c] - g["lqr_steer"][c]) <= 1e-6 * max(1.0, abs(g["lqr_steer"][c])), f"steering of case {c}"
+    assert set(np.unique(r.sweeps)) <= {116, 117, 5000}
+
+
+def test_lqr_batch_vs_port(pl):
+    from emplanner_carla_amd.api import lqr_params
+    from oracle import lqr_lateral as lq
+    g = load_golden("mpc.npz")
+    para = tuple(g["vehicle_para"])
+    rng = np.random.default_rng(8)
+    B, M = 130, 40
+    path = np.zeros((B, M, 4))
+    n = rng.integers(5, M + 1, B).astype(np.int32)
+    state = np.zeros((B, 5))
+    vx = rng.choice([1.0, 4.0, 11.0, 22.0], B)
+    mi = np.zeros(B, np.int32)
+    for b in range(B):
+        t = np.arange(n[b]) * 2.4
+        xy = np.stack([t, 8 * np.sin(t / 30.0 + rng.uniform(0, 3))], axis=1)
+        th = np.arctan2(np.gradient(xy[:, 1]), np.gradient(xy[:, 0]))
+        ka = np.gradient(th) / np.hypot(np.gradient(xy[:, 0]), np.gradient(xy[:, 1]))
+        path[b, :n[b]] = np.column_stack([xy, th, ka])
+        at = int(rng.integers(0, n[b]))
+        state[b] = [xy[at, 0] + rng.normal(0, 0.5), xy[at, 1] + rng.normal(0, 0.5), th[at] + rng.normal(0, 0.1),
+                    rng.normal(0, 0.3), rng.normal(0, 0.1)]
+    r = pl.lqr_lateral(lqr_params(vehicle_para=para), path, n, state, vx, mi)
+    assert (r.status == 0).all()
+    for b in range(0, B, 5):
+        want = lq.lateral_lqr([tuple(q) for q in path[b, :n[b]]], tuple(state[b]), float(vx[b]), 0, para)
+        assert r.min_index[b] == want["min_index"] and r.sweeps[b] == want["sweeps"]
+        assert abs(r.steer[b] - want["steering"]) <= 1e-6 * max(1.0, abs(want["steering"]))
+    # empty path: IndexError in the reference
+    r0 = pl.lqr_lateral(lqr_params(vehicle_para=para), path[:1], np.zeros(1, np.int32), state[:1], vx[:1], mi[:1])
+    assert r0.status[0] != 0
+
+
+def test_dropin_lqr_class(pl):
+    import math
+    from types import SimpleNamespace as NS
+    from emplanner_carla_amd.controller.controller import Lateral_LQR_controller
+    g = load_golden("mpc.npz")
+    c = 7
+    n = int(g["n"][c])
+    x, y, fi, Vy, fi_dot = g["state"][c]
+    Vx = float(g["Vx"][c])
+    speed, beta = math.hypot(Vx, Vy), math.atan2(Vy, Vx)
+    vehicle = NS(get_location=lambda: NS(x=x, y=y, z=0.0),
+                 get_transform=lambda: NS(rotation=NS(yaw=fi * 180 / math.pi)),
+                 get_velocity=lambda: NS(x=speed * math.cos(fi + beta), y=speed * math.sin(fi + beta), z=0.0),
+                 get_angular_velocity=lambda: NS(z=fi_dot * 180 / math.pi))
+    ctl = Lateral_LQR_controller(vehicle, tuple(g["vehicle_para"]), [tuple(r) for r in g["path"][c, :n]])
+    steer = ctl._control()
+    assert abs(steer - g["lqr_steer"][c]) <= 1e-5 * max(1.0, abs(g["lqr_steer"][c]))
+    assert ctl.min_index == g["lqr_min_index"][c] and ctl.K.shape == (1, 4)

@@ -395,3 +395,18 @@ def test_mpc_port_matches_reference_class():
         # the recorded constraint set is the +-1 box (controller.py:300-304)
         np.testing.assert_array_equal(g["G"][c], np.concatenate((np.identity(12), -np.identity(12))))
         np.testing.assert_array_equal(g["h"][c], np.ones(24))
+
+
+def test_lqr_port_matches_reference_class():
+    """Lateral_LQR_controller (:374-611): fully pinned - gain, Riccati sweep count implied by it, errors, steering."""
+    from oracle import lqr_lateral as lq
+    g = load_golden("mpc.npz")
+    para = tuple(g["vehicle_para"])
+    for c in range(len(g["n"])):
+        n = int(g["n"][c])
+        out = lq.lateral_lqr([tuple(r) for r in g["path"][c, :n]], tuple(g["state"][c]), float(g["Vx"][c]),
+                             int(g["min_index_in"][c]), para)
+        np.testing.assert_array_equal(out["K"].reshape(-1), g["lqr_K"][c])
+        np.testing.assert_array_equal(out["e_rr"], g["lqr_e_rr"][c])
+        assert out["min_index"] == g["lqr_min_index"][c] and out["k_r"] == g["lqr_k_r"][c]
+        assert out["delta_f"] == g["lqr_delta_f"][c] and out["steering"] == g["lqr_steer"][c]
