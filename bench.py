@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   cpu_baseline  the reference-structured CPU port (oracle/ref_port.py), one core, bounded sample
   kernels_ms    mean duration of every kernel of the cycle, from a short diagnostic pass after the timed region
                 with every kernel bracketed by events (the brackets themselves cost ~7 % of a step)
+  roofline_dp_edge, dp_only   the FP64-VALU-bound edge kernel against the vector peak, and the DP alone (same pass)
 """
 from __future__ import annotations
 
@@ -33,6 +34,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (public spec figure)
 
 
 def cpu_baseline(cfg, n_scenes, seed0):
@@ -181,6 +183,23 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": bytes_dp, "launches_timed": sweep_launches,
                     "mean_launch_us": round(sweep_ms * 1e3, 2)}
+        # Secondary figures from the diagnostic pass (event-bracketed kernels; not part of the timed region):
+        # the edge-cost kernel against the FP64 vector peak with SURVEY.md 8(d)'s ALGORITHMIC flop count (obstacles
+        # out of reach are skipped at run time, so fewer are executed), and the DP alone.
+        extra = {}
+        if "dp_edge" in kernels:
+            flops = E * (40 + 10 * (36 + 7 * cfg.n_obs)) * count
+            tf = flops / (kernels["dp_edge"] * 1e-3) / 1e12
+            extra["roofline_dp_edge"] = {"kernel": "dp_edge_kernel", "bound": "fp64_valu", "achieved": round(tf, 2),
+                                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                                         "algorithmic_flops_per_launch": flops,
+                                         "mean_launch_us": round(kernels["dp_edge"] * 1e3, 2),
+                                         "source": "diagnostic pass after the timed region"}
+        if all(k in kernels for k in ("dp_edge", "dp_sweep", "dp_enrich")):
+            dp_ms = kernels["dp_edge"] + kernels["dp_sweep"] + kernels["dp_enrich"]
+            extra["dp_only"] = {"value": round(count / (dp_ms * 1e-3), 1), "unit": "DP plans/s per GPU",
+                                "source": "sum of the three DP kernels' mean durations in the diagnostic pass"}
         value = total * args.steps / elapsed
         line = {
             "metric": "planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)", "value": round(value, 1),
@@ -195,6 +214,7 @@ def main():
                        "ref_line_points": int(P), "qp_stations": 21, "dp_mode": args.dp_mode,
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
+            **extra,
             "kernels_ms": kernels,
             "scenes_fully_planned_frac": round(ok_frac, 4),
         }

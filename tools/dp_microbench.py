@@ -7,7 +7,7 @@ from emplanner_carla_amd import scenes as S, _lib as L
 from emplanner_carla_amd.api import Planner, dp_params_from_cfg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = S.CFG2
+cfg = S.CONFIGS.get(os.environ.get('EMP_CFG', ''), S.CFG2)
 batch = S.make_batch(range(B), cfg)
 pl = Planner(0)
 p = dp_params_from_cfg(cfg)
