@@ -196,3 +196,29 @@ def test_error_behaviour_matches_reference(mods):
         pp.Quadratic_planning(2.0 * np.ones(12), -2.0 * np.ones(12), 0.0, 0.0, 0.0)
     with pytest.raises(IndexError):
         pu.cal_heading_kappa([(0.0, 0.0)])
+
+
+def test_integration_md_binding_example_runs():
+    """The hand-written ctypes binding shown in INTEGRATION.md section 5 is executed as printed."""
+    import os
+    import re
+    from emplanner_carla_amd import scenes as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def DP_rows" in b][0]
+    block = block.replace('C.CDLL("emplanner_carla_amd/libemplanner.so")',
+                          f'C.CDLL("{os.path.join(root, "emplanner_carla_amd", "libemplanner.so")}")')
+    import torch  # noqa: F401  (the library must see torch's HIP runtime first, as _lib.load() arranges)
+    ns = {}
+    exec(block, ns)
+    sc = S.make_scene(3, S.CFG2)
+    rows, status = ns["DP_rows"](list(sc.sl_obs_s), list(sc.sl_obs_l), *[float(v) for v in sc.sl_start], row=9, col=40,
+                                 sample_s=2.5, sample_l=1.5)
+    from emplanner_carla_amd.planner import path_planning as pp
+    s_list, l_list = pp.DP_algorithm(list(sc.sl_obs_s), list(sc.sl_obs_l), *[float(v) for v in sc.sl_start], row=9, col=40,
+                                     sample_s=2.5, sample_l=1.5)
+    assert status in (0, 1) and len(rows) == 40
+    # the densified path of the drop-in passes through the lattice nodes the raw binding chose
+    want_l = (np.float64(9 + 1) / 2 - 1 - rows) * 1.5
+    got = np.interp(np.asarray(s_list[0]) + 2.5 * np.arange(1, 41), s_list, l_list)
+    assert np.allclose(got, want_l, atol=1e-9)
