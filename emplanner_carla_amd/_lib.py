@@ -65,7 +65,8 @@ _vp, _i32, _f64, _u64 = C.c_void_p, C.c_int32, C.c_double, C.c_uint64
 class CycleIO(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "ref_line", "n_ref", "origin_xy", "start_xy", "start_v", "start_a", "obs_xy", "n_obs",
-        "dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status")]
+        "dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status",
+        "dyn_dis_speed")]
 
 
 # name -> (restype, argtypes); data pointers are void* so numpy arrays and raw device addresses both fit
@@ -151,7 +152,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 1:
+    if lib.emp_abi_version() != 2:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

@@ -630,8 +630,9 @@ class Planner:
 
     # ---- whole cycle ------------------------------------------------------------------------
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
-                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_FUSED) -> CycleResult:
-        """ref motion_planning body, test_9.py:113-218, for a batch of scenes."""
+                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_FUSED, dyn_dis_speed=None) -> CycleResult:
+        """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
+        of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169."""
         a = self._args(ref_line, origin_xy)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
@@ -645,6 +646,7 @@ class Planner:
         io.start_a = a.inp(start_a, np.float64, (B, 2))
         io.obs_xy = a.inp(obs_xy, np.float64, (B, mo, 2)) if mo else None
         io.n_obs = a.inp(n_obs, np.int32, (B,)) if mo else None
+        io.dyn_dis_speed = a.inp(dyn_dis_speed, np.float64, (B, 2)) if dyn_dis_speed is not None else None
         res = {}
         for name, shape, dt in (("dp_rows", (B, p.col), np.float64), ("dp_s", (B, M), np.float64),
                                 ("dp_l", (B, M), np.float64), ("dp_len", (B,), np.int32),

@@ -450,7 +450,8 @@ static inline dim3 grid1(int n, int block) { return dim3((unsigned)((n + block -
 static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const double* ref_line, const int* n_ref,
                        const double* origin_xy, const double* start_xy, const double* start_v, const double* start_a,
                        const double* obs_xy, const int* n_obs, double* s_map, double* obs_s, double* obs_l,
-                       double* begin_sl, double* start) {
+                       double* begin_sl, double* start, int obs_cap = -1, const double* dyn = nullptr,
+                       int* n_obs_out = nullptr) {
     if (B == 0) return EMP_OK;
     const size_t lds = (size_t)5 * max_ref * sizeof(double);
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "reference line too long for the LDS-resident projection kernel");
@@ -459,7 +460,8 @@ static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const doub
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer t(ctx, "project");
     hipLaunchKernelGGL(frenet_project_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_ref, max_obs, ref_line,
-                       n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs, s_map, obs_s, obs_l, begin_sl, start);
+                       n_ref, origin_xy, start_xy, start_v, start_a, obs_xy, n_obs, s_map, obs_s, obs_l, begin_sl, start,
+                       obs_cap < 0 ? max_obs : obs_cap, dyn, n_obs_out);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -791,8 +793,11 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                    emp_mem where) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_REQUIRE(ctx, p && q && sp && io, "NULL parameter struct");
+    // with a dynamic obstacle per scene (test_9.py:137-169) up to three virtual obstacles join the projected ones
+    const bool has_dyn = io->dyn_dis_speed != nullptr;
+    const int obs_cap = max_obs + (has_dyn ? 3 : 0);
     DpDev d;
-    int rc = make_dp_dev(ctx, p, B, max_obs, &d);
+    int rc = make_dp_dev(ctx, p, B, obs_cap, &d);
     if (rc) return rc;
     EMP_REQUIRE(ctx, max_ref >= 2 && max_pts >= 2 && max_pts <= 255, "max_ref >= 2 and 2 <= max_pts <= 255 required");
     EMP_REQUIRE(ctx, io->ref_line && io->n_ref && io->origin_xy && io->start_xy && io->start_v && io->start_a,
@@ -812,6 +817,8 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.in(io->start_a, (size_t)B * 2, &d_a))) return rc;
     if ((rc = st.in(io->obs_xy, (size_t)B * max_obs * 2, &d_oxy))) return rc;
     if ((rc = st.in(io->n_obs, (size_t)B, &d_no))) return rc;
+    const double* d_dyn = nullptr;
+    if (has_dyn && (rc = st.in(io->dyn_dis_speed, (size_t)B * 2, &d_dyn))) return rc;
     // outputs (optional ones fall back to device temporaries); no memsets: every kernel of the cycle writes its
     // rows completely, padding included
     double *d_rows, *d_dps, *d_dpl, *d_ps, *d_pl, *d_traj;
@@ -835,7 +842,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.out(io->status, (size_t)B, &d_st, false))) return rc;
     // intermediates
     double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
-    const int mo = max_obs > 0 ? max_obs : 1;
+    const int mo = obs_cap > 0 ? obs_cap : 1;
     if ((rc = st.tmp((size_t)B * max_ref, &d_sm))) return rc;
     if ((rc = st.tmp((size_t)B * mo, &d_os))) return rc;
     if ((rc = st.tmp((size_t)B * mo, &d_ol))) return rc;
@@ -846,10 +853,13 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         if ((rc = st.tmp((size_t)B, &d_zero_nobs, true))) return rc;
         d_no = d_zero_nobs;
     }
+    int* d_ntot = nullptr;
+    if (has_dyn && (rc = st.tmp((size_t)B, &d_ntot, false))) return rc;
     if (B == 0) return st.finish();
     if ((rc = dev_project(ctx, B, max_ref, max_obs, d_ref, d_nr, d_o, d_sxy, d_v, d_a, d_oxy, d_no, d_sm, d_os, d_ol,
-                          d_bsl, d_start)))
+                          d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;
+    if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
     if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
     if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
     const QpDev Q = make_qp_dev(q);

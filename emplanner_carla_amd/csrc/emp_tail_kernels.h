@@ -79,7 +79,9 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     const double* __restrict__ origin_xy, const double* __restrict__ start_xy, const double* __restrict__ start_v,
     const double* __restrict__ start_a, const double* __restrict__ obs_xy, const int* __restrict__ n_obs,
     double* __restrict__ s_map, double* __restrict__ obs_s, double* __restrict__ obs_l, double* __restrict__ begin_sl,
-    double* __restrict__ start) {
+    double* __restrict__ start, int obs_cap, const double* __restrict__ dyn, int* __restrict__ n_obs_out) {
+    // obs_xy rows hold max_obs slots, obs_s / obs_l rows obs_cap >= max_obs (+3 when `dyn` is given: the virtual
+    // obstacles of test_9.py:137-169 are appended behind the projected ones and n_obs_out gets the total)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     double* lx = lds;
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
             const int jj = (j & ~63) + lane;
             if (jj <= j) {
                 const double px = obs_xy[((size_t)b * max_obs + jj) * 2], py = obs_xy[((size_t)b * max_obs + jj) * 2 + 1];
-                obs_s[(size_t)b * max_obs + jj] = projection_s(node(my_match), sm[my_match], px, py);
-                obs_l[(size_t)b * max_obs + jj] = lateral_offset(project_on(node(first_match), px, py), px, py);
+                obs_s[(size_t)b * obs_cap + jj] = projection_s(node(my_match), sm[my_match], px, py);
+                obs_l[(size_t)b * obs_cap + jj] = lateral_offset(project_on(node(first_match), px, py), px, py);
             }
         }
     }
@@ -166,6 +168,33 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
         start[4 * b + 1] = fs.l;
         start[4 * b + 2] = fs.dl_ds;
         start[4 * b + 3] = fs.ddl_ds;
+        // ref test_9.py:137-169: the FIRST dynamic obstacle (distance Dis, speed V_obs) becomes three obstacles on
+        // the centre line covering the stretch where it and the ego meet, unless they part beyond s = 80 m
+        int total = k;
+        if (dyn && !isnan(dyn[2 * b]) && k + 3 <= obs_cap) {
+            const double Len_vehicle = 2.910, Len_obs = 3.0;
+            const double Dis = dyn[2 * b], V_obs = dyn[2 * b + 1];
+            const double vx = start_v[2 * b], vy = start_v[2 * b + 1];
+            const double V_ego = sqrt(vx * vx + vy * vy);
+            const double delta_v = V_ego - V_obs;
+            const double meet_t = ((Dis - Len_vehicle / 2.0) - Len_obs / 2.0) / delta_v;
+            const double delta_t = (Len_vehicle + Len_obs) / delta_v;
+            const double leave_t = meet_t + delta_t;
+            const double meet_s = ((bs + Dis) + V_obs * meet_t) - Len_obs / 2.0;
+            const double leave_s = ((bs + Dis) + V_obs * leave_t) + Len_obs / 2.0;
+            const double delta_s = leave_s - meet_s;
+            const double obs_pos = meet_s + delta_s / 2.0;
+            if (leave_s < 80.0) {
+                double* os = obs_s + (size_t)b * obs_cap + k;
+                double* ol = obs_l + (size_t)b * obs_cap + k;
+                os[0] = meet_s - 10.0;
+                os[1] = obs_pos;
+                os[2] = leave_s;
+                ol[0] = ol[1] = ol[2] = 0.0;
+                total = k + 3;
+            }
+        }
+        if (n_obs_out) n_obs_out[b] = total;
     }
 }
 

@@ -1,0 +1,89 @@
+"""The planning process body on the GPU: requests in the reference's wire format in, replies out.
+
+The reference runs ``motion_planning(conn)`` (test_9.py:92-220) in a child process: it receives the tuple the driver
+sends (test_9.py:390-392)
+
+    (static_obs [(x, y, dis)], dynamic_obs [(x, y, dis, speed)], vehicle_loc, pred_loc, vehicle_v, vehicle_a,
+     global_frenet_path [(x, y, theta, kappa)], match_point_list)
+
+and answers with (trajectory [(x, y, theta, kappa)], match_point_list, path_s, path_l) (test_9.py:220).
+``plan_requests`` does that for a BATCH of requests with two device calls - ``emp_reference_line`` (match on the
+global path, 51-node window, smoothing) and ``emp_plan_cycle`` (projection, virtual obstacles of the first dynamic
+obstacle, S-L DP, path QP, Cartesian tail) - and ``motion_planning(conn)`` is the one-request loop with the
+reference's Pipe protocol.  Host logic here is only what the reference does with Python lists before the numerics:
+static obstacles count only if the nearest is within 30 m (test_9.py:117), only the first dynamic obstacle is used
+(:141-142).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .api import Planner, dp_params, max_path_points, qp_params, smooth_params
+
+INFEASIBLE_BANNER = "********************     can't find a feasible path      ********************"
+
+
+def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None):
+    """requests: list of request tuples.  Returns a list of (reply tuple or None, status): None where the reference
+    would have raised (IndexError paths) or where a QP is infeasible."""
+    dp = dp or dp_params()
+    qp = qp or qp_params()
+    sp = sp or smooth_params()
+    B = len(requests)
+    if B == 0:
+        return []
+    G = max(len(r[6]) for r in requests)
+    K = max(1, max((len(r[0]) for r in requests), default=1))
+    gp = np.zeros((B, G, 4))
+    n_global = np.zeros(B, np.int32)
+    pred = np.zeros((B, 2))
+    veh = np.zeros((B, 2))
+    v = np.zeros((B, 2))
+    a = np.zeros((B, 2))
+    pre = np.zeros(B, np.int32)
+    obs = np.zeros((B, K, 2))
+    n_obs = np.zeros(B, np.int32)
+    dyn = np.full((B, 2), np.nan)
+    for b, (static, dynamic, vehicle_loc, pred_loc, vehicle_v, vehicle_a, path, match_list) in enumerate(requests):
+        n_global[b] = len(path)
+        gp[b, :len(path)] = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path])
+        pred[b], veh[b], v[b], a[b] = pred_loc, vehicle_loc, vehicle_v, vehicle_a
+        pre[b] = int(match_list[0])
+        if len(static) != 0 and static[0][-1] <= 30:                       # test_9.py:117
+            n_obs[b] = len(static)
+            obs[b, :len(static)] = [(float(o[0]), float(o[1])) for o in static]
+        if len(dynamic) != 0:                                               # test_9.py:141-142
+            dyn[b] = (float(dynamic[0][2]), float(dynamic[0][3]))
+    ref, n_ref, match, _, st_ref = planner.reference_line(sp, gp, n_global, pred, pre)
+    M = max_path_points(dp)
+    res = planner.plan_cycle(dp, qp, sp, max_pts=M, ref_line=ref, n_ref=np.where(st_ref == 0, n_ref, 2).astype(np.int32),
+                             origin_xy=veh, start_xy=pred, start_v=v, start_a=a, obs_xy=obs, n_obs=n_obs, dyn_dis_speed=dyn)
+    out = []
+    for b in range(B):
+        status = int(st_ref[b]) | int(res.status[b])
+        if int(st_ref[b]) != 0 or (int(res.status[b]) & ~1) != 0:
+            out.append((None, status))
+            continue
+        m, k = int(res.traj_len[b]), int(res.path_len[b])
+        traj = [tuple(float(x) for x in row) for row in res.traj[b, :m]]
+        out.append(((traj, [int(match[b])], [float(x) for x in res.path_s[b, :k]], [float(x) for x in res.path_l[b, :k]]),
+                    status))
+    return out
+
+
+def motion_planning(conn, device_id: int = 0, dp=None):
+    """Drop-in for the reference's planning process (test_9.py:92-220): ``multiprocessing.Process(target=
+    motion_planning, args=(conn,))``.  Blocks on ``conn.recv()`` like the reference; a request the reference would fail
+    on raises the same exception type here.  ``dp`` overrides the lattice (default: the reference's keyword defaults,
+    path_planning.py:218)."""
+    planner = Planner(device_id)                                            # created in the child process
+    while 1:
+        request = conn.recv()
+        reply, status = plan_requests(planner, [request], dp=dp)[0]
+        if status & 1:
+            print(INFEASIBLE_BANNER)                                        # path_planning.py:351
+        if reply is None:
+            if status & (2 | 4):
+                raise IndexError("list index out of range")
+            raise ValueError("path or smoothing QP infeasible")
+        conn.send(reply)

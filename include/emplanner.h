@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 1
+#define EMP_ABI_VERSION 2
 
 typedef struct emp_ctx emp_ctx;
 
@@ -271,6 +271,10 @@ typedef struct emp_cycle_io {
     double* path_s; double* path_l; int32_t* path_len;
     double* traj; int32_t* traj_len;
     int32_t* status;
+    /* optional input (ABI 2): [B][2] = distance and speed of the FIRST dynamic obstacle of each scene, NaN distance =
+     * none.  ref test_9.py:137-169: it becomes three virtual static obstacles on the centre line (meet_s - 10, the
+     * middle of the encounter, leave_s) unless the encounter ends beyond s = 80 m.  NULL: no dynamic obstacles. */
+    const double* dyn_dis_speed;
 } emp_cycle_io;
 
 int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q, const emp_smooth_params* sp,

@@ -588,8 +588,29 @@ def cal_dy_obs_deri(l_set, vx_set, vy_set, proj_heading_set, proj_kappa_set):
 # --------------------------------------------------------------------------------------
 # one planning cycle  (test_9.py:92-221, the reference's motion_planning without the Pipe)
 # --------------------------------------------------------------------------------------
+def virtual_obstacles(begin_s, start_v, dyn_dis_speed):
+    """test_9.py:137-169 - the FIRST dynamic obstacle (distance, speed) becomes three static obstacles on the centre
+    line (l = 0) covering the stretch where it and the ego meet, unless they part beyond s = 80 m."""
+    if dyn_dis_speed is None:
+        return []
+    Len_vehicle, Len_obs = 2.910, 3
+    Dis, V_obs = dyn_dis_speed
+    V_ego = math.sqrt(start_v[0] ** 2 + start_v[1] ** 2)
+    delta_v = V_ego - V_obs
+    meet_t = (Dis - Len_vehicle / 2 - Len_obs / 2) / delta_v
+    delta_t = (Len_vehicle + Len_obs) / delta_v
+    leave_t = meet_t + delta_t
+    meet_s = begin_s + Dis + V_obs * meet_t - Len_obs / 2
+    leave_s = begin_s + Dis + V_obs * leave_t + Len_obs / 2
+    delta_s = leave_s - meet_s
+    obs_pos = meet_s + delta_s / 2
+    if leave_s < 80:
+        return [(meet_s - 10, 0), (obs_pos, 0), (leave_s, 0)]
+    return []
+
+
 def plan_cycle(ref_line, origin_xy, start_xy, start_v, start_a, static_obs_xy, dp_kwargs=None,
-               obs_length=5, obs_width=5, decimate=2, use_qp=True, midpoint=True, verbose=True):
+               obs_length=5, obs_width=5, decimate=2, use_qp=True, midpoint=True, verbose=True, dyn_dis_speed=None):
     """test_9.py:113-218 from the smoothed reference line onward; returns a dict of every stage."""
     dp_kwargs = dict(dp_kwargs or {})
     ref_line = [tuple(p) for p in ref_line]
@@ -599,6 +620,9 @@ def plan_cycle(ref_line, origin_xy, start_xy, start_v, start_a, static_obs_xy, d
     else:
         obs_s, obs_l = [], []
     begin_s, begin_l = cal_s_l_fun([tuple(start_xy)], ref_line, s_map)                           # :134
+    for vs, vl in virtual_obstacles(begin_s[0], start_v, dyn_dis_speed):                         # :137-169
+        obs_s = list(obs_s) + [vs]
+        obs_l = list(obs_l) + [vl]
     l0, _, _, _, dl0, _, ddl0 = cal_s_l_deri_fun([tuple(start_xy)], [tuple(start_v)], [tuple(start_a)],
                                                  ref_line, tuple(start_xy))                     # :172
     dp_s, dp_l, rows, feasible = DP_algorithm(obs_s, obs_l, begin_s[0], l0[0], dl0[0], ddl0[0],
@@ -623,3 +647,16 @@ def plan_cycle(ref_line, origin_xy, start_xy, start_v, start_a, static_obs_xy, d
     out.update(path_s=path_s, path_l=path_l, target_xy=target_xy, trajectory=traj,
                smooth_status=smooth_status)
     return out
+
+
+def motion_planning_body(request, dp_kwargs=None, verbose=False):
+    """One pass of the planning process body, test_9.py:92-220: request tuple in (:95-96), reply tuple out (:220)."""
+    static_obs, dynamic_obs, vehicle_loc, pred_loc, vehicle_v, vehicle_a, global_path, match_list = request
+    match_list, _ = find_match_points([tuple(pred_loc)], global_path, False, match_list[0])      # :99-102
+    local = sampling(match_list[0], global_path)                                                  # :104
+    line = smooth_reference_line(local)                                                           # :110
+    static_xy = [(x, y) for x, y, _ in static_obs] if len(static_obs) != 0 and static_obs[0][-1] <= 30 else []   # :116-124
+    dyn = (dynamic_obs[0][2], dynamic_obs[0][3]) if len(dynamic_obs) != 0 else None               # :126-131, :141-142
+    out = plan_cycle(line, vehicle_loc, pred_loc, vehicle_v, vehicle_a, static_xy, dp_kwargs=dp_kwargs, verbose=verbose,
+                     dyn_dis_speed=dyn)
+    return out["trajectory"], match_list, out["path_s"], out["path_l"], out

@@ -148,3 +148,40 @@ def load_controller_reference():
         for name in ("planner", "planner.planning_utils", "controller"):
             sys.modules.pop(name, None)
     return mod
+
+
+def load_driver_reference():
+    """Return the reference's ``test_9`` driver module so that its ``motion_planning(conn)`` (test_9.py:92-220, the
+    planning process body) can be run against a fake Pipe.  The driver's other imports (CARLA agents, sensors, the
+    global planner, the controller) are irrelevant to that function and are stubbed as empty modules carrying the
+    imported names; ``planner.planning_utils`` / ``planner.path_planning`` are the reference's own."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at " + REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    _install_stubs()
+    stubs = {"planner.global_planning": ("global_path_planner",), "sensors": (), "sensors.Sensors_detector_lib": ("Obstacle_detector",),
+             "agents": (), "agents.navigation": (), "agents.navigation.behavior_agent": ("BehaviorAgent",),
+             "controller": (), "controller.controller": ("Vehicle_control",)}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        for name in ("planner", "planner.planning_utils", "planner.path_planning", "test_9"):
+            sys.modules.pop(name, None)
+        importlib.import_module("planner.planning_utils")
+        importlib.import_module("planner.path_planning")
+        for name, attrs in stubs.items():
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, type(a, (), {}))
+            sys.modules[name] = m
+        mod = importlib.import_module("test_9")
+    finally:
+        sys.path.remove(REFERENCE_ROOT)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        for name in ("planner", "planner.planning_utils", "planner.path_planning", "test_9"):
+            sys.modules.pop(name, None)
+    return mod

@@ -409,3 +409,109 @@ def test_reference_line_feeds_the_cycle(planner):
         assert_rel(traj[b, :tl[b], 2], want[:, 2], RTOL, 1.0, "trajectory theta")
         checked += 1
     assert checked >= 2
+
+
+def _driver_request(g, c):
+    ns, nd = int(g["n_static"][c]), int(g["n_dynamic"][c])
+    return ([tuple(r) for r in g["static"][c, :ns]], [tuple(r) for r in g["dynamic"][c, :nd]], tuple(g["veh"][c]),
+            tuple(g["pred"][c]), tuple(g["v"][c]), tuple(g["a"][c]), [tuple(r) for r in g["path"][c]], [int(g["pre_match"][c])])
+
+
+def test_planning_process_body_vs_reference_driver(planner):
+    """emplanner_carla_amd.service.plan_requests == the reference's motion_planning(conn) (test_9.py:92-220), run for real
+    through a fake Pipe when the fixture was made: front end, the nearest-static-obstacle rule, the virtual obstacles of
+    the first dynamic obstacle, DP, QPs.  All 18 requests in ONE batch of two device calls.  This fixture runs the DP
+    with sample_s = 14.7 (keyword default overridden from outside, see tests/golden/make_golden_driver.py)."""
+    from emplanner_carla_amd import service
+    from emplanner_carla_amd.api import dp_params
+    g = load_golden("driver_s147.npz")
+    reqs = [_driver_request(g, c) for c in range(len(g["case"]))]
+    replies = service.plan_requests(planner, reqs, dp=dp_params(sample_s=14.7))
+    compared = 0
+    for c, (reply, status) in enumerate(replies):
+        if not g["qp_ok"][c]:
+            # an infeasible QP: the reference ignores cvxopt's status and sends its last iterate (path_planning.py:
+            # 211-218); here the request is refused
+            assert reply is None and status & (8 | 16), f"request {c}: status {status}"
+            continue
+        assert bool(g["ok"][c]) and reply is not None, f"request {c}: status {status}"
+        compared += 1
+        traj, match, ps, pl = reply
+        n, m = int(g["n_traj"][c]), int(g["n_path"][c])
+        assert match[0] == g["match"][c]
+        assert len(traj) == n and len(ps) == m, f"request {c} (kind {g['case'][c]}): {len(traj)} trajectory points, reference {n}"
+        assert_rel(np.asarray(ps), g["path_s"][c, :m], RTOL, 1.0, "path_s")
+        assert_rel(np.asarray(pl), g["path_l"][c, :m], RTOL, 1.0, "path_l")
+        t = np.asarray(traj)
+        assert_rel(t[:, :3], g["traj"][c, :n, :3], RTOL, 1.0, "x, y, theta")
+        assert_rel(t[:, 3], g["traj"][c, :n, 3], RTOL, 1e-2, "kappa")
+    assert compared >= 12
+
+
+def _distance_to_polyline(poly, x, y):
+    a, b = poly[:-1], poly[1:]
+    ab = b - a
+    t = np.clip(((x - a[:, 0]) * ab[:, 0] + (y - a[:, 1]) * ab[:, 1]) / np.maximum((ab ** 2).sum(axis=1), 1e-12), 0.0, 1.0)
+    return float(np.min(np.hypot(a[:, 0] + t * ab[:, 0] - x, a[:, 1] + t * ab[:, 1] - y)))
+
+
+def test_planning_process_body_default_lattice_same_curve(planner):
+    """The driver exactly as it is runs the DP with sample_s = 15: the reference then sizes each densified segment with
+    int(end_s - start_s) (path_planning.py:398), i.e. int(15 -+ 1 ulp), and which side of 15 the difference falls on
+    follows the last bits of the planning start's s - here the output of the reference-line smoothing QP, which no two
+    solvers reproduce to the bit (the reference's own cvxopt included).  A flipped segment has one sample less, the
+    stations of the path QP move; without obstacles the plan is the same curve sampled elsewhere, with obstacles the
+    bounds move with the stations and the plans differ like two runs of the reference on two machines would."""
+    from emplanner_carla_amd import service
+    g = load_golden("driver.npz")
+    reqs = [_driver_request(g, c) for c in range(len(g["case"]))]
+    replies = service.plan_requests(planner, reqs)
+    planned = 0
+    for c, (reply, status) in enumerate(replies):
+        if reply is None or not g["qp_ok"][c]:
+            continue
+        traj, match, ps, pl = reply
+        n, m = int(g["n_traj"][c]), int(g["n_path"][c])
+        assert match[0] == g["match"][c] and abs(len(ps) - m) <= 3
+        want = g["traj"][c, :n]
+        t = np.asarray(traj)
+        d = np.array([_distance_to_polyline(want[:, :2], x, y) for x, y in t[:, :2]])
+        if g["case"][c] in (0, 2, 5):      # no obstacle takes part: the same curve, sampled at other stations
+            # (the last station may lie one spacing, 4 m, beyond the reference's last one: other truncation at s_map[-1])
+            assert np.median(d) < 0.05 and d.max() < 4.5, f"request {c}: curve distance max {d.max():.2f} median {np.median(d):.2f}"
+        else:                              # with obstacles the shifted stations also shift the QP bounds (cal_lmin_lmax's
+            assert d.max() < 9.0           # index offsets, path_planning.py:240): a different, equally valid plan
+        planned += 1
+    assert planned >= 10
+
+
+def test_motion_planning_process_loop(planner):
+    """The Pipe-protocol loop (drop-in for the reference's child process) answers a request and blocks for the next."""
+    from emplanner_carla_amd import service
+    from emplanner_carla_amd.api import dp_params
+    g = load_golden("driver_s147.npz")        # non-integer sample_s: no int() truncation flips (DESIGN.md)
+
+    class Done(Exception):
+        pass
+
+    class FakeConn:
+        def __init__(self, reqs):
+            self.reqs, self.sent = list(reqs), []
+
+        def recv(self):
+            if not self.reqs:
+                raise Done()
+            return self.reqs.pop(0)
+
+        def send(self, obj):
+            self.sent.append(obj)
+
+    conn = FakeConn([_driver_request(g, 4), _driver_request(g, 9)])
+    with pytest.raises(Done):
+        service.motion_planning(conn, dp=dp_params(sample_s=14.7))
+    assert len(conn.sent) == 2
+    for reply, c in zip(conn.sent, (4, 9)):
+        traj, match, ps, pl = reply
+        assert len(traj) == g["n_traj"][c] and match == [int(g["match"][c])]
+        assert isinstance(traj[0], tuple) and len(traj[0]) == 4 and isinstance(ps, list)
+        assert_rel(np.array(traj)[:, :3], g["traj"][c, :len(traj), :3], 1e-6, 1.0, "trajectory")

@@ -410,3 +410,29 @@ def test_lqr_port_matches_reference_class():
         np.testing.assert_array_equal(out["e_rr"], g["lqr_e_rr"][c])
         assert out["min_index"] == g["lqr_min_index"][c] and out["k_r"] == g["lqr_k_r"][c]
         assert out["delta_f"] == g["lqr_delta_f"][c] and out["steering"] == g["lqr_steer"][c]
+
+
+# --------------------------------------------------------------------------------------
+# planning process body (reference test_9.py:92-220, run for real through a fake Pipe) - oracle/ref_port.py
+# --------------------------------------------------------------------------------------
+def _driver_request(g, c):
+    ns, nd = int(g["n_static"][c]), int(g["n_dynamic"][c])
+    return ([tuple(r) for r in g["static"][c, :ns]], [tuple(r) for r in g["dynamic"][c, :nd]], tuple(g["veh"][c]),
+            tuple(g["pred"][c]), tuple(g["v"][c]), tuple(g["a"][c]), [tuple(r) for r in g["path"][c]], [int(g["pre_match"][c])])
+
+
+@pytest.mark.parametrize("fname,sample_s", [("driver.npz", None), ("driver_s147.npz", 14.7)])
+def test_motion_planning_body_port_matches_reference_driver(fname, sample_s):
+    g = load_golden(fname)
+    kw = None if sample_s is None else dict(sample_s=sample_s)
+    for c in range(len(g["case"])):
+        traj, match, ps, pl, _ = op.motion_planning_body(_driver_request(g, c), dp_kwargs=kw)
+        assert bool(g["ok"][c])
+        n, m = int(g["n_traj"][c]), int(g["n_path"][c])
+        assert match[0] == g["match"][c] and len(traj) == n and len(ps) == m
+        np.testing.assert_array_equal(np.asarray(ps, dtype=np.float64), g["path_s"][c, :m])
+        np.testing.assert_array_equal(np.asarray(pl, dtype=np.float64), g["path_l"][c, :m])
+        np.testing.assert_array_equal(np.asarray(traj, dtype=np.float64), g["traj"][c, :n])
+    # the dynamic-obstacle kinds really change the plan (virtual obstacles on the centre line, test_9.py:163-169)
+    kinds = g["case"]
+    assert np.abs(g["path_l"][kinds == 3]).max() > 1.0 and np.abs(g["path_l"][kinds == 0]).max() < 1.0
