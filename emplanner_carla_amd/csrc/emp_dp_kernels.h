@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
     __syncthreads();
 
     const int lanes_used = P.S * row;
-    const double t_last = t_smp[kSamples - 1];
 
     // ---- start edges (column 0): generic form, one thread per (scene, row); only chunk 0 does them
     if (blockIdx.y == 0 && start_cost != nullptr && tid < lanes_used) {

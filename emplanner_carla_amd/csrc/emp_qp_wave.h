@@ -223,7 +223,20 @@ __device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rin
         for (int d = 1; d <= KD; ++d) a[d] = inband[d] ? acc[d] * r : 0.0;
         rinv = r;
     }
-    const bool bad = row && !(diag > 0.0);
+    // A failed factorisation (pivot <= 0, or anything non-finite) must not leave its garbage in the registers:
+    // with G = 32 the substitutions' shifts would carry a NaN into the neighbouring group, where 0 * NaN poisons a
+    // healthy problem.  The failed group gets the identity factor (the caller stops it anyway).
+    double offd = 0.0;
+#pragma unroll
+    for (int d = 1; d <= KD; ++d) offd += fabs(a[d]);
+    const bool bad = row && !(diag > 0.0 && diag < 1e300 && offd < 1e300);
+    const bool failed = group_any<G>(bad);
+    if (failed) {
+        a[0] = 1.0;
+#pragma unroll
+        for (int d = 1; d <= KD; ++d) a[d] = 0.0;
+        rinv = 1.0;
+    }
     // column entries for the forward substitution: low[e] = U[gl-e][e]
     low[0] = 0.0;
     {
@@ -238,18 +251,19 @@ __device__ __forceinline__ bool band_chol_group(double (&a)[KD + 1], double& rin
             low[3] = (gl >= 3) ? t : 0.0;
         }
     }
-    return !group_any<G>(bad);
+    return !failed;
 }
 
 // solve U'U x = b with the factor from band_chol_group; b (one entry per lane) is overwritten with x.
 // Same sweep idea: y_j = (b_j - sum_e U[j-e][e] y_{j-e}) / U[j][j] is recomputed by every lane at every step from
 // its neighbours' current values; after step k entries 0..k are final (backward: N-1..N-1-k).  All operands are
-// finite (the factor is final), and shifted-in values from outside the group meet a zero coefficient.
+// finite (band_chol_group replaces a failed factor by the identity, a non-finite right-hand side is zeroed), and
+// shifted-in values from outside the group meet a zero coefficient.
 template <int G, int KD>
 __device__ __forceinline__ void band_solve_group(const double (&a)[KD + 1], double rinv, const double (&low)[KD + 1],
                                                  double& b, int N, int gl) {
     const int nmax = group_nmax<G>(N);
-    const double rhs = b;
+    const double rhs = (fabs(b) < 1e300) ? b : 0.0;               // a NaN must not travel into the neighbouring group
     double y = rhs * rinv;
     for (int k = 1; k < nmax; ++k) {                               // U' y = b
         const double y1 = lane_up1(y);
