@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      the DP min-plus sweep kernel (HBM bound): algorithmic bytes / mean HIP-event duration of its
                 launches INSIDE the timed region (the only kernel bracketed by events there)
   cpu_baseline  the reference-structured CPU port (oracle/ref_port.py), one core, bounded sample
+  cpu_baseline_pool   the same port on a pool of single-threaded processes (up to 64 host cores), whole-pool rate
   kernels_ms    mean duration of every kernel of the cycle, from a short diagnostic pass after the timed region
                 with every kernel bracketed by events (the brackets themselves cost ~7 % of a step)
   roofline_dp_edge, dp_only   the FP64-VALU-bound edge kernel against the vector peak, and the DP alone (same pass)
@@ -64,6 +65,42 @@ def cpu_baseline(cfg, n_scenes, seed0):
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+def cpu_baseline_pool(cfg_name, workers, per_worker):
+    """The same CPU path on `workers` host cores at once (one single-threaded process per core, spawned so that no
+    worker inherits this process's HIP state): whole-pool throughput over workers * per_worker scenes."""
+    import multiprocessing as mp
+    from oracle import cpu_pool
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            pool.map(cpu_pool.warm, range(workers), chunksize=1)           # processes up, modules imported
+            jobs = [("CFG2", list(range(10000 + w * per_worker, 10000 + (w + 1) * per_worker))) for w in range(workers)]
+            t0 = time.perf_counter()
+            done = pool.map(cpu_pool.plan_seeds, jobs, chunksize=1)
+            dt = time.perf_counter() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    n = sum(d[0] for d in done)
+    busy = sum(d[1] for d in done)                  # CPU-seconds the workers spent planning
+    quota = "unknown"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota = fh.read().strip()
+    except OSError:
+        pass
+    return {"value": n / dt, "per_core_value": n / busy, "affinity_cores": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_max": quota, "unit": "planning cycles/s", "cores": workers, "kind": "port",
+            "sample": f"{n} scenes (seeds 10000..{10000 + n - 1}) over a pool of {workers} single-threaded processes "
+                      f"(os.cpu_count() = {os.cpu_count()}), {per_worker} scenes each, oracle/ref_port.py plan_cycle, "
+                      f"{dt:.1f} s wall"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +110,9 @@ def main():
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
+                    "-1 = min(os.cpu_count(), 64))")
+    ap.add_argument("--cpu-pool-scenes", type=int, default=6, help="scenes per pool process")
     args = ap.parse_args()
 
     import torch
@@ -220,6 +260,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, 0)
+            workers = min(os.cpu_count() or 1, 64) if args.cpu_pool < 0 else args.cpu_pool
+            if workers > 0:
+                try:
+                    line["cpu_baseline_pool"] = cpu_baseline_pool("CFG2", workers, args.cpu_pool_scenes)
+                except Exception as exc:                                       # informational: never fails the bench
+                    line["cpu_baseline_pool"] = {"error": f"{type(exc).__name__}: {exc}"}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
