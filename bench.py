@@ -65,6 +65,19 @@ def cpu_baseline(cfg, n_scenes, seed0):
                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+def usable_cores(cap):
+    """Host cores this process may actually use: the scheduler affinity, cut by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline_pool(cfg_name, workers, per_worker):
     """The same CPU path on `workers` host cores at once (one single-threaded process per core, spawned so that no
     worker inherits this process's HIP state): whole-pool throughput over workers * per_worker scenes."""
@@ -111,8 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
-                    "-1 = min(os.cpu_count(), 64))")
-    ap.add_argument("--cpu-pool-scenes", type=int, default=6, help="scenes per pool process")
+                    "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
+    ap.add_argument("--cpu-pool-scenes", type=int, default=16, help="scenes per pool process")
     args = ap.parse_args()
 
     import torch
@@ -260,7 +273,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, 0)
-            workers = min(os.cpu_count() or 1, 64) if args.cpu_pool < 0 else args.cpu_pool
+            workers = usable_cores(64) if args.cpu_pool < 0 else args.cpu_pool
             if workers > 0:
                 try:
                     line["cpu_baseline_pool"] = cpu_baseline_pool("CFG2", workers, args.cpu_pool_scenes)
