@@ -39,9 +39,28 @@ class _Matrix:
 
     def __init__(self, a):
         self.a = np.array(a, dtype=np.float64)
+        if self.a.ndim == 1:                       # cvxopt turns a 1-D array into a column vector
+            self.a = self.a.reshape(-1, 1)
 
     def __array__(self, dtype=None, copy=None):
         return self.a if dtype is None else self.a.astype(dtype)
+
+    # item access as far as the reference's speed_QP uses it (speed_planning_test.py:446-482): 2-D slices with an
+    # array on the right, single indices into column vectors (column-major linear index, like cvxopt)
+    @property
+    def size(self):
+        return self.a.shape
+
+    def __setitem__(self, key, value):
+        if isinstance(key, tuple):
+            self.a[key] = np.asarray(value, dtype=np.float64)
+        else:
+            self.a.reshape(-1, order="F")[key] = value
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            return self.a[key]
+        return self.a.reshape(-1, order="F")[key]
 
 
 class _Solution:
@@ -77,6 +96,11 @@ def _install_stubs():
     def qp(P, q, G=None, h=None, A=None, b=None, **_kw):
         arr = lambda m: None if m is None else np.asarray(m, dtype=np.float64)
         rec = {"P": arr(P), "q": arr(q), "G": arr(G), "h": arr(h), "A": arr(A), "b": arr(b)}
+        if rec["A"] is not None and rec["A"].ndim == 2 and rec["A"].shape[1] != rec["P"].shape[0]:
+            # what cvxopt does with the reference's speed_QP call (an untransposed equality matrix, :503)
+            rec["status"] = "rejected"
+            QP_LOG.append(rec)
+            raise TypeError("'A' must be a 'd' matrix with %d columns" % rec["P"].shape[0])
         res = qp_dense.solve_qp(rec["P"], rec["q"], rec["G"], rec["h"], rec["A"], rec["b"])
         rec["x"] = res.x.copy()
         rec["status"] = res.status

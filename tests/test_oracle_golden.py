@@ -436,3 +436,106 @@ def test_motion_planning_body_port_matches_reference_driver(fname, sample_s):
     # the dynamic-obstacle kinds really change the plan (virtual obstacles on the centre line, test_9.py:163-169)
     kinds = g["case"]
     assert np.abs(g["path_l"][kinds == 3]).max() > 1.0 and np.abs(g["path_l"][kinds == 0]).max() < 1.0
+
+
+# --------------------------------------------------------------------------------------
+# S-T speed planning back end (reference speed_planning_test.py:308-620) - oracle/st_backend.py
+# --------------------------------------------------------------------------------------
+RAISE = {1: ValueError, 2: IndexError}
+
+
+def _convex_space_call(be, g, b):
+    n = int(g["path_len"][b])
+    return be.port_generate_convex_space(g["dp_s"][b], g["dp_t"][b], g["path_index2s"][b, :n], g["s_in"][b], g["s_out"][b],
+                                         g["t_in"][b], g["t_out"][b], g["path_kappa"][b, :n])
+
+
+def test_convex_space_port_matches_reference():
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    ran = 0
+    for b in range(len(g["v0"])):
+        code = int(g["cs_raise"][b])
+        if code:
+            with pytest.raises(RAISE[code]):
+                _convex_space_call(be, g, b)
+            continue
+        out = _convex_space_call(be, g, b)
+        np.testing.assert_array_equal(np.stack(out), g["cs_out"][b])
+        ran += 1
+    assert ran >= 60 and (g["cs_raise"] == 1).sum() >= 5 and (g["cs_raise"] == 2).sum() >= 1
+    # both decisions occur: corridors bounded from above (yield) and from below (overtake)
+    assert np.isfinite(g["cs_out"][:, 0]).any() and np.isfinite(g["cs_out"][:, 1]).any()
+
+
+def test_speed_qp_formulation_matches_what_the_reference_builds():
+    """Everything speed_QP computes before its solver call (which cvxopt rejects): H, f, A, Aeq, dt, qp_size, and the
+    single aliased bound vector, which ends up holding the intended UPPER bounds."""
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    built = 0
+    for b in range(len(g["v0"])):
+        code = int(g["qp_code"][b])
+        if code < 0:
+            continue
+        args = (float(g["v0"][b]), float(g["qp_a0"][b]), g["dp_s"][b], g["dp_t"][b], *g["cs_out"][b])
+        if code == 2:                                   # full-length DP profile: dp_speed_s[16]
+            with pytest.raises(IndexError):
+                be.speed_qp_formulation(*args)
+            continue
+        F = be.speed_qp_formulation(*args)
+        n = int(g["qp_size"][b])
+        assert F["qp_size"] == n and F["dt"] == g["qp_dt"][b]
+        np.testing.assert_array_equal(F["H"], g["qp_H"][b, :3 * n, :3 * n])
+        np.testing.assert_array_equal(F["f"].reshape(-1), g["qp_f"][b, :3 * n])
+        np.testing.assert_array_equal(F["A"], g["qp_A"][b, :n - 1, :3 * n])
+        np.testing.assert_array_equal(F["Aeq"], g["qp_Aeq"][b, :3 * n, :2 * n - 2])
+        np.testing.assert_array_equal(F["ub"], g["qp_bound"][b, :3 * n])
+        built += 1
+    assert built >= 30
+
+
+def test_intended_speed_qp_is_certified():
+    """The problem speed_QP means: unique minimiser, KKT-certified by the dense solver; the profile obeys the
+    continuity equations, the bounds and s monotone."""
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    solved = 0
+    for b in np.nonzero(g["qp_code"] == 3)[0][:24]:
+        (qs, qv, qa, qt), res, F = be.speed_qp(float(g["v0"][b]), float(g["qp_a0"][b]), g["dp_s"][b], g["dp_t"][b],
+                                               *g["cs_out"][b])
+        if res is None or res.status != "optimal":
+            assert np.isnan(g["prof"][b]).all()
+            continue
+        n, dt = F["qp_size"], F["dt"]
+        assert res.stationarity < 1e-6 and res.violation < 1e-8
+        np.testing.assert_allclose(np.stack([qs, qv, qa, qt])[:, :n], g["prof"][b][:, :n], rtol=0, atol=1e-9)
+        assert qs[0] == pytest.approx(0.0, abs=1e-9) and qv[0] == pytest.approx(g["v0"][b], abs=1e-9)
+        assert np.allclose(qs[1:n], qs[:n - 1] + dt * qv[:n - 1] + dt * dt / 3 * qa[:n - 1] + dt * dt / 6 * qa[1:n], atol=1e-8)
+        assert np.allclose(qv[1:n], qv[:n - 1] + dt / 2 * (qa[:n - 1] + qa[1:n]), atol=1e-8)
+        assert (np.diff(qs[:n]) >= -1e-8).all() and (qa[1:n] >= -6 - 1e-8).all() and (qa[1:n] <= 4 + 1e-8).all()
+        assert (qs[1:n] <= g["cs_out"][b, 1, :n - 1] + 1e-8).all() and (qs[1:n] >= g["cs_out"][b, 0, :n - 1] - 1e-8).all()
+        solved += 1
+    assert solved >= 12
+
+
+def test_increase_points_and_merge_ports_match_reference():
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    dense = merged = 0
+    for b in range(len(g["v0"])):
+        if g["dense_raise"][b] != 0:
+            continue
+        out = be.port_increase_points(*g["prof"][b])
+        np.testing.assert_array_equal(np.stack(out), g["dense_out"][b])
+        dense += 1
+        width = int(g["merge_n"][b]) if b == 1 else g["merge_x"].shape[1]
+        args = (*g["dense_out"][b], float(g["merge_now"][b]), g["merge_path_s"][b, :width], g["merge_x"][b, :width],
+                g["merge_y"][b, :width], g["merge_heading"][b, :width], g["merge_kappa"][b, :width])
+        if g["merge_raise"][b] == 2:
+            with pytest.raises(IndexError):
+                be.port_path_speed_merge(*args)
+            continue
+        np.testing.assert_array_equal(np.stack(be.port_path_speed_merge(*args)), g["merge_out"][b])
+        merged += 1
+    assert dense >= 30 and merged >= 30
