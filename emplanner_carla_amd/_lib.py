@@ -54,6 +54,12 @@ class MpcParams(C.Structure):
                 ("Iz", C.c_double), ("q_diag", C.c_double * 4), ("f_diag", C.c_double * 4), ("r", C.c_double)]
 
 
+class SpeedQpParams(C.Structure):
+    """emp_speed_qp_params: keyword arguments of the reference's speed_QP (speed_planning_test.py:410-411)."""
+    _fields_ = [("w_cost_s_dot2", C.c_double), ("w_cost_v_ref", C.c_double), ("w_cost_jerk", C.c_double),
+                ("reference_speed", C.c_double)]
+
+
 class SpeedDpParams(C.Structure):
     _fields_ = [("reference_speed", C.c_double), ("w_cost_ref_speed", C.c_double), ("w_cost_accel", C.c_double),
                 ("w_cost_obs", C.c_double)]
@@ -125,6 +131,11 @@ PROTOTYPES = {
     "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),
     "emp_st_edge_costs": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32, _i32] + [_vp] * 7 + [C.c_int]),
     "emp_st_collision_cost": (C.c_int, [_vp, _i32, _f64, _vp, _vp, C.c_int]),
+    "emp_speed_qp_params_default": (None, [C.POINTER(SpeedQpParams)]),
+    "emp_speed_convex_space": (C.c_int, [_vp, _i32, _i32, _i32, _f64] + [_vp] * 14 + [C.c_int]),
+    "emp_speed_qp": (C.c_int, [_vp, C.POINTER(SpeedQpParams), _i32] + [_vp] * 14 + [C.c_int]),
+    "emp_speed_increase_points": (C.c_int, [_vp, _i32] + [_vp] * 9 + [C.c_int]),
+    "emp_path_speed_merge": (C.c_int, [_vp, _i32, _i32] + [_vp] * 13 + [C.c_int]),
 }
 
 _lib = None
@@ -152,7 +163,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 2:
+    if lib.emp_abi_version() != 3:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

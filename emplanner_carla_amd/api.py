@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from ._lib import DpParams, QpParams, SmoothParams, SpeedDpParams, MpcParams, EmpError
+from ._lib import DpParams, QpParams, SmoothParams, SpeedDpParams, SpeedQpParams, MpcParams, EmpError
 
 
 def dp_params(row=12, col=6, sample_s=15, sample_l=1.5, sampling_res=2, w_collision_cost=1e12,
@@ -96,6 +96,15 @@ class MpcResult:
     f: object            # (B, 12) or None
     iters: object
     status: object
+
+
+SPEED_DP_COLS, SPEED_QP_POINTS, SPEED_DENSE_POINTS = 16, 17, 401
+STB_RANGE, STB_INDEX, STB_QP_FAILED, STB_NO_PROFILE = 2, 4, 8, 64     # EMP_STB_* status bits
+
+
+def speed_qp_params(w_cost_s_dot2=10, w_cost_v_ref=50, w_cost_jerk=500, reference_speed=50) -> SpeedQpParams:
+    """Keyword defaults of reference speed_QP (speed_planning_test.py:410-411)."""
+    return SpeedQpParams(float(w_cost_s_dot2), float(w_cost_v_ref), float(w_cost_jerk), float(reference_speed))
 
 
 def speed_dp_params(reference_speed=50, w_cost_ref_speed=4000, w_cost_accel=100, w_cost_obs=10000000) -> SpeedDpParams:
@@ -575,6 +584,66 @@ class Planner:
         self._check(self._lib.emp_st_collision_cost(self._h, n, float(w_cost_obs), a.inp(min_dis, np.float64, (n,)), cp,
                                                     a.where))
         return c
+
+    # ---- S-T speed planning back end (reference speed_planning_test.py:308-620) ---------------------
+    def speed_convex_space(self, dp_speed_s, dp_speed_t, path_index2s, path_kappa, path_len, s_in, s_out, t_in, t_out,
+                           max_lateral_accel=0.2 * 9.8):
+        """ref generate_convex_space: DP profile (B,16) + path (B,P) + S-T segments (B,K) -> s_lb, s_ub, s_dot_lb,
+        s_dot_ub (B,16), status (B,)."""
+        a = self._args(dp_speed_s, path_index2s, s_in)
+        B, P, K = int(dp_speed_s.shape[0]), int(path_index2s.shape[1]), int(s_in.shape[1])
+        outs = [a.out((B, SPEED_DP_COLS), np.float64) for _ in range(4)]
+        st, stp = a.out((B,), np.int32)
+        self._check(self._lib.emp_speed_convex_space(
+            self._h, B, K, P, float(max_lateral_accel), a.inp(dp_speed_s, np.float64, (B, SPEED_DP_COLS)),
+            a.inp(dp_speed_t, np.float64, (B, SPEED_DP_COLS)), a.inp(path_index2s, np.float64, (B, P)),
+            a.inp(path_kappa, np.float64, (B, P)), a.inp(path_len, np.int32, (B,)), a.inp(s_in, np.float64, (B, K)),
+            a.inp(s_out, np.float64, (B, K)), a.inp(t_in, np.float64, (B, K)), a.inp(t_out, np.float64, (B, K)),
+            outs[0][1], outs[1][1], outs[2][1], outs[3][1], stp, a.where))
+        return outs[0][0], outs[1][0], outs[2][0], outs[3][0], st
+
+    def speed_qp(self, p: SpeedQpParams, plan_start_s_dot, plan_start_s_dot2, dp_speed_s, dp_speed_t, s_lb, s_ub, s_dot_lb,
+                 s_dot_ub):
+        """ref speed_QP (the problem it states, see include/emplanner.h): -> qp_s, qp_s_dot, qp_s_dot2, relative_time
+        (B,17), iters (B,), status (B,)."""
+        a = self._args(dp_speed_s, s_lb)
+        B = int(dp_speed_s.shape[0])
+        outs = [a.out((B, SPEED_QP_POINTS), np.float64) for _ in range(4)]
+        it, itp = a.out((B,), np.int32)
+        st, stp = a.out((B,), np.int32)
+        c16 = lambda x: a.inp(x, np.float64, (B, SPEED_DP_COLS))
+        self._check(self._lib.emp_speed_qp(
+            self._h, C.byref(p), B, a.inp(plan_start_s_dot, np.float64, (B,)), a.inp(plan_start_s_dot2, np.float64, (B,)),
+            c16(dp_speed_s), c16(dp_speed_t), c16(s_lb), c16(s_ub), c16(s_dot_lb), c16(s_dot_ub), outs[0][1], outs[1][1],
+            outs[2][1], outs[3][1], itp, stp, a.where))
+        return outs[0][0], outs[1][0], outs[2][0], outs[3][0], it, st
+
+    def speed_increase_points(self, s_init, s_dot_init, s_dot2_init, relative_time_init):
+        """ref increase_points: (B,17) profiles -> s, s_dot, s_dot2, relative_time (B,401), status (B,)."""
+        a = self._args(s_init)
+        B = int(s_init.shape[0])
+        outs = [a.out((B, SPEED_DENSE_POINTS), np.float64) for _ in range(4)]
+        st, stp = a.out((B,), np.int32)
+        c17 = lambda x: a.inp(x, np.float64, (B, SPEED_QP_POINTS))
+        self._check(self._lib.emp_speed_increase_points(self._h, B, c17(s_init), c17(s_dot_init), c17(s_dot2_init),
+                                                        c17(relative_time_init), outs[0][1], outs[1][1], outs[2][1],
+                                                        outs[3][1], stp, a.where))
+        return outs[0][0], outs[1][0], outs[2][0], outs[3][0], st
+
+    def path_speed_merge(self, s, s_dot, s_dot2, relative_time, current_time, path_s, x_init, y_init, heading_init,
+                         kappa_init, n_init):
+        """ref path_speed_merge: speed samples (B,401) x path arrays (B,P) -> trajectory (B,7,401) = x, y, heading,
+        kappa, speed, accel, time; status (B,)."""
+        a = self._args(s, path_s)
+        B, P = int(s.shape[0]), int(path_s.shape[1])
+        out, outp = a.out((B, 7, SPEED_DENSE_POINTS), np.float64)
+        st, stp = a.out((B,), np.int32)
+        d = lambda x: a.inp(x, np.float64, (B, SPEED_DENSE_POINTS))
+        q = lambda x: a.inp(x, np.float64, (B, P))
+        self._check(self._lib.emp_path_speed_merge(
+            self._h, B, P, d(s), d(s_dot), d(s_dot2), d(relative_time), a.inp(current_time, np.float64, (B,)), q(path_s),
+            q(x_init), q(y_init), q(heading_init), q(kappa_init), a.inp(n_init, np.int32, (B,)), outp, stp, a.where))
+        return out, st
 
     # ---- QP stages ------------------------------------------------------------------------
     def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):

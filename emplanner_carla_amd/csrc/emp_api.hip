@@ -6,6 +6,7 @@
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
 #include "emp_st_kernels.h"
+#include "emp_st_backend_kernels.h"
 #include "emp_tail_kernels.h"
 #include "emp_mpc_kernels.h"
 
@@ -1251,6 +1252,172 @@ int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const doub
     if ((rc = stg.out(cost, (size_t)n, &d_c, false))) return rc;
     if (n) {
         hipLaunchKernelGGL(st_collision_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, w_cost_obs, d_d, d_c);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+// ---- S-T speed planning back end (reference speed_planning_test.py:308-620) ---------------------
+void emp_speed_qp_params_default(emp_speed_qp_params* p) {
+    if (!p) return;
+    // ref: speed_QP keyword defaults, speed_planning_test.py:410-411
+    p->w_cost_s_dot2 = 10.0;
+    p->w_cost_v_ref = 50.0;
+    p->w_cost_jerk = 500.0;
+    p->reference_speed = 50.0;
+}
+
+int emp_speed_convex_space(emp_ctx* ctx, int32_t B, int32_t n_slots, int32_t max_path, double max_lateral_accel,
+                           const double* dp_speed_s, const double* dp_speed_t, const double* path_index2s,
+                           const double* path_kappa, const int32_t* path_len, const double* s_in, const double* s_out,
+                           const double* t_in, const double* t_out, double* s_lb, double* s_ub, double* s_dot_lb,
+                           double* s_dot_ub, int32_t* status, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && n_slots >= 1 && max_path >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, dp_speed_s && dp_speed_t && path_index2s && path_kappa && path_len && s_in && s_out && t_in && t_out &&
+                         s_lb && s_ub && s_dot_lb && s_dot_ub && status, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double *d_ds, *d_dt, *d_i2s, *d_k, *d_si, *d_so, *d_ti, *d_to;
+    const int* d_pl;
+    double *d_lb, *d_ub, *d_vlb, *d_vub;
+    int* d_st;
+    if ((rc = stg.in(dp_speed_s, (size_t)B * stb::kDp, &d_ds))) return rc;
+    if ((rc = stg.in(dp_speed_t, (size_t)B * stb::kDp, &d_dt))) return rc;
+    if ((rc = stg.in(path_index2s, (size_t)B * max_path, &d_i2s))) return rc;
+    if ((rc = stg.in(path_kappa, (size_t)B * max_path, &d_k))) return rc;
+    if ((rc = stg.in(path_len, (size_t)B, &d_pl))) return rc;
+    if ((rc = stg.in(s_in, (size_t)B * n_slots, &d_si))) return rc;
+    if ((rc = stg.in(s_out, (size_t)B * n_slots, &d_so))) return rc;
+    if ((rc = stg.in(t_in, (size_t)B * n_slots, &d_ti))) return rc;
+    if ((rc = stg.in(t_out, (size_t)B * n_slots, &d_to))) return rc;
+    if ((rc = stg.out(s_lb, (size_t)B * stb::kDp, &d_lb, false))) return rc;
+    if ((rc = stg.out(s_ub, (size_t)B * stb::kDp, &d_ub, false))) return rc;
+    if ((rc = stg.out(s_dot_lb, (size_t)B * stb::kDp, &d_vlb, false))) return rc;
+    if ((rc = stg.out(s_dot_ub, (size_t)B * stb::kDp, &d_vub, false))) return rc;
+    if ((rc = stg.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "speed_convex_space");
+        hipLaunchKernelGGL(stb::convex_space_kernel, grid1(B, 64), dim3(64), 0, ctx->stream, B, n_slots, max_path,
+                           max_lateral_accel, d_ds, d_dt, d_i2s, d_k, d_pl, d_si, d_so, d_ti, d_to, d_lb, d_ub, d_vlb, d_vub,
+                           d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+int emp_speed_qp(emp_ctx* ctx, const emp_speed_qp_params* p, int32_t B, const double* plan_start_s_dot,
+                 const double* plan_start_s_dot2, const double* dp_speed_s, const double* dp_speed_t, const double* s_lb,
+                 const double* s_ub, const double* s_dot_lb, const double* s_dot_ub, double* qp_s, double* qp_s_dot,
+                 double* qp_s_dot2, double* relative_time, int32_t* iters, int32_t* status, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, p != nullptr && B >= 0, "bad argument");
+    EMP_REQUIRE(ctx, plan_start_s_dot && plan_start_s_dot2 && dp_speed_s && dp_speed_t && s_lb && s_ub && s_dot_lb && s_dot_ub &&
+                         qp_s && qp_s_dot && qp_s_dot2 && relative_time && status, "NULL argument");
+    EMP_REQUIRE(ctx, p->w_cost_s_dot2 > 0 && p->w_cost_v_ref > 0 && p->w_cost_jerk >= 0, "weights must be positive");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double *d_v0, *d_a0, *d_ds, *d_dt, *d_lb, *d_ub, *d_vlb, *d_vub;
+    double *d_qs, *d_qv, *d_qa, *d_qt;
+    int *d_it, *d_st;
+    if ((rc = stg.in(plan_start_s_dot, (size_t)B, &d_v0))) return rc;
+    if ((rc = stg.in(plan_start_s_dot2, (size_t)B, &d_a0))) return rc;
+    if ((rc = stg.in(dp_speed_s, (size_t)B * stb::kDp, &d_ds))) return rc;
+    if ((rc = stg.in(dp_speed_t, (size_t)B * stb::kDp, &d_dt))) return rc;
+    if ((rc = stg.in(s_lb, (size_t)B * stb::kDp, &d_lb))) return rc;
+    if ((rc = stg.in(s_ub, (size_t)B * stb::kDp, &d_ub))) return rc;
+    if ((rc = stg.in(s_dot_lb, (size_t)B * stb::kDp, &d_vlb))) return rc;
+    if ((rc = stg.in(s_dot_ub, (size_t)B * stb::kDp, &d_vub))) return rc;
+    if ((rc = stg.out(qp_s, (size_t)B * stb::kQp, &d_qs, false))) return rc;
+    if ((rc = stg.out(qp_s_dot, (size_t)B * stb::kQp, &d_qv, false))) return rc;
+    if ((rc = stg.out(qp_s_dot2, (size_t)B * stb::kQp, &d_qa, false))) return rc;
+    if ((rc = stg.out(relative_time, (size_t)B * stb::kQp, &d_qt, false))) return rc;
+    if ((rc = stg.out(iters, (size_t)B, &d_it, false))) return rc;
+    if ((rc = stg.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        const stb::SpeedQpParams prm{p->w_cost_s_dot2, p->w_cost_v_ref, p->w_cost_jerk, p->reference_speed};
+        const size_t lds = 2 * (size_t)(stb::speed_qp_words(stb::kQp) + 1) * sizeof(double);
+        KernelTimer t(ctx, "speed_qp");
+        hipLaunchKernelGGL(stb::speed_qp_kernel<32>, dim3((B + 1) / 2), dim3(64), lds, ctx->stream, B, prm, d_v0, d_a0, d_ds,
+                           d_dt, d_lb, d_ub, d_vlb, d_vub, d_qs, d_qv, d_qa, d_qt, d_it, d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+int emp_speed_increase_points(emp_ctx* ctx, int32_t B, const double* s_init, const double* s_dot_init,
+                              const double* s_dot2_init, const double* relative_time_init, double* s, double* s_dot,
+                              double* s_dot2, double* relative_time, int32_t* status, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && s_init && s_dot_init && s_dot2_init && relative_time_init && s && s_dot && s_dot2 &&
+                         relative_time && status, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double *d_qs, *d_qv, *d_qa, *d_qt;
+    double *d_s, *d_v, *d_a, *d_t;
+    int* d_st;
+    if ((rc = stg.in(s_init, (size_t)B * stb::kQp, &d_qs))) return rc;
+    if ((rc = stg.in(s_dot_init, (size_t)B * stb::kQp, &d_qv))) return rc;
+    if ((rc = stg.in(s_dot2_init, (size_t)B * stb::kQp, &d_qa))) return rc;
+    if ((rc = stg.in(relative_time_init, (size_t)B * stb::kQp, &d_qt))) return rc;
+    if ((rc = stg.out(s, (size_t)B * stb::kDense, &d_s, false))) return rc;
+    if ((rc = stg.out(s_dot, (size_t)B * stb::kDense, &d_v, false))) return rc;
+    if ((rc = stg.out(s_dot2, (size_t)B * stb::kDense, &d_a, false))) return rc;
+    if ((rc = stg.out(relative_time, (size_t)B * stb::kDense, &d_t, false))) return rc;
+    if ((rc = stg.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        KernelTimer t(ctx, "speed_increase_points");
+        hipLaunchKernelGGL(stb::densify_kernel, dim3(B), dim3(64), 0, ctx->stream, B, d_qs, d_qv, d_qa, d_qt, d_s, d_v, d_a, d_t,
+                           d_st);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
+int emp_path_speed_merge(emp_ctx* ctx, int32_t B, int32_t max_path, const double* s, const double* s_dot,
+                         const double* s_dot2, const double* relative_time, const double* current_time,
+                         const double* path_s, const double* x_init, const double* y_init, const double* heading_init,
+                         const double* kappa_init, const int32_t* n_init, double* trajectory, int32_t* status,
+                         emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_path >= 1, "bad sizes");
+    EMP_REQUIRE(ctx, s && s_dot && s_dot2 && relative_time && current_time && path_s && x_init && y_init && heading_init &&
+                         kappa_init && n_init && trajectory && status, "NULL argument");
+    const size_t lds = (size_t)5 * max_path * sizeof(double);
+    EMP_REQUIRE(ctx, lds <= 64 * 1024, "path too long for the LDS-resident merge kernel");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double *d_s, *d_v, *d_a, *d_t, *d_now, *d_ps, *d_x, *d_y, *d_h, *d_k;
+    const int* d_n;
+    double* d_out;
+    int* d_st;
+    if ((rc = stg.in(s, (size_t)B * stb::kDense, &d_s))) return rc;
+    if ((rc = stg.in(s_dot, (size_t)B * stb::kDense, &d_v))) return rc;
+    if ((rc = stg.in(s_dot2, (size_t)B * stb::kDense, &d_a))) return rc;
+    if ((rc = stg.in(relative_time, (size_t)B * stb::kDense, &d_t))) return rc;
+    if ((rc = stg.in(current_time, (size_t)B, &d_now))) return rc;
+    if ((rc = stg.in(path_s, (size_t)B * max_path, &d_ps))) return rc;
+    if ((rc = stg.in(x_init, (size_t)B * max_path, &d_x))) return rc;
+    if ((rc = stg.in(y_init, (size_t)B * max_path, &d_y))) return rc;
+    if ((rc = stg.in(heading_init, (size_t)B * max_path, &d_h))) return rc;
+    if ((rc = stg.in(kappa_init, (size_t)B * max_path, &d_k))) return rc;
+    if ((rc = stg.in(n_init, (size_t)B, &d_n))) return rc;
+    if ((rc = stg.out(trajectory, (size_t)B * 7 * stb::kDense, &d_out, false))) return rc;
+    if ((rc = stg.out(status, (size_t)B, &d_st, false))) return rc;
+    if (B) {
+        if (lds > 48 * 1024)
+            EMP_HIP(ctx, hipFuncSetAttribute((const void*)stb::merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KernelTimer t(ctx, "path_speed_merge");
+        hipLaunchKernelGGL(stb::merge_kernel, dim3(B), dim3(64), lds, ctx->stream, B, max_path, d_s, d_v, d_a, d_t, d_now, d_ps,
+                           d_x, d_y, d_h, d_k, d_n, d_out, d_st);
         EMP_LAUNCH_CHECK(ctx);
     }
     return stg.finish();

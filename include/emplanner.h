@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 2
+#define EMP_ABI_VERSION 3
 
 typedef struct emp_ctx emp_ctx;
 
@@ -382,6 +382,58 @@ int emp_st_edge_costs(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int
 
 /* ref: CalcCollisionCost (:274-284): n distances -> n costs */
 int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const double* min_dis, double* cost, emp_mem where);
+
+/* ---- S-T speed planning back end (reference planner/speed_planning_test.py:308-620) ----
+ * Status bits of these four entry points (per scene; the arrays of a flagged scene are NaN): */
+#define EMP_STB_RANGE 2       /* scipy interp1d bounds error / np.interp on an empty path (ValueError in the reference) */
+#define EMP_STB_INDEX 4       /* IndexError in the reference (s_ub[16], dp_speed_s[16], a trajectory without NaN padding) */
+#define EMP_STB_QP_FAILED 8   /* speed QP infeasible or not converged */
+#define EMP_STB_NO_PROFILE 64 /* the profile / trajectory starts with NaN: nothing to work on */
+#define EMP_SPEED_DP_COLS 16
+#define EMP_SPEED_QP_POINTS 17
+#define EMP_SPEED_DENSE_POINTS 401
+
+/* ref: keyword arguments of speed_QP, speed_planning_test.py:410-411 */
+typedef struct emp_speed_qp_params {
+    double w_cost_s_dot2, w_cost_v_ref, w_cost_jerk;    /* 10, 50, 500 */
+    double reference_speed;                             /* 50 */
+} emp_speed_qp_params;
+void emp_speed_qp_params_default(emp_speed_qp_params* p);
+
+/* ref: generate_convex_space (:308-407).  dp_speed_s / dp_speed_t [B][16] (NaN behind the terminal column, as
+ * emp_speed_dp returns them); path_index2s / path_kappa [B][max_path] with path_len[b] entries handed to the
+ * reference (ascending; a zero-padded tail is recognised as in :326-330); obstacle S-T segments [B][n_slots], NaN =
+ * empty.  Outputs s_lb, s_ub, s_dot_lb, s_dot_ub [B][16] (+-inf where unbounded). */
+int emp_speed_convex_space(emp_ctx* ctx, int32_t B, int32_t n_slots, int32_t max_path, double max_lateral_accel,
+                           const double* dp_speed_s, const double* dp_speed_t, const double* path_index2s,
+                           const double* path_kappa, const int32_t* path_len, const double* s_in, const double* s_out,
+                           const double* t_in, const double* t_out, double* s_lb, double* s_ub, double* s_dot_lb,
+                           double* s_dot_ub, int32_t* status, emp_mem where);
+
+/* ref: speed_QP (:410-511).  The reference's call cannot run (untransposed equality matrix, bounds never passed,
+ * ub aliased to lb); this solves the problem it states: piecewise-linear acceleration through qp_size = (valid DP
+ * columns) time stations dt = T / (qp_size - 1) apart, station 0 pinned to (0, plan_start_s_dot, plan_start_s_dot2),
+ * station i >= 1 bounded by column i-1 of the convex space and -6 <= s_dot2 <= 4, s non-decreasing, cost
+ * sum w_a s_dot2^2 + w_v (s_dot - v_ref)^2 + w_j (s_dot2_{i+1} - s_dot2_i)^2.  Outputs [B][17], NaN behind the last
+ * station.  A DP profile without NaN tail is EMP_STB_INDEX, as in the reference (:435). */
+int emp_speed_qp(emp_ctx* ctx, const emp_speed_qp_params* p, int32_t B, const double* plan_start_s_dot,
+                 const double* plan_start_s_dot2, const double* dp_speed_s, const double* dp_speed_t, const double* s_lb,
+                 const double* s_ub, const double* s_dot_lb, const double* s_dot_ub, double* qp_s, double* qp_s_dot,
+                 double* qp_s_dot2, double* relative_time, int32_t* iters, int32_t* status, emp_mem where);
+
+/* ref: increase_points (:514-566): [B][17] profiles -> [B][401] samples (the first sample lies at -dt and the last
+ * interval extrapolates the one before it, as in the reference) */
+int emp_speed_increase_points(emp_ctx* ctx, int32_t B, const double* s_init, const double* s_dot_init,
+                              const double* s_dot2_init, const double* relative_time_init, double* s, double* s_dot,
+                              double* s_dot2, double* relative_time, int32_t* status, emp_mem where);
+
+/* ref: path_speed_merge (:569-620): speed samples [B][401] x path arrays [B][max_path] (n_init[b] entries as handed to
+ * the reference, NaN behind the valid points) -> trajectory [B][7][401] = x, y, heading, kappa, speed, accel, time */
+int emp_path_speed_merge(emp_ctx* ctx, int32_t B, int32_t max_path, const double* s, const double* s_dot,
+                         const double* s_dot2, const double* relative_time, const double* current_time,
+                         const double* path_s, const double* x_init, const double* y_init, const double* heading_init,
+                         const double* kappa_init, const int32_t* n_init, double* trajectory, int32_t* status,
+                         emp_mem where);
 
 #ifdef __cplusplus
 }

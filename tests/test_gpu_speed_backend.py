@@ -1,0 +1,156 @@
+"""GPU parity of the S-T speed planning back end (reference
+planner/speed_planning_test.py:308-620) against golden vectors of the imported reference and oracle/st_backend.py.
+
+Bars: generate_convex_space and path_speed_merge bit-exact against the reference's outputs, statuses equal to the
+exception the reference raises; increase_points 1e-12 relative (the reference squares with libm pow on NumPy scalars,
+the kernel with a multiplication - see emp_st_backend_core.h) and bit-exact against the same arithmetic in NumPy;
+speed_QP: parity unpinned (the reference's call cannot run) - the kernel's minimiser is compared with the dense
+oracle's certified one at 1e-6 and checked against the constraints the reference builds."""
+import numpy as np
+import pytest
+
+from tests.conftest import assert_rel, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pl():
+    from emplanner_carla_amd.api import Planner
+    p = Planner(0)
+    yield p
+    p.close()
+
+
+def _convex_space(pl, g, sel=slice(None)):
+    return pl.speed_convex_space(g["dp_s"][sel], g["dp_t"][sel], g["path_index2s"][sel], g["path_kappa"][sel],
+                                 g["path_len"][sel].astype(np.int32), g["s_in"][sel], g["s_out"][sel], g["t_in"][sel],
+                                 g["t_out"][sel])
+
+
+def test_convex_space_bit_exact_vs_reference(pl):
+    g = load_golden("speed_backend.npz")
+    s_lb, s_ub, v_lb, v_ub, st = _convex_space(pl, g)
+    want_status = np.array([0, 2, 4])[g["cs_raise"]]              # none / ValueError / IndexError
+    np.testing.assert_array_equal(st, want_status)
+    ok = st == 0
+    assert ok.sum() >= 60
+    np.testing.assert_array_equal(np.stack([s_lb, s_ub, v_lb, v_ub], axis=1)[ok], g["cs_out"][ok])
+    assert np.isnan(s_lb[~ok]).all()
+
+
+def test_speed_qp_vs_certified_oracle(pl):
+    from emplanner_carla_amd.api import speed_qp_params
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    sel = np.nonzero(g["qp_code"] >= 0)[0]
+    cs = g["cs_out"][sel]
+    qs, qv, qa, qt, it, st = pl.speed_qp(speed_qp_params(), g["v0"][sel], g["qp_a0"][sel], g["dp_s"][sel], g["dp_t"][sel],
+                                        cs[:, 0], cs[:, 1], cs[:, 2], cs[:, 3])
+    solved = infeasible = 0
+    for k, b in enumerate(sel):
+        if g["qp_code"][b] == 2:                                  # full-length DP profile: IndexError in the reference
+            assert st[k] == 4 and np.isnan(qs[k]).all()
+            continue
+        (os_, ov, oa, ot), res, F = be.speed_qp(float(g["v0"][b]), float(g["qp_a0"][b]), g["dp_s"][b], g["dp_t"][b], *cs[k])
+        n, dt = F["qp_size"], F["dt"]
+        if res is None or res.status != "optimal":
+            assert st[k] == 8, f"case {b}: the oracle found no minimiser, the kernel reports {st[k]}"
+            infeasible += 1
+            continue
+        assert st[k] == 0 and it[k] > 0, f"case {b}: status {st[k]}"
+        np.testing.assert_array_equal(qt[k, :n], np.arange(n) * dt)
+        assert np.isnan(qs[k, n:]).all()
+        assert_rel(qs[k, :n], os_[:n], 1e-6, scale=1.0)
+        assert_rel(qv[k, :n], ov[:n], 1e-6, scale=1.0)
+        assert_rel(qa[k, :n], oa[:n], 1e-6, scale=1.0)
+        # the reference's own matrices: continuity equations and monotone s
+        X = np.stack([qs[k, :n], qv[k, :n], qa[k, :n]], axis=1).reshape(-1)
+        assert np.abs(F["Aeq"].T @ X).max() < 1e-8 * max(1.0, np.abs(X).max())
+        assert (F["A"] @ X <= 1e-8).all()
+        assert (X <= F["ub"] + 1e-7).all() and (X >= F["lb"] - 1e-7).all()
+        solved += 1
+    assert solved >= 25, (solved, infeasible)
+
+
+def _exact_increase_points(qs, qv, qa, qt):
+    """oracle/st_backend.port_increase_points with x * x in place of x ** 2 and the kernel's association."""
+    t_end = int(np.nonzero(np.isnan(qt))[0][0]) - 1
+    dt = qt[t_end] / 400
+    out = np.zeros((4, 401))
+    tmp = 0
+    for i in range(401):
+        cur = (i - 1) * dt
+        for j in range(t_end - 1):
+            if qt[j] <= cur < qt[j + 1]:
+                tmp = j
+                break
+        x = cur - qt[tmp]
+        x2 = x * x
+        out[0, i] = ((qs[tmp] + qv[tmp] * x) + ((1.0 / 3.0) * qa[tmp]) * x2) + ((1.0 / 6.0) * qa[tmp + 1]) * x2
+        out[1, i] = (qv[tmp] + (0.5 * qa[tmp]) * x) + (0.5 * qa[tmp + 1]) * x
+        out[2, i] = qa[tmp] + ((qa[tmp + 1] - qa[tmp]) * x) / (qt[tmp + 1] - qt[tmp])
+        out[3, i] = cur
+    return out
+
+
+def test_increase_points_vs_reference(pl):
+    g = load_golden("speed_backend.npz")
+    sel = np.nonzero(g["dense_raise"] == 0)[0]
+    prof = g["prof"][sel]
+    s, v, a, t, st = pl.speed_increase_points(prof[:, 0], prof[:, 1], prof[:, 2], prof[:, 3])
+    assert (st == 0).all() and len(sel) >= 30
+    got = np.stack([s, v, a, t], axis=1)
+    np.testing.assert_array_equal(got[:, 3], g["dense_out"][sel][:, 3])          # sample times: bit-exact
+    for k in range(len(sel)):
+        np.testing.assert_array_equal(got[k], _exact_increase_points(*prof[k]))
+        for c in range(3):
+            assert_rel(got[k, c], g["dense_out"][sel[k], c], 1e-12, scale=1.0)
+    # a profile without NaN tail: relative_time_init[17] in the reference
+    full = np.tile(np.arange(17.0), (1, 1))
+    _, _, _, _, st = pl.speed_increase_points(full, full, full, full)
+    assert st[0] == 4
+
+
+def test_path_speed_merge_bit_exact_vs_reference(pl):
+    g = load_golden("speed_backend.npz")
+    sel = np.nonzero(g["merge_raise"] >= 0)[0]
+    d = g["dense_out"][sel]
+    n_init = np.full(len(sel), g["merge_x"].shape[1], np.int32)
+    n_init[sel == 1] = g["merge_n"][1]                            # case 1 was handed arrays without NaN padding
+    out, st = pl.path_speed_merge(d[:, 0], d[:, 1], d[:, 2], d[:, 3], g["merge_now"][sel], g["merge_path_s"][sel],
+                                  g["merge_x"][sel], g["merge_y"][sel], g["merge_heading"][sel], g["merge_kappa"][sel], n_init)
+    np.testing.assert_array_equal(st, np.array([0, 2, 4])[g["merge_raise"][sel]])
+    ok = st == 0
+    assert ok.sum() >= 30
+    np.testing.assert_array_equal(out[ok], g["merge_out"][sel][ok])
+
+
+def test_back_end_chain_on_device_tensors(pl):
+    """DP -> convex space -> QP -> densify -> merge without leaving the device; equal to the host-pointer path."""
+    import torch
+    from emplanner_carla_amd.api import speed_qp_params
+    g = load_golden("speed_backend.npz")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    s_lb, s_ub, v_lb, v_ub, st = pl.speed_convex_space(t(g["dp_s"]), t(g["dp_t"]), t(g["path_index2s"]), t(g["path_kappa"]),
+                                                       t(g["path_len"].astype(np.int32)), t(g["s_in"]), t(g["s_out"]),
+                                                       t(g["t_in"]), t(g["t_out"]))
+    qs, qv, qa, qt, it, st2 = pl.speed_qp(speed_qp_params(), t(g["v0"]), t(g["qp_a0"]), t(g["dp_s"]), t(g["dp_t"]), s_lb, s_ub,
+                                          v_lb, v_ub)
+    s, v, a, tt, st3 = pl.speed_increase_points(qs, qv, qa, qt)
+    n_init = np.full(len(g["v0"]), g["merge_x"].shape[1], np.int32)
+    out, st4 = pl.path_speed_merge(s, v, a, tt, t(g["merge_now"]), t(g["merge_path_s"]), t(g["merge_x"]), t(g["merge_y"]),
+                                   t(g["merge_heading"]), t(g["merge_kappa"]), t(n_init))
+    pl.synchronize()
+    st, st2, st3 = st.cpu().numpy(), st2.cpu().numpy(), st3.cpu().numpy()
+    # a scene that failed one stage hands NaN to the next, which flags it too
+    assert ((st != 0) <= (st2 != 0)).all() and ((st2 != 0) <= (st3 != 0)).all()
+    hs = _convex_space(pl, g)
+    np.testing.assert_array_equal(s_lb.cpu().numpy(), hs[0])
+    good = (st2 == 0)
+    assert good.sum() >= 25
+    hq = pl.speed_qp(speed_qp_params(), g["v0"], g["qp_a0"], g["dp_s"], g["dp_t"], *hs[:4])
+    np.testing.assert_array_equal(qs.cpu().numpy()[good], hq[0][good])
+    dense_s = s.cpu().numpy()
+    assert (np.diff(dense_s[good][:, 1:], axis=1) >= -1e-6).all(), "s does not run backwards"
