@@ -1,7 +1,7 @@
 """Drop-in for the S-T speed-DP part of reference planner/speed_planning_test.py (:38-305): same function
 names, argument order, keyword names and defaults; results from the HIP kernels (batch of one scene).
-Line numbers cite the reference file.  The speed QP and the path/speed merge (:308-611) are not part of
-the hot path and are not provided.
+Line numbers cite the reference file.  The back end (:308-620: ``generate_convex_space``, ``speed_QP``,
+``increase_points``, ``path_speed_merge``) is at the bottom of this module.
 
 ``speed_DP`` in the reference cannot return: its backtrack indexes ``s_list`` with a float read from
 ``dp_st_node`` and raises ``IndexError`` (:184) whenever the terminal column is not 0, and its two outputs
@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..api import speed_dp_params, st_grid
+from ..api import STB_INDEX, STB_NO_PROFILE, STB_QP_FAILED, STB_RANGE, speed_dp_params, speed_qp_params, st_grid
 from ._runtime import planner
 
 _MAX_OBS = 64
@@ -92,3 +92,73 @@ def speed_DP(obs_st_s_in_set, obs_st_s_out_set, obs_st_t_in_set, obs_st_t_out_se
         both[col] = res.speed_t[0, col]
         return both, both
     return np.array(res.speed_s[0]), np.array(res.speed_t[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# back end (ref :308-620)
+# ---------------------------------------------------------------------------------------------
+def _row(values, width=None, fill=np.nan):
+    vals = [float(v) for v in values]
+    w = max(len(vals), 1) if width is None else max(width, 1)
+    row = np.full((1, w), fill)
+    k = min(len(vals), w)
+    row[0, :k] = vals[:k]
+    return row
+
+
+def _raise_like_reference(status, what):
+    """Turn a status bit back into the exception the reference raises on the same input."""
+    if status & STB_RANGE:
+        raise ValueError(f"{what}: a value in x_new is outside the interpolation range")
+    if status & (STB_INDEX | STB_NO_PROFILE):
+        raise IndexError(f"{what}: index out of bounds")
+    if status & STB_QP_FAILED:
+        raise ValueError(f"{what}: the speed QP is infeasible or did not converge")
+
+
+def generate_convex_space(dp_speed_s, dp_speed_t, path_index2s, obs_st_s_in_set, obs_st_s_out_set, obs_st_t_in_set,
+                          obs_st_t_out_set, trajectory_kappa_init, max_lateral_accel=0.2 * 9.8):
+    """ref :308-407 -> s_lb, s_ub, s_dot_lb, s_dot_ub (16 each).  ``path_index2s`` must ascend (the reference sorts
+    it inside scipy's interp1d; an ascending array is what ``trajectory_index2s`` produces)."""
+    if len(dp_speed_s) != 16 or len(dp_speed_t) != 16:
+        raise IndexError("dp_speed_s / dp_speed_t must hold 16 columns")           # the reference indexes [i] for i < 16
+    sets, _ = _sets(obs_st_s_in_set, obs_st_s_out_set, obs_st_t_in_set, obs_st_t_out_set)
+    n = len(path_index2s)
+    out = planner().speed_convex_space(_row(dp_speed_s), _row(dp_speed_t), _row(path_index2s, fill=0.0),
+                                       _row(trajectory_kappa_init, width=max(n, 1), fill=0.0), np.array([n], np.int32),
+                                       *sets, max_lateral_accel=max_lateral_accel)
+    _raise_like_reference(int(out[4][0]), "generate_convex_space")
+    return tuple(np.array(o[0]) for o in out[:4])
+
+
+def speed_QP(plan_start_s_dot, plan_start_s_dot2, dp_speed_s, dp_speed_t, s_lb, s_ub, s_dot_lb, s_dot_ub,
+             w_cost_s_dot2=10, w_cost_v_ref=50, w_cost_jerk=500, reference_speed=50):
+    """ref :410-511 -> qp_s_init, qp_s_dot_init, qp_s_dot2_init, relative_time_init (17 each, NaN padded).
+
+    The reference's own call raises TypeError inside cvxopt (it passes the equality matrix untransposed, never passes
+    its bounds, and aliases ub to lb); this solves the problem the function states, see include/emplanner.h."""
+    p = speed_qp_params(w_cost_s_dot2, w_cost_v_ref, w_cost_jerk, reference_speed)
+    out = planner().speed_qp(p, np.array([float(plan_start_s_dot)]), np.array([float(plan_start_s_dot2)]), _row(dp_speed_s),
+                             _row(dp_speed_t), _row(s_lb), _row(s_ub), _row(s_dot_lb), _row(s_dot_ub))
+    _raise_like_reference(int(out[5][0]), "speed_QP")
+    return tuple(np.array(o[0]) for o in out[:4])
+
+
+def increase_points(s_init, s_dot_init, s_dot2_init, relative_time_init):
+    """ref :514-566 -> s, s_dot, s_dot2, relative_time (401 each)."""
+    out = planner().speed_increase_points(_row(s_init, 17), _row(s_dot_init, 17), _row(s_dot2_init, 17),
+                                          _row(relative_time_init, 17))
+    _raise_like_reference(int(out[4][0]), "increase_points")
+    return tuple(np.array(o[0]) for o in out[:4])
+
+
+def path_speed_merge(s, s_dot, s_dot2, relative_time, current_time, path_s, trajectory_x_init, trajectory_y_init,
+                     trajectory_heading_init, trajectory_kappa_init):
+    """ref :569-620 -> trajectory_x, _y, _heading, _kappa, _speed, _accel, _time (401 each)."""
+    n = len(trajectory_x_init)
+    out, st = planner().path_speed_merge(_row(s, 401), _row(s_dot, 401), _row(s_dot2, 401), _row(relative_time, 401),
+                                         np.array([float(current_time)]), _row(path_s, width=n, fill=0.0),
+                                         _row(trajectory_x_init), _row(trajectory_y_init), _row(trajectory_heading_init),
+                                         _row(trajectory_kappa_init), np.array([n], np.int32))
+    _raise_like_reference(int(st[0]), "path_speed_merge")
+    return tuple(np.array(out[0, c]) for c in range(7))

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "..", "..", "emplanner_carla_amd", "csrc")
 
 
 def load():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("emp_core.h", "emp_frenet_core.h", "emp_qp_core.h", "emp_st_core.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("emp_core.h", "emp_frenet_core.h", "emp_qp_core.h", "emp_st_core.h", "emp_st_backend_core.h")]
     if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT],
@@ -37,4 +37,12 @@ def load():
     lib.hc_st_grid.argtypes = [p, p]
     lib.hc_st_terminal.restype = i
     lib.hc_st_terminal.argtypes = [p, p, p]
+    lib.hc_stb_convex_space.restype = i
+    lib.hc_stb_convex_space.argtypes = [p, p, p, p, i, p, p, p, p, i, d, p, p, p, p]
+    lib.hc_stb_speed_qp.restype = i
+    lib.hc_stb_speed_qp.argtypes = [p, p, d, d, p, p, p, p, p, p, p, p, p, p]
+    lib.hc_stb_increase_points.restype = i
+    lib.hc_stb_increase_points.argtypes = [p] * 8
+    lib.hc_stb_np_interp.restype = d
+    lib.hc_stb_np_interp.argtypes = [p, p, i, d]
     return lib

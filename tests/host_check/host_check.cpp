@@ -6,6 +6,7 @@
 #include "../../emplanner_carla_amd/csrc/emp_frenet_core.h"
 #include "../../emplanner_carla_amd/csrc/emp_qp_core.h"
 #include "../../emplanner_carla_amd/csrc/emp_st_core.h"
+#include "../../emplanner_carla_amd/csrc/emp_st_backend_core.h"
 
 using namespace emp;
 
@@ -71,6 +72,44 @@ void hc_st_grid(double* s_rows, double* t_cols) {
 
 int hc_st_terminal(const double* cost, int* row, int* col) {
     return st::terminal_node([&](int r, int c) { return cost[r * st::kCols + c]; }, row, col) ? 1 : 0;
+}
+
+
+// ---- S-T speed planning back end (emp_st_backend_core.h) ------------------------------------
+int hc_stb_convex_space(const double* dp_s, const double* dp_t, const double* idx2s, const double* kappa, int path_len,
+                        const double* s_in, const double* s_out, const double* t_in, const double* t_out, int n_slots,
+                        double max_lat, double* s_lb, double* s_ub, double* sd_lb, double* sd_ub) {
+    return stb::convex_space(dp_s, dp_t, idx2s, kappa, path_len, s_in, s_out, t_in, t_out, n_slots, max_lat, s_lb, s_ub,
+                             sd_lb, sd_ub);
+}
+
+int hc_stb_speed_qp(const double* dp_s, const double* dp_t, double v0, double a0, const double* s_lb, const double* s_ub,
+                    const double* sd_lb, const double* sd_ub, const double* w4, double* qs, double* qv, double* qa,
+                    double* qt, int* iters) {
+    static double mem[stb::speed_qp_words(stb::kQp)];
+    const stb::SpeedQpParams prm{w4[0], w4[1], w4[2], w4[3]};
+    return stb::speed_qp_solve_scalar(mem, dp_s, dp_t, v0, a0, s_lb, s_ub, sd_lb, sd_ub, prm, qs, qv, qa, qt, iters);
+}
+
+// increase_points with the kernel's structure: match per sample, running maximum as the sticky interval
+int hc_stb_increase_points(const double* qs, const double* qv, const double* qa, const double* qt, double* s, double* v,
+                           double* a, double* t) {
+    const int t_end = stb::dense_t_end(qt);
+    if (t_end >= stb::kQp || t_end < 0) return t_end < 0 ? stb::kStbNoProfile : stb::kStbIndex;
+    const double dt = qt[t_end] / (double)(stb::kDense - 1);
+    int tmp = 0;
+    for (int i = 0; i < stb::kDense; ++i) {
+        const double cur = (double)(i - 1) * dt;
+        const int m = stb::dense_match(qt, t_end, cur);
+        if (m > tmp) tmp = m;
+        stb::dense_sample(qs, qv, qa, qt, tmp, cur, &s[i], &v[i], &a[i]);
+        t[i] = cur;
+    }
+    return 0;
+}
+
+double hc_stb_np_interp(const double* xp, const double* fp, int n, double x) {
+    return stb::np_interp_at(xp, fp, n, (x != x) ? 0 : stb::np_interp_index(xp, n, x), x);
 }
 
 }  // extern "C"

@@ -244,3 +244,65 @@ def test_st_core_pruning_is_exact(hc):
         want = float(st_speed.exact_obs_cost(s0, t0, s1, t0 + 0.5, s_in, s_out, t_in, t_out, 10000000.0))
         worst = max(worst, abs(obs.value - want) / max(1.0, abs(want)))
     assert worst <= 1e-13
+
+
+# --------------------------------------------------------------------------------------
+# S-T speed planning back end: the scalar core the kernels call (emp_st_backend_core.h) against the reference's
+# golden vectors and oracle/st_backend.py - no GPU involved
+# --------------------------------------------------------------------------------------
+def test_stb_core_convex_space_and_interp_vs_reference_golden(hc):
+    g = load_golden("speed_backend.npz")
+    ptr = lambda a: a.ctypes.data
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    ran = 0
+    for b in range(len(g["v0"])):
+        n = int(g["path_len"][b])
+        outs = [np.zeros(16) for _ in range(4)]
+        ins = [c(g[k][b]) for k in ("dp_s", "dp_t", "path_index2s", "path_kappa")]
+        sets = [c(g[k][b]) for k in ("s_in", "s_out", "t_in", "t_out")]
+        st = hc.hc_stb_convex_space(*[ptr(a) for a in ins], n, *[ptr(a) for a in sets], 16, 0.2 * 9.8, *[ptr(a) for a in outs])
+        assert st == [0, 2, 4][int(g["cs_raise"][b])]
+        if st == 0:
+            np.testing.assert_array_equal(np.stack(outs), g["cs_out"][b])
+            ran += 1
+    assert ran >= 60
+    # numpy.interp, knot hits and clamped ends included
+    rng = np.random.default_rng(3)
+    xp = np.cumsum(rng.uniform(0.5, 1.5, 40))
+    fp = rng.normal(size=40)
+    xs = np.concatenate([xp[[0, 7, 39]], rng.uniform(xp[0] - 2, xp[-1] + 2, 500), [np.nan]])
+    got = np.array([hc.hc_stb_np_interp(ptr(xp), ptr(fp), 40, float(x)) for x in xs])
+    np.testing.assert_array_equal(got, np.interp(xs, xp, fp))
+
+
+def test_stb_core_speed_qp_and_increase_points(hc):
+    from oracle import st_backend as be
+    g = load_golden("speed_backend.npz")
+    ptr = lambda a: a.ctypes.data
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    w4 = np.array([10.0, 50.0, 500.0, 50.0])
+    solved = 0
+    for b in np.nonzero(g["qp_code"] >= 0)[0]:
+        outs = [np.zeros(17) for _ in range(4)]
+        iters = C.c_int(0)
+        cs = [c(g["cs_out"][b, k]) for k in range(4)]
+        st = hc.hc_stb_speed_qp(ptr(c(g["dp_s"][b])), ptr(c(g["dp_t"][b])), float(g["v0"][b]), float(g["qp_a0"][b]),
+                                *[ptr(a) for a in cs], ptr(w4), *[ptr(a) for a in outs], C.byref(iters))
+        if g["qp_code"][b] == 2:
+            assert st == 4
+            continue
+        if np.isnan(g["prof"][b]).all():                  # the dense oracle found the corridor infeasible
+            assert st == 8
+            continue
+        assert st == 0 and 0 < iters.value < 60
+        k = int(g["qp_size"][b])
+        assert_rel(np.stack(outs)[:, :k], g["prof"][b][:, :k], 1e-6, scale=1.0)
+        assert np.isnan(np.stack(outs)[:, k:]).all()
+        solved += 1
+    assert solved >= 25
+    for b in np.nonzero(g["dense_raise"] == 0)[0]:
+        prof = [c(g["prof"][b, k]) for k in range(4)]
+        outs = [np.zeros(401) for _ in range(4)]
+        assert hc.hc_stb_increase_points(*[ptr(a) for a in prof], *[ptr(a) for a in outs]) == 0
+        np.testing.assert_array_equal(outs[3], g["dense_out"][b, 3])
+        assert_rel(np.stack(outs[:3]), g["dense_out"][b, :3], 1e-12, scale=1.0)
