@@ -44,8 +44,12 @@ EMP_HD Interp interp1d(FX x, FY y, int n, double x_new) {
         r.out_of_range = true;
         return r;
     }
-    int idx = 0;                    // first index with x[idx] >= x_new  (searchsorted, side='left')
-    while (idx < n && x(idx) < x_new) ++idx;
+    int idx = 0, hi = n;            // first index with x[idx] >= x_new  (searchsorted, side='left'): bisection
+    while (idx < hi) {
+        const int mid = (idx + hi) >> 1;
+        if (x(mid) < x_new) idx = mid + 1;
+        else hi = mid;
+    }
     if (idx < 1) idx = 1;
     if (idx > n - 1) idx = n - 1;
     const double xlo = x(idx - 1), xhi = x(idx), ylo = y(idx - 1), yhi = y(idx);

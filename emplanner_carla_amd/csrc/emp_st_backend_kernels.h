@@ -23,9 +23,14 @@ __global__ __launch_bounds__(64) void convex_space_kernel(
     const int* __restrict__ path_len, const double* __restrict__ s_in, const double* __restrict__ s_out,
     const double* __restrict__ t_in, const double* __restrict__ t_out, double* __restrict__ s_lb,
     double* __restrict__ s_ub, double* __restrict__ sd_lb, double* __restrict__ sd_ub, int* __restrict__ status) {
+    // the six 16-entry arrays of a lane are indexed at run time: LDS, not registers (a lane's block is 97 doubles
+    // long, an odd stride, so the lanes of a wavefront spread over the banks)
+    constexpr int kLaneWords = 6 * kDp + 1;
+    __shared__ double lane_mem[64 * kLaneWords];
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    double lb[kDp], ub[kDp], vlb[kDp], vub[kDp], ds[kDp], dt[kDp];
+    double* mine = lane_mem + threadIdx.x * kLaneWords;
+    double *lb = mine, *ub = mine + kDp, *vlb = mine + 2 * kDp, *vub = mine + 3 * kDp, *ds = mine + 4 * kDp, *dt = mine + 5 * kDp;
     for (int i = 0; i < kDp; ++i) {
         ds[i] = dp_s[(size_t)b * kDp + i];
         dt[i] = dp_t[(size_t)b * kDp + i];

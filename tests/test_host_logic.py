@@ -286,7 +286,8 @@ def test_stb_core_speed_qp_and_increase_points(hc):
         outs = [np.zeros(17) for _ in range(4)]
         iters = C.c_int(0)
         cs = [c(g["cs_out"][b, k]) for k in range(4)]
-        st = hc.hc_stb_speed_qp(ptr(c(g["dp_s"][b])), ptr(c(g["dp_t"][b])), float(g["v0"][b]), float(g["qp_a0"][b]),
+        dps, dpt = c(g["dp_s"][b]), c(g["dp_t"][b])         # named: the arrays must outlive the call
+        st = hc.hc_stb_speed_qp(ptr(dps), ptr(dpt), float(g["v0"][b]), float(g["qp_a0"][b]),
                                 *[ptr(a) for a in cs], ptr(w4), *[ptr(a) for a in outs], C.byref(iters))
         if g["qp_code"][b] == 2:
             assert st == 4
