@@ -137,7 +137,8 @@ EMP_HD int convex_space(const double* dp_s, const double* dp_t, const double* id
 // (separate lb / ub; the reference aliases them and never passes them, see oracle/st_backend.py).
 // ---------------------------------------------------------------------------------------------
 using SpeedRangeQp = RangeQp<3, 4, 4>;
-constexpr double kSpeedBig = 1e6;          // stands in for an infinite bound (curvature bounds reach 1.4e5 m/s)
+constexpr double kSpeedBig = 1e4;          // stands in for an infinite bound: no s (m) or s_dot (m/s) of an 8 s horizon with
+                                           // s_dot2 <= 4 comes near it (curvature bounds on straights reach 1.4e5 m/s)
 
 struct SpeedQpParams {
     double w_s_dot2, w_v_ref, w_jerk, v_ref;
