@@ -91,28 +91,35 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     if (d.B == 0) return EMP_OK;
     static const int variant = getenv("EMP_SWEEP_VARIANT") ? atoi(getenv("EMP_SWEEP_VARIANT")) : 0;
     KernelTimer t(ctx, "dp_sweep", true);   // the roofline kernel: events stamped by the dispatch itself
-#define EMP_SWEEP(R, PD, WPB)                                                                               \
+#define EMP_SWEEP(R, PD, WPB) EMP_SWEEP_NT(R, PD, WPB, false)
+#define EMP_SWEEP_NT(R, PD, WPB, NT)                                                                        \
     do {                                                                                                    \
         const size_t lds = (size_t)(WPB) * (d.col * 64 + 64 * sizeof(double));                              \
         EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the predecessor table in LDS");           \
         if (lds > 48 * 1024)                                                                                \
-            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB>,                      \
+            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB, NT>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-        hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+        hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
                               ctx->stream, t.start, t.stop, 0, d, start_cost, edge, n_obs, rows, min_cost, status); \
     } while (0)
+    // Ring depth PD (columns in flight per wavefront), measured at 4096 scenes: 2 is best for rows 5..12 (row 9:
+    // 20.4 us against 23.2 at PD = 8, 21.4 at PD = 1), 3 for the 21-row lattice; nontemporal loads change nothing.
+    // EMP_SWEEP_VARIANT selects alternatives for the 9-row lattice (development).
     switch (d.row) {
-        case 5: EMP_SWEEP(5, 12, 1); break;
+        case 5: EMP_SWEEP(5, 2, 1); break;
         case 9:
-            if (variant == 1) EMP_SWEEP(9, 12, 1);
-            else if (variant == 2) EMP_SWEEP(9, 16, 1);
-            else EMP_SWEEP(9, 8, 1);
+            if (variant == 1) EMP_SWEEP(9, 3, 1);
+            else if (variant == 2) EMP_SWEEP(9, 4, 1);
+            else if (variant == 3) EMP_SWEEP(9, 8, 1);
+            else if (variant == 4) EMP_SWEEP_NT(9, 2, 1, true);
+            else EMP_SWEEP(9, 2, 1);
             break;
-        case 12: EMP_SWEEP(12, 8, 1); break;
-        case 21: EMP_SWEEP(21, 6, 1); break;
+        case 12: EMP_SWEEP(12, 2, 1); break;
+        case 21: EMP_SWEEP(21, 3, 1); break;
         default: EMP_SWEEP(0, 1, 1); break;
     }
 #undef EMP_SWEEP
+#undef EMP_SWEEP_NT
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
 // One wavefront per tile of S scenes; block = WPB wavefronts.  LDS: predecessor bytes [wave][col][64].
 // ROW > 0: compile-time row count, register double buffer of PD columns (loads for the next group are
 // in flight while the current group is reduced).  ROW == 0: generic fallback with a runtime row count.
-template <int ROW, int PD, int WPB>
+template <int ROW, int PD, int WPB, bool NT = false>
 __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const double* __restrict__ start_cost,
                                                        const double* __restrict__ edge,
                                                        const int* __restrict__ n_obs,
@@ -251,17 +251,18 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
     };
 
     if constexpr (ROW > 0) {
-        // Register ring of PD columns: column j's edges are loaded PD columns before they are reduced, so one
-        // wavefront keeps PD*ROW 512-byte rows in flight (the reduction of one column takes ~0.15 us, memory
-        // latency ~1-2 us: the ring must be >= ~12 columns deep to hide it).  Columns past the end re-read the
-        // last column (never used), which keeps the loads unconditional and the code straight-line.
+        // Register ring of PD columns: column j's edges are loaded PD columns before they are reduced.  A shallow
+        // ring wins (PD = 2 at 9 rows: 18 rows of 512 B in flight per wavefront): the launch is limited by reading
+        // the tensor, not by load latency, and a deeper ring only lengthens the prologue and the register file.
+        // Columns past the end re-read the last column (never used), which keeps the loads unconditional and the
+        // code straight-line.
         const int last_col = P.col - 1;
         double ring[PD][ROW];
         auto load_col = [&](double (&dst)[ROW], int jcol) {
             const int j = min(jcol, last_col);
             const double* src = tile_edge + (size_t)(j - 1) * ROW * 64;
 #pragma unroll
-            for (int k = 0; k < ROW; ++k) dst[k] = src[k * 64];
+            for (int k = 0; k < ROW; ++k) dst[k] = NT ? __builtin_nontemporal_load(&src[k * 64]) : src[k * 64];   // read once: nontemporal
         };
         // The predecessor of column j is extracted one column late: its 2 * ROW compare / select instructions
         // would otherwise sit, in program order, between the new cost and the next column's LDS exchange.  Issued

@@ -7,7 +7,7 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
-template <int PD, int ROW>
+template <int PD, int ROW, bool NT = false>
 __global__ __launch_bounds__(64) void stream8(const double* __restrict__ src, double* out, int rows_per_wave) {
     const double* p = src + (size_t)blockIdx.x * rows_per_wave * 64 + threadIdx.x;
     double acc[ROW];
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) void stream8(const double* __restrict__ src, do
 #pragma unroll
     for (int d = 0; d < PD; ++d)
 #pragma unroll
-        for (int k = 0; k < ROW; ++k) ring[d][k] = p[(size_t)(min(d, ncol - 1) * ROW + k) * 64];
+        for (int k = 0; k < ROW; ++k) ring[d][k] = NT ? __builtin_nontemporal_load(&p[(size_t)(min(d, ncol - 1) * ROW + k) * 64]) : p[(size_t)(min(d, ncol - 1) * ROW + k) * 64];
     for (int j0 = 0; j0 < ncol; j0 += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void stream8(const double* __restrict__ src, do
             for (int k = 0; k < ROW; ++k) acc[k] = fmin(acc[k], ring[d][k]);
             const int j = min(j0 + d + PD, ncol - 1);
 #pragma unroll
-            for (int k = 0; k < ROW; ++k) ring[d][k] = p[(size_t)(j * ROW + k) * 64];
+            for (int k = 0; k < ROW; ++k) ring[d][k] = NT ? __builtin_nontemporal_load(&p[(size_t)(j * ROW + k) * 64]) : p[(size_t)(j * ROW + k) * 64];
         }
     }
     double s = 0;
@@ -90,6 +90,8 @@ int main(int argc, char** argv) {
     auto report = [&](const char* name, double us) { printf("%-28s %7.2f us  %6.0f GB/s\n", name, us, bytes / us / 1e3); };
     report("8B/lane  PD=4", time_us([&] { hipLaunchKernelGGL((stream8<4, 9>), dim3(waves), dim3(64), 0, 0, buf[r++ % 3], out, rows); }, 30));
     report("8B/lane  PD=8", time_us([&] { hipLaunchKernelGGL((stream8<8, 9>), dim3(waves), dim3(64), 0, 0, buf[r++ % 3], out, rows); }, 30));
+    report("8B/lane  PD=8 nontemporal", time_us([&] { hipLaunchKernelGGL((stream8<8, 9, true>), dim3(waves), dim3(64), 0, 0, buf[r++ % 3], out, rows); }, 30));
+    report("8B/lane  PD=4 nontemporal", time_us([&] { hipLaunchKernelGGL((stream8<4, 9, true>), dim3(waves), dim3(64), 0, 0, buf[r++ % 3], out, rows); }, 30));
     report("8B/lane  PD=13", time_us([&] { hipLaunchKernelGGL((stream8<13, 9>), dim3(waves), dim3(64), 0, 0, buf[r++ % 3], out, rows); }, 30));
     // 16 B mode: 39*9 rows of 512 B = 175.5 rows of 1024 B -> 20 "columns" of 9 rows (2.5 % more bytes)
     const int rows16 = 20 * 9;
