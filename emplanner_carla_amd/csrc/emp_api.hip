@@ -48,7 +48,7 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     int ncol = d.col - 1;
     int chunks = 1;
     if (ncol > 0) {
-        chunks = (2048 + d.tiles - 1) / d.tiles;
+        chunks = (2048 + d.tiles - 1) / d.tiles;      // ~2000-8000 blocks measure the same; fewer are slower
         if (chunks > ncol) chunks = ncol;
         if (chunks < 1) chunks = 1;
     }
