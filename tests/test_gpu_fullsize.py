@@ -163,3 +163,84 @@ def test_configs3_32768_scenes_and_rank_shards(planner):
     outp = _plan_resident(planner, cfg, host, perm)
     _assert_same({k: v[perm] for k, v in out.items()}, outp, "permuted batch")
     _check_properties(planner, cfg, host, out)
+
+
+def _moved(host, phi, shift):
+    B = len(phi)
+    c, s = np.cos(phi), np.sin(phi)
+
+    def rot(xy):                                   # (B, ..., 2) vectors
+        x, y = xy[..., 0], xy[..., 1]
+        cc = c.reshape((B,) + (1,) * (x.ndim - 1))
+        ss = s.reshape((B,) + (1,) * (x.ndim - 1))
+        return np.stack([cc * x - ss * y, ss * x + cc * y], axis=-1)
+
+    moved = dict(host)
+    ref = host["ref_line"].copy()
+    ref[..., :2] = rot(host["ref_line"][..., :2]) + shift[:, None, :]
+    ref[..., 2] = host["ref_line"][..., 2] + phi[:, None]
+    moved["ref_line"] = ref
+    for k in ("origin_xy", "start_xy"):
+        moved[k] = rot(host[k]) + shift
+    for k in ("start_v", "start_a"):
+        moved[k] = rot(host[k])
+    moved["obs_xy"] = rot(host["obs_xy"]) + shift[:, None, :]
+    return moved
+
+
+def _back(xy, phi, shift):
+    c, s = np.cos(phi)[:, None], np.sin(phi)[:, None]
+    d = xy - shift[:, None, :]
+    return np.stack([c * d[..., 0] + s * d[..., 1], -s * d[..., 0] + c * d[..., 1]], axis=-1)
+
+
+def test_rigid_motion_of_the_scene_moves_the_plan_with_it(planner):
+    """Move every scene of the 4096 batch (reference line, ego state, obstacles) and plan again: the Frenet-frame
+    results (DP rows, path s / l) must not change, the un-smoothed Cartesian path must move with the scene under any
+    rigid motion, and the smoothed trajectory under a translation (its +-0.2 m boxes are aligned with the global axes,
+    planning_utils.py:308-311, so a rotation legitimately changes it).  Holds for the reference up to rounding; here it
+    checks projection, DP, QP and the Cartesian tail against each other on poses the golden vectors do not contain."""
+    cfg = S.CFG2
+    B = 4096
+    m = 23
+    batch = S.make_batch(range(B), cfg)
+    host = _host_inputs(batch)
+    out = _plan_resident(planner, cfg, host)
+    rng = np.random.default_rng(5)
+
+    def targets(h, o):
+        sm, _, _, bsl, _ = planner.frenet_project(**h)
+        return planner.frenet_path_to_xy(h["ref_line"], sm, h["n_ref"], bsl, o["path_s"], o["path_l"], o["path_len"])[0]
+
+    for kind in ("rigid", "translation"):
+        phi = rng.uniform(-np.pi, np.pi, B) if kind == "rigid" else np.zeros(B)
+        shift = rng.uniform(-500.0, 500.0, (B, 2))
+        moved = _moved(host, phi, shift)
+        outm = _plan_resident(planner, cfg, moved)
+        ok = ((out["status"] & ~1) == 0) & ((outm["status"] & ~1) == 0)
+        assert (out["status"] == outm["status"]).mean() > 0.995
+        same_rows = (out["dp_rows"] == outm["dp_rows"]).all(axis=1)
+        assert same_rows[ok].mean() > 0.995, "a DP decision may flip on a near-tie, but rarely"
+        sel = ok & same_rows
+        assert sel.sum() > 3000
+        assert (out["traj_len"][sel] == m).all() and (outm["traj_len"][sel] == m).all()
+        assert np.abs(out["path_s"][sel][:, :m - 1] - outm["path_s"][sel][:, :m - 1]).max() < 1e-6, kind
+        assert np.abs(out["path_l"][sel][:, :m - 1] - outm["path_l"][sel][:, :m - 1]).max() < 1e-6, kind
+        t0, t1 = targets(host, out), targets(moved, outm)
+        # A station within rounding of a reference-line knot may project from the neighbouring node in the other pose
+        # (cal_proj_point walks `while s_map[idx + 1] < s`, path_planning.py:62-63), which moves it by O(kappa ds^2),
+        # about a millimetre.  The synthetic scenes put the planning start on the normal through a node, so every
+        # fourth station sits on a knot: those points get 5 mm, all others 1e-6.
+        sm = planner.frenet_project(**host)[0]
+        bsl = planner.frenet_project(**host)[3]
+        st_s = np.concatenate([bsl[:, :1], out["path_s"][:, :m - 1]], axis=1)            # s of trajectory point k
+        on_knot = (np.abs(st_s[:, :, None] - sm[:, None, :]).min(axis=2) < 1e-6)[sel]
+        d = np.abs(_back(t1[:, :m], phi, shift)[sel] - t0[sel][:, :m]).max(axis=2)
+        assert on_knot.mean() < 0.5 and d[~on_knot].max() < 1e-6 and d.max() < 5e-3, (kind, d[~on_knot].max(), d.max())
+        moved_traj = _back(outm["traj"][:, :m, :2], phi, shift)[sel] - out["traj"][sel][:, :m, :2]
+        if kind == "translation":                      # smoothing couples the points: millimetres everywhere
+            assert np.abs(moved_traj).max() < 5e-3
+            assert np.abs(outm["traj"][sel][:, 2:m, 2] - out["traj"][sel][:, 2:m, 2]).max() < 5e-3
+            assert np.abs(outm["traj"][sel][:, 2:m, 3] - out["traj"][sel][:, 2:m, 3]).max() < 5e-3
+        else:                                          # the boxes bound how far the smoothed points can drift apart
+            assert np.abs(moved_traj).max() < 0.4 * np.sqrt(2) + 1e-6
