@@ -191,3 +191,82 @@ def test_dropin_back_end_functions(pl):
     with pytest.raises(IndexError):
         sp.path_speed_merge(*g["dense_out"][b], 0.0, g["merge_path_s"][1, :w], g["merge_x"][1, :w], g["merge_y"][1, :w],
                             g["merge_heading"][1, :w], g["merge_kappa"][1, :w])
+
+
+def test_back_end_fuzz_vs_port(pl):
+    """300 random cases beyond the golden set against oracle/st_backend.py's ports (themselves bit-identical to the
+    reference on the golden set): convex space and merge bit-exact, statuses equal to the exceptions raised."""
+    from oracle import st_backend as be
+    rng = np.random.default_rng(99)
+    B, K, P = 300, 12, 70
+    dp_s = np.full((B, 16), np.nan)
+    dp_t = np.full((B, 16), np.nan)
+    idx2s = np.zeros((B, P))
+    kappa = np.zeros((B, P))
+    path_len = np.zeros(B, np.int32)
+    sets = [np.full((B, K), np.nan) for _ in range(4)]
+    for b in range(B):
+        n = int(rng.integers(1, 17))
+        v = rng.uniform(1.0, 9.0)
+        dp_t[b, :n] = 0.5 * (np.arange(n) + 1)
+        dp_s[b, :n] = np.cumsum(rng.uniform(0.3, 1.2, n) * v * 0.5)
+        npth = int(rng.integers(20, P + 1))
+        s = np.concatenate(([0.0], np.cumsum(rng.uniform(0.8, 1.6, npth - 1))))
+        idx2s[b, :npth] = s
+        kappa[b, :npth] = rng.normal(0, 0.02, npth)
+        path_len[b] = npth if rng.random() < 0.5 else P
+        k = int(rng.integers(0, K + 1))
+        slots = rng.choice(K, k, replace=False)
+        t_in = rng.uniform(0.0, 7.0, k)
+        sets[2][b, slots] = t_in
+        sets[3][b, slots] = t_in + rng.uniform(0.3, 3.0, k)
+        s_in = rng.uniform(0.0, 50.0, k)
+        sets[0][b, slots] = s_in
+        sets[1][b, slots] = s_in + rng.uniform(-4.0, 12.0, k)
+    out = pl.speed_convex_space(dp_s, dp_t, idx2s, kappa, path_len, *sets)
+    st = out[4]
+    seen = set()
+    for b in range(B):
+        n = int(path_len[b])
+        try:
+            want = be.port_generate_convex_space(dp_s[b], dp_t[b], idx2s[b, :n], sets[0][b], sets[1][b], sets[2][b],
+                                                 sets[3][b], kappa[b, :n])
+            code = 0
+        except ValueError:
+            code = 2
+        except IndexError:
+            code = 4
+        assert st[b] == code, f"case {b}: status {st[b]}, the reference {code}"
+        seen.add(code)
+        if code == 0:
+            np.testing.assert_array_equal(np.stack([o[b] for o in out[:4]]), np.stack(want))
+    assert seen == {0, 2, 4}
+    # densify + merge on smooth random profiles
+    prof = np.full((B, 4, 17), np.nan)
+    for b in range(B):
+        n = int(rng.integers(2, 17))
+        dt = rng.uniform(0.3, 0.7)
+        a = rng.uniform(-2, 2, n)
+        v = np.maximum(0.2, 5 + np.cumsum(a) * dt)
+        prof[b, 0, :n] = np.concatenate(([0.0], np.cumsum(v[:-1] * dt)))
+        prof[b, 1, :n], prof[b, 2, :n], prof[b, 3, :n] = v, a, np.arange(n) * dt
+    s, v, a, t, st = pl.speed_increase_points(prof[:, 0], prof[:, 1], prof[:, 2], prof[:, 3])
+    assert (st == 0).all()
+    for b in range(0, B, 3):
+        want = np.stack(be.port_increase_points(*prof[b]))
+        np.testing.assert_array_equal(t[b], want[3])
+        assert_rel(np.stack([s[b], v[b], a[b]]), want[:3], 1e-12, scale=1.0)
+    W = 80
+    px, py, ph, pk = (np.full((B, W), np.nan) for _ in range(4))
+    ps = np.zeros((B, W))
+    n_valid = rng.integers(3, W - 1, B)
+    for b in range(B):
+        n = n_valid[b]
+        ps[b, :n] = np.concatenate(([0.0], np.cumsum(rng.uniform(0.5, 1.5, n - 1))))
+        px[b, :n], py[b, :n], ph[b, :n], pk[b, :n] = rng.normal(size=(4, n)).cumsum(axis=1)
+    now = rng.uniform(0, 50, B)
+    out, st = pl.path_speed_merge(s, v, a, t, now, ps, px, py, ph, pk, np.full(B, W, np.int32))
+    assert (st == 0).all()
+    for b in range(0, B, 3):
+        want = np.stack(be.port_path_speed_merge(s[b], v[b], a[b], t[b], float(now[b]), ps[b], px[b], py[b], ph[b], pk[b]))
+        np.testing.assert_array_equal(out[b], want)
