@@ -1143,7 +1143,7 @@ static emp::StDev make_st_dev(const emp_speed_dp_params* p, int B, int max_obs) 
     d.w.v_ref = p->reference_speed;
     d.w.w_ref = p->w_cost_ref_speed;
     d.w.w_acc = p->w_cost_accel;
-    d.w.w_obs = p->w_cost_obs;
+    d.w.w_obs = emp::st::make_pow_base(p->w_cost_obs);
     return d;
 }
 
@@ -1258,7 +1258,7 @@ int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const doub
     if ((rc = stg.in(min_dis, (size_t)n, &d_d))) return rc;
     if ((rc = stg.out(cost, (size_t)n, &d_c, false))) return rc;
     if (n) {
-        hipLaunchKernelGGL(st_collision_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, w_cost_obs, d_d, d_c);
+        hipLaunchKernelGGL(st_collision_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, st::make_pow_base(w_cost_obs), d_d, d_c);
         EMP_LAUNCH_CHECK(ctx);
     }
     return stg.finish();

@@ -48,16 +48,41 @@ EMP_HD double div_dt(double x, double dt) { return dt == 0.5 ? x * 2.0 : x / dt;
 #define EMP_ST_COLD __attribute__((noinline))
 #endif
 
+// w ** y for the collision cost's base (ref :281: w_cost_obs ** ((0.5 - min_dis) + 1)).  The base is fixed per call,
+// so log2(w) is computed once on the host as a double-double and the kernels evaluate exp2(y * log2 w): the product
+// exactly (fma), exp2 of its head, first-order correction for its tail - within 2 ulp of the true power, against
+// < 1 ulp for libm's pow, at a fifth of the instructions of the general pow() expansion (which was 30 % of the speed
+// DP kernel).  A base that is not a positive finite number falls back to pow() and its special cases.
+struct PowBase {
+    double w, lg_hi, lg_lo;
+};
+inline PowBase make_pow_base(double w) {        // host side (the library's launchers, tests/host_check)
+    PowBase b{w, NAN, 0.0};
+    if (w > 0.0 && w < INFINITY) {
+        const long double L = log2l((long double)w);
+        b.lg_hi = (double)L;
+        b.lg_lo = (double)(L - (long double)b.lg_hi);
+    }
+    return b;
+}
+EMP_HD double pow_base(const PowBase& b, double y) {
+    if (!(b.lg_hi == b.lg_hi)) return pow(b.w, y);
+    const double p = y * b.lg_hi;
+    const double tail = fma(y, b.lg_hi, -p) + y * b.lg_lo;
+    const double r = exp2(p);
+    return fma(r, 0.6931471805599453 * tail, r);
+}
+
 // ref :274-284 (CalcCollisionCost)
-EMP_HD double collision_cost(double w, double d) {
+EMP_HD double collision_cost(const PowBase& w, double d) {
     const double a = fabs(d);
-    if (a < 0.5) return w;
-    if (0.5 < a && a < 1.5) return pow(w, (0.5 - d) + 1.0);
+    if (a < 0.5) return w.w;
+    if (0.5 < a && a < 1.5) return pow_base(w, (0.5 - d) + 1.0);
     return 0.0;
 }
 
 // ref :258-269 - cost of one sample point (s, t) against one S-T obstacle segment: the reference's arithmetic
-EMP_HD double point_cost(double w, double s, double t, double s_in, double t_in, double s_out, double t_out) {
+EMP_HD double point_cost(const PowBase& w, double s, double t, double s_in, double t_in, double s_out, double t_out) {
     const double v1x = s_in - s, v1y = t_in - t;
     const double v2x = s_out - s, v2y = t_out - t;
     const double v3x = v2x - v1x, v3y = v2y - v1y;
@@ -77,7 +102,7 @@ EMP_HD double point_cost(double w, double s, double t, double s_in, double t_in,
 // Out-of-line copy for the kernels: samples that are near an obstacle are rare per lane but not per
 // wavefront, so they are gathered first and costed together (obs_cost below); one copy of the long pow()
 // expansion per kernel.
-EMP_ST_COLD static double point_cost_cold(double w, double s, double t, double s_in, double t_in, double s_out,
+EMP_ST_COLD static double point_cost_cold(PowBase w, double s, double t, double s_in, double t_in, double s_out,
                                           double t_out) {
     return point_cost(w, s, t, s_in, t_in, s_out, t_out);
 }
@@ -119,7 +144,7 @@ EMP_HD void obs_frame(double s_in, double t_in, double s_out, double t_out, doub
 
 // ref :234-271 (CalcObsCost).  Obstacles / samples that are provably at least kPruneGap (> 1.5) away
 // contribute exactly 0 and are skipped; everything else goes through the reference's arithmetic.
-EMP_HD double obs_cost(double w, double s0, double t0, double s1, double t1, const ObsSet& o) {
+EMP_HD double obs_cost(const PowBase& w, double s0, double t0, double s1, double t1, const ObsSet& o) {
     const double dt = (t1 - t0) * 0.25;  // == (t1 - t0) / (n - 1), n = 5 (ref :244-246)
     const double k = div_dt(s1 - s0, t1 - t0);
     // ref :251-252: sample m sits at t0 + (m-1) dt, s0 + (k (m-1)) dt - the first one lies BEFORE the edge
@@ -186,7 +211,8 @@ EMP_HD double obs_cost(double w, double s0, double t0, double s1, double t1, con
 }
 
 struct Weights {
-    double v_ref, w_ref, w_acc, w_obs;  // ref :101-102 reference_speed, w_cost_ref_speed, w_cost_accel, w_cost_obs
+    double v_ref, w_ref, w_acc;  // ref :101-102 reference_speed, w_cost_ref_speed, w_cost_accel
+    PowBase w_obs;               // w_cost_obs
 };
 
 // ref :217-226 - the state-dependent part of CalcDpCost (everything except the obstacle term)

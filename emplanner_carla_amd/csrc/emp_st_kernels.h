@@ -197,7 +197,7 @@ __global__ void st_edge_cost_kernel(StDev d, int n_edges, const double* __restri
 }
 
 // ref :274-284
-__global__ void st_collision_cost_kernel(int n, double w, const double* __restrict__ dist, double* __restrict__ cost) {
+__global__ void st_collision_cost_kernel(int n, st::PowBase w, const double* __restrict__ dist, double* __restrict__ cost) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) cost[i] = st::collision_cost(w, dist[i]);
 }

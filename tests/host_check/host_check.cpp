@@ -53,7 +53,7 @@ int hc_match(const double* line, int n_ref, double x, double y, int first, int s
 // ---- S-T speed DP scalar pieces (emp_st_core.h) ---------------------------------------------------
 double hc_st_edge_cost(const double* w4, const double* edge5, int n_obs, const double* s_in, const double* s_out,
                        const double* t_in, const double* t_out, double* obs) {
-    const st::Weights w{w4[0], w4[1], w4[2], w4[3]};
+    const st::Weights w{w4[0], w4[1], w4[2], st::make_pow_base(w4[3])};
     double ux[st::kMaxObs], uy[st::kMaxObs], len[st::kMaxObs];
     for (int j = 0; j < n_obs; ++j) st::obs_frame(s_in[j], t_in[j], s_out[j], t_out[j], &ux[j], &uy[j], &len[j]);
     const st::ObsSet set{n_obs, s_in, s_out, t_in, t_out, ux, uy, len};

@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+from emplanner_carla_amd import _lib
+if os.environ.get("EMP_DBG_LIB"):                     # a development build of the library (tools/dbg_*.hip)
+    _lib.LIB_PATH = os.path.abspath(os.environ["EMP_DBG_LIB"])
 from emplanner_carla_amd import scenes as S
 from emplanner_carla_amd.api import Planner, speed_dp_params
 
