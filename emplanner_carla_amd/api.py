@@ -645,6 +645,24 @@ class Planner:
             q(x_init), q(y_init), q(heading_init), q(kappa_init), a.inp(n_init, np.int32, (B,)), outp, stp, a.where))
         return out, st
 
+    def speed_plan(self, dp: SpeedDpParams, qp: SpeedQpParams, obs_s, obs_l, obs_s_dot, obs_l_dot, plan_start_s_dot,
+                   plan_start_s_dot2, path_index2s, path_kappa, path_len, current_time, path_s, x_init, y_init,
+                   heading_init, kappa_init, n_init, max_lateral_accel=0.2 * 9.8):
+        """The whole S-T speed planner for B scenes, stage by stage on the device (the order of the reference's
+        functions in speed_planning_test.py: generate_st_graph -> speed_DP -> generate_convex_space -> speed_QP ->
+        increase_points -> path_speed_merge).  With torch inputs nothing leaves the GPU between the stages.  Returns a
+        dict: trajectory (B,7,401), status (B,) = OR of the stages' status bits, and every intermediate result."""
+        sets = self.st_graph(obs_s, obs_l, obs_s_dot, obs_l_dot)
+        res = self.speed_dp(dp, *sets, plan_start_s_dot, tables=False)
+        cs = self.speed_convex_space(res.speed_s, res.speed_t, path_index2s, path_kappa, path_len, *sets,
+                                     max_lateral_accel=max_lateral_accel)
+        q = self.speed_qp(qp, plan_start_s_dot, plan_start_s_dot2, res.speed_s, res.speed_t, *cs[:4])
+        d = self.speed_increase_points(*q[:4])
+        traj, st_merge = self.path_speed_merge(*d[:4], current_time, path_s, x_init, y_init, heading_init, kappa_init, n_init)
+        status = cs[4] | q[5] | d[4] | st_merge
+        return dict(trajectory=traj, status=status, st_sets=sets, dp=res, convex_space=cs[:4], qp=q[:4], qp_iters=q[4],
+                    dense=d[:4], stage_status=(cs[4], q[5], d[4], st_merge))
+
     # ---- QP stages ------------------------------------------------------------------------
     def lmin_lmax(self, dp_s, dp_l, n_pts, obs_s, obs_l, n_obs, obs_length, obs_width):
         """ref cal_lmin_lmax: returns l_min, l_max (B,M), status (B,)."""

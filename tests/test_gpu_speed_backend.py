@@ -270,3 +270,41 @@ def test_back_end_fuzz_vs_port(pl):
     for b in range(0, B, 3):
         want = np.stack(be.port_path_speed_merge(s[b], v[b], a[b], t[b], float(now[b]), ps[b], px[b], py[b], ph[b], pk[b]))
         np.testing.assert_array_equal(out[b], want)
+
+
+def test_speed_plan_chain(pl):
+    """Planner.speed_plan == the six stages called one by one; scenes whose DP ends before the last column (the only
+    profiles speed_QP accepts, speed_planning_test.py:435) come out as 401-point trajectories on the path."""
+    import torch
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import speed_dp_params, speed_qp_params
+    B, P = 256, 96
+    o = S.make_dynamic_batch(range(900, 900 + B))
+    rng = np.random.default_rng(12)
+    s_path = np.concatenate([np.zeros((B, 1)), np.cumsum(rng.uniform(0.9, 1.1, (B, P - 1)), axis=1)], axis=1)
+    kappa = 0.02 * np.sin(s_path / 15.0)
+    th = np.cumsum(kappa, axis=1)
+    pad = lambda a: np.concatenate([a[:, :80], np.full((B, P - 80), np.nan)], axis=1)
+    x, y = np.cumsum(np.cos(th), axis=1), np.cumsum(np.sin(th), axis=1)
+    n_full = np.full(B, P, np.int32)
+    args = (o[0], o[1], o[2], o[3], o[4], np.zeros(B), s_path, kappa, n_full, np.full(B, 3.0), s_path, pad(x), pad(y), pad(th),
+            pad(kappa), n_full)
+    r = pl.speed_plan(speed_dp_params(), speed_qp_params(), *args)
+    sets = pl.st_graph(*o[:4])
+    dp = pl.speed_dp(speed_dp_params(), *sets, o[4], tables=False)
+    cs = pl.speed_convex_space(dp.speed_s, dp.speed_t, s_path, kappa, n_full, *sets)
+    q = pl.speed_qp(speed_qp_params(), o[4], np.zeros(B), dp.speed_s, dp.speed_t, *cs[:4])
+    np.testing.assert_array_equal(r["qp"][0], q[0])
+    np.testing.assert_array_equal(r["stage_status"][1], q[5])
+    ok = r["status"] == 0
+    short = np.isnan(dp.speed_s).any(axis=1)
+    assert (ok <= short).all(), "only profiles with a NaN tail get through speed_QP"
+    if ok.any():
+        tr = r["trajectory"][ok]
+        assert np.isfinite(tr[:, :, :400]).all() and (np.diff(tr[:, 6, :400], axis=1) > 0).all()     # time runs forward
+        assert (tr[:, 4, :400] >= -1e-6).all()                                                       # no reversing
+    dev = torch.device("cuda:0")
+    rd = pl.speed_plan(speed_dp_params(), speed_qp_params(), *[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args])
+    pl.synchronize()
+    np.testing.assert_array_equal(rd["status"].cpu().numpy(), r["status"])
+    np.testing.assert_array_equal(rd["trajectory"].cpu().numpy(), r["trajectory"])
