@@ -153,7 +153,15 @@ EMP_HD double obs_cost(const PowBase& w, double s0, double t0, double s1, double
     const double s_lo = fmin(s_a, s_b), s_hi = fmax(s_a, s_b);
     const double t_lo = fmin(t_a, t_b), t_hi = fmax(t_a, t_b);
     const double G = kPruneGap;
-    uint64_t live = 0;
+    // One pass over the obstacles decides, per sample, which of them can be within reach.  The five samples lie on
+    // the straight edge, so their coordinates in a segment's frame are linear in the sample index: the two end
+    // samples' frame coordinates (needed for the edge-level rejection anyway) give every sample's by interpolation.
+    // The tests carry a 0.1 margin over the 1.5 reach, ten orders of magnitude above the rounding of that
+    // interpolation.  cand[m] bit j: sample m is inside obstacle j's 1.6-wide band and not beyond its ends.
+    uint64_t cand[kStSamples];
+#pragma unroll
+    for (int m = 0; m < kStSamples; ++m) cand[m] = 0;
+    bool any = false;
     for (int j = 0; j < o.n; ++j) {
         const double si = o.s_in[j], so = o.s_out[j], ti = o.t_in[j], to = o.t_out[j];
         if (isnan(si)) continue;  // ref :255
@@ -165,11 +173,21 @@ EMP_HD double obs_cost(const PowBase& w, double s0, double t0, double s1, double
         const double na = ay * ux - ax * uy, nb = by * ux - bx * uy;
         const double la = ax * ux + ay * uy, lb = bx * ux + by * uy;
         apart = apart || (na >= G && nb >= G) || (na <= -G && nb <= -G) || (la <= -G && lb <= -G) || (la >= top && lb >= top);
-        if (!apart) live |= (uint64_t)1 << j;
+        if (apart) continue;
+        const double dn = nb - na, dl = lb - la;
+#pragma unroll
+        for (int m = 0; m < kStSamples; ++m) {
+            const double w = 0.25 * (double)m;
+            const double nn = na + dn * w, ll = la + dl * w;
+            if (!(fabs(nn) >= G || ll <= -G || ll >= top)) {       // a NaN frame (degenerate segment) keeps the pair
+                cand[m] |= (uint64_t)1 << j;
+                any = true;
+            }
+        }
     }
     double total = 0.0;
-    if (live == 0) return total;
-    // pass 1: which (sample, obstacle) pairs are near?  Cheap arithmetic only.
+    if (!any) return total;
+    // pass 1: which of the candidate (sample, obstacle) pairs are near?  The reference's own intermediates, no sqrt.
     uint64_t near[kStSamples];
 #pragma unroll
     for (int m = 0; m < kStSamples; ++m) {
@@ -177,14 +195,9 @@ EMP_HD double obs_cost(const PowBase& w, double s0, double t0, double s1, double
         const double t = t0 + f * dt;
         const double s = s0 + (k * f) * dt;
         uint64_t hit = 0;
-        for (uint64_t rest = live; rest; rest &= rest - 1) {
+        for (uint64_t rest = cand[m]; rest; rest &= rest - 1) {
             const int j = ctz64(rest);
-            const double si = o.s_in[j], ti = o.t_in[j];
-            const double ux = o.ux[j], uy = o.uy[j];
-            const double px = s - si, py = t - ti;
-            const double nn = py * ux - px * uy, ll = px * ux + py * uy;
-            if (fabs(nn) >= G || ll <= -G || ll >= o.len[j] + G) continue;  // provably >= 1.6 away: exact 0
-            if (!point_is_far(s, t, si, ti, o.s_out[j], o.t_out[j])) hit |= (uint64_t)1 << j;
+            if (!point_is_far(s, t, o.s_in[j], o.t_in[j], o.s_out[j], o.t_out[j])) hit |= (uint64_t)1 << j;
         }
         near[m] = hit;
     }
