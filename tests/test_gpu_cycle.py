@@ -515,3 +515,45 @@ def test_motion_planning_process_loop(planner):
         assert len(traj) == g["n_traj"][c] and match == [int(g["match"][c])]
         assert isinstance(traj[0], tuple) and len(traj[0]) == 4 and isinstance(ps, list)
         assert_rel(np.array(traj)[:, :3], g["traj"][c, :len(traj), :3], 1e-6, 1.0, "trajectory")
+
+
+def test_cycle_with_dynamic_obstacle_on_the_fine_lattice_vs_port(planner):
+    """The virtual obstacles of the first dynamic obstacle (test_9.py:137-169) on the 40x9 lattice, next to eight
+    static obstacles: every stage against oracle/ref_port.plan_cycle (itself pinned on the reference driver run)."""
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg = S.CFG2
+    seeds = list(range(40, 96))
+    b = S.make_batch(seeds, cfg)
+    B, P = b.ref.shape[:2]
+    rng = np.random.default_rng(8)
+    dyn = np.full((B, 2), np.nan)
+    has = rng.random(B) < 0.75
+    dyn[has, 0] = rng.uniform(8.0, 45.0, has.sum())                 # distance ahead
+    dyn[has, 1] = rng.uniform(0.0, 6.0, has.sum())                  # its speed; the ego's is ~8 m/s
+    v = np.tile([8.0, 0.0], (B, 1)) + rng.normal(0, 0.2, (B, 2))
+    r = planner.plan_cycle(dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width),
+                           smooth_params(), ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy,
+                           start_xy=b.start_xy, start_v=v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs,
+                           dyn_dis_speed=dyn)
+    kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
+    compared = with_virtual = 0
+    for i in range(B):
+        d = None if np.isnan(dyn[i, 0]) else tuple(dyn[i])
+        try:
+            want = op.plan_cycle([tuple(x) for x in b.ref[i]], b.origin_xy[i], b.start_xy[i], v[i], b.start_a[i],
+                                 b.obs_xy[i, :b.n_obs[i]], dp_kwargs=kw, obs_length=cfg.obs_length,
+                                 obs_width=cfg.obs_width, verbose=False, dyn_dis_speed=d)
+        except IndexError:
+            assert r.status[i] & (2 | 4), f"scene {i}: the reference raises IndexError"
+            continue
+        with_virtual += len(want["obs_s"]) > b.n_obs[i]
+        assert np.array_equal(r.dp_rows[i], np.asarray(want["dp_rows"], dtype=np.float64)), f"scene {i}: DP rows"
+        if want.get("qp_status") not in (None, "optimal"):
+            assert r.status[i] & 8
+            continue
+        assert (r.status[i] & ~1) == 0, f"scene {i}: status {r.status[i]}"
+        m = len(want["trajectory"])
+        assert r.traj_len[i] == m
+        assert_rel(r.traj[i, :m, :3], np.asarray(want["trajectory"], dtype=np.float64)[:, :3], RTOL, 1.0, f"scene {i} trajectory")
+        compared += 1
+    assert compared >= 10 and with_virtual >= 8
