@@ -1113,6 +1113,93 @@ __device__ inline int box_qp_setup_group(BoxRangeQp& Q, const double* ref, int s
 // constants as range_qp_solve_wave_fast with BoxRangeQp (emp_qp_core.h: box_qp_forms / box_qp_setup).
 // r: this lane's reference coordinate (lanes >= m of the group: anything).  Returns 0 ok / 2 failed per group.
 // ---------------------------------------------------------------------------------------------
+// The same box QP by a primal-dual active set iteration (Hintermueller / Ito / Kunisch): fix the coordinates whose
+// bound is active, solve the banded system of the others, re-classify from the gradient, until the classification
+// repeats.  A fixed point is the KKT point, i.e. THE minimiser, exact to rounding - and it is reached in two to
+// five factorisations where the interior-point iteration needs nine to fourteen with two solves each.  There is no
+// convergence guarantee for this Hessian (D2'D2 has positive off-diagonals: not an M-matrix), so the caller falls
+// back to box_qp_lanes when this returns -1 (classification still changing after kBoxAsMaxIter rounds).
+// Same lane layout as box_qp_lanes: one coordinate per lane, r = reference value, box r +- thr.
+constexpr int kBoxAsMaxIter = 8;
+template <int G>
+__device__ inline int box_qp_active_set_lanes(double r, int m, const SmoothQpParams& prm, double* out_u, int* iters_out) {
+    constexpr int KD = 2;
+    const int gl = (threadIdx.x & 63) & (G - 1);
+    const bool has = gl < m;
+    *iters_out = 0;
+    *out_u = r;
+    if (m < 2 || !(prm.thr > 0.0)) return 2;
+    double Prow[KD + 1], Plow[KD + 1];
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) {                      // ref planning_utils.py:262-361 cost matrices, as box_qp_lanes
+        double e = 0.0;
+        if (has && gl + d < m) {
+            for (int rr = max(0, gl + d - 2); rr <= min(m - 3, gl); ++rr) {
+                const double a = (gl - rr == 1) ? -2.0 : 1.0, b = (gl + d - rr == 1) ? -2.0 : 1.0;
+                e += 2.0 * prm.w_smooth * a * b;
+            }
+            for (int rr = max(0, gl + d - 1); rr <= min(m - 2, gl); ++rr) {
+                const double a = (gl - rr == 0) ? 1.0 : -1.0, b = (gl + d - rr == 0) ? 1.0 : -1.0;
+                e += 2.0 * prm.w_length * a * b;
+            }
+            if (d == 0) e += 2.0 * prm.w_ref;
+        }
+        Prow[d] = e;
+    }
+    {
+        const double t1 = lane_up1(Prow[1]), t2 = lane_up1(lane_up1(Prow[2]));
+        Plow[0] = 0.0;
+        Plow[1] = (gl >= 1) ? t1 : 0.0;                  // P[gl-1][gl]
+        Plow[2] = (gl >= 2) ? t2 : 0.0;                  // P[gl-2][gl]
+    }
+    const double q = has ? -2.0 * prm.w_ref * r : 0.0;   // ref :346
+    const double lo = r - prm.thr, hi = r + prm.thr;     // ref :308-311
+    const double c = 2.0 * (6.0 * prm.w_smooth + 2.0 * prm.w_length + prm.w_ref);   // the Hessian's interior diagonal
+    int code = 0;                                        // 0 free, 1 fixed at hi, 2 fixed at lo
+    double x = r;
+    int state = 1, iters = 0;                            // 1 running, 0 converged, -1 gave up
+    while (__any(state == 1)) {
+        const bool go = state == 1;
+        const bool act = go && has && code != 0;
+        const double bnd = (code == 1) ? hi : lo;
+        const double af = act ? 1.0 : 0.0, ab = act ? bnd : 0.0;
+        // neighbours' flags and fixed values (0 beyond the ends of the group: Prow / Plow are 0 there as well)
+        const double f_p1 = lane_dn1(af), f_p2 = lane_dn1(f_p1);      // (the band is stored by its upper half)
+        const double b_p1 = lane_dn1(ab), b_p2 = lane_dn1(b_p1), b_m1 = lane_up1(ab), b_m2 = lane_up1(b_m1);
+        double fa[KD + 1], flow[KD + 1], frinv = 1.0;
+        fa[0] = act ? 1.0 : ((go && has) ? Prow[0] : 0.0);
+        fa[1] = (go && !act && f_p1 == 0.0) ? Prow[1] : 0.0;
+        fa[2] = (go && !act && f_p2 == 0.0) ? Prow[2] : 0.0;
+        double rhs = -q - (((Prow[1] * b_p1 + Prow[2] * b_p2) + Plow[1] * b_m1) + Plow[2] * b_m2);
+        rhs = act ? bnd : ((go && has) ? rhs : 0.0);
+        const bool okf = band_chol_group<G, KD>(fa, frinv, flow, m, gl, go);
+        band_solve_group<G, KD>(fa, frinv, flow, rhs, m, gl);
+        if (go) {
+            if (has) x = rhs;
+            ++iters;
+        }
+        // gradient of the full problem at x and the new classification
+        const double xs = (go && has) ? x : 0.0;
+        const double x_p1 = lane_dn1(xs), x_p2 = lane_dn1(x_p1), x_m1 = lane_up1(xs), x_m2 = lane_up1(x_m1);
+        const double g = (q + Prow[0] * xs) + (((Prow[1] * x_p1 + Prow[2] * x_p2) + Plow[1] * x_m1) + Plow[2] * x_m2);
+        const double lam = -g;
+        int ncode = 0;
+        if (lam + c * (xs - hi) > 0.0) ncode = 1;
+        else if (lam + c * (xs - lo) < 0.0) ncode = 2;
+        if (!(go && has)) ncode = code;
+        const bool changed = group_any<G>(ncode != code);
+        if (go) {
+            code = ncode;
+            if (!okf) state = -1;
+            else if (!changed) state = 0;
+            else if (iters >= kBoxAsMaxIter) state = -1;
+        }
+    }
+    *iters_out = iters;
+    if (state == 0) *out_u = x;
+    return state;
+}
+
 template <int G>
 __device__ inline int box_qp_lanes(double r, int m, const SmoothQpParams& prm, double* out_u, int* iters_out) {
     constexpr int KD = 2;
@@ -1453,7 +1540,19 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
         const double r = gl < m ? xy[(size_t)gl * stride + grp] : 0.0;
         double uu = 0.0;
         int it_mine = 0;
-        const int rc = box_qp_lanes<32>(r, m, grp ? sy : sx, &uu, &it_mine);
+        // active-set iteration first; the interior-point solver takes over for a coordinate whose classification
+        // did not settle (every lane of the wavefront walks through it then, the settled half keeps its result)
+        int rc = box_qp_active_set_lanes<32>(r, m, grp ? sy : sx, &uu, &it_mine);
+        if (__any(rc < 0)) {
+            double u2 = 0.0;
+            int it2 = 0;
+            const int rc2 = box_qp_lanes<32>(r, m, grp ? sy : sx, &u2, &it2);
+            if (rc < 0) {
+                rc = rc2;
+                uu = u2;
+                it_mine += it2;
+            }
+        }
         __syncthreads();
         if (gl < m) lds[grp * m + gl] = uu;
         __syncthreads();
