@@ -1120,7 +1120,7 @@ __device__ inline int box_qp_setup_group(BoxRangeQp& Q, const double* ref, int s
 // convergence guarantee for this Hessian (D2'D2 has positive off-diagonals: not an M-matrix), so the caller falls
 // back to box_qp_lanes when this returns -1 (classification still changing after kBoxAsMaxIter rounds).
 // Same lane layout as box_qp_lanes: one coordinate per lane, r = reference value, box r +- thr.
-constexpr int kBoxAsMaxIter = 8;
+constexpr int kBoxAsMaxIter = 16;
 template <int G>
 __device__ inline int box_qp_active_set_lanes(double r, int m, const SmoothQpParams& prm, double* out_u, int* iters_out) {
     constexpr int KD = 2;
@@ -1523,7 +1523,16 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     if (WIDE && m > 32 && m <= 64) {                    // one point per lane, x and y side by side, all in registers
         double ux = 0.0, uy = 0.0;
         const double rx = lane < m ? xy[(size_t)lane * stride] : 0.0, ry = lane < m ? xy[(size_t)lane * stride + 1] : 0.0;
-        const int rc = smooth_pair_lanes(rx, ry, m, sx, sy, &ux, &uy, iters_out);
+        // active-set iteration for x, then for y; the paired interior-point solver if either did not settle
+        int itx = 0, ity = 0;
+        int rc = box_qp_active_set_lanes<64>(rx, m, sx, &ux, &itx);
+        if (rc == 0) rc = box_qp_active_set_lanes<64>(ry, m, sy, &uy, &ity);
+        *iters_out = max(itx, ity);
+        if (rc < 0) {
+            int it2 = 0;
+            rc = smooth_pair_lanes(rx, ry, m, sx, sy, &ux, &uy, &it2);
+            *iters_out += it2;
+        }
         __syncthreads();
         if (lane < m) {
             lds[lane] = ux;

@@ -5,7 +5,7 @@ import numpy as np
 from emplanner_carla_amd import scenes as S
 from emplanner_carla_amd.api import Planner, dp_params_from_cfg, qp_params, smooth_params, max_path_points
 cfg = S.CFG2
-B = 512
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 b = S.make_batch(range(B), cfg)
 P = b.ref.shape[1]
 pl = Planner(0)
