@@ -557,3 +557,47 @@ def test_cycle_with_dynamic_obstacle_on_the_fine_lattice_vs_port(planner):
         assert_rel(r.traj[i, :m, :3], np.asarray(want["trajectory"], dtype=np.float64)[:, :3], RTOL, 1.0, f"scene {i} trajectory")
         compared += 1
     assert compared >= 10 and with_virtual >= 8
+
+
+def test_smoothing_active_set_on_hard_polylines(planner):
+    """The active-set smoother (emp_qp_wave.h: box_qp_active_set_lanes) on polylines that are much rougher than its
+    0.2 m boxes - most coordinates end on a bound, zig-zags flip between the two bounds, some points repeat - against
+    the faithful port's certified minimiser, for the half-wave (<= 32 points) and the full-wave (33..64) paths."""
+    from emplanner_carla_amd.api import smooth_params
+    rng = np.random.default_rng(77)
+    cases = []
+    for m in (5, 23, 32, 33, 51, 64):
+        for kind in range(6):
+            t = np.arange(m) * 2.0
+            base = np.column_stack([t, 8 * np.sin(t / 25.0)])
+            if kind == 0:
+                pts = base + rng.normal(0, 0.6, (m, 2))                   # noise three times the box
+            elif kind == 1:
+                pts = base + 0.5 * np.column_stack([(-1.0) ** np.arange(m), (-1.0) ** (np.arange(m) // 2)])   # zig-zag
+            elif kind == 2:
+                pts = base.copy()
+                pts[m // 2:] += [0.0, 1.5]                                # a step in the line
+            elif kind == 3:
+                pts = np.repeat(base[:(m + 1) // 2], 2, axis=0)[:m]       # every point twice
+            elif kind == 4:
+                pts = base + rng.normal(0, 0.02, (m, 2))                  # nearly smooth: no bound active
+            else:
+                pts = base + rng.uniform(-0.2, 0.2, (m, 2)) * 1.0000001   # deviations right at the box size
+            cases.append(pts)
+    B = len(cases)
+    xy = np.zeros((B, 64, 2))
+    n_pts = np.array([len(c) for c in cases], np.int32)
+    for b, c in enumerate(cases):
+        xy[b, :len(c)] = c
+    out, iters, st = planner.smooth_line(smooth_params(), xy, n_pts)
+    assert (st == 0).all()
+    at_bound = 0
+    for b, c in enumerate(cases):
+        n = len(c)
+        want = np.asarray(op.smooth_reference_line([tuple(p) for p in c]), dtype=np.float64)
+        assert_rel(out[b, :n, :2], want[:, :2], RTOL, 1.0, f"case {b} smoothed xy")
+        dev = np.abs(out[b, :n, :2] - c)
+        assert (dev <= 0.2 + 1e-12).all()
+        at_bound += int((dev >= 0.2 - 1e-12).sum())
+    assert at_bound > 500, "the hard cases really end on their bounds"
+    assert iters.max() <= 16, "the active-set iteration settled everywhere (no interior-point fallback)"
