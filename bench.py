@@ -131,8 +131,6 @@ def main():
     import torch
     import torch.distributed as dist
     from emplanner_carla_amd import _lib as L
-    if os.environ.get("EMP_DBG_LIB"):            # a development build of the library (tools/dbg_*.hip), never the default
-        L.LIB_PATH = os.path.abspath(os.environ["EMP_DBG_LIB"])
     from emplanner_carla_amd import dist as emp_dist
     from emplanner_carla_amd import scenes as S
     from emplanner_carla_amd.api import (Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params)
