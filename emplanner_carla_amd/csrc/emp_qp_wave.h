@@ -49,6 +49,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return r;
 }
 
+constexpr double kQpInfeasibleZ = 1e5;    // multipliers beyond this many Hessian diagonals with a stalled primal residual: infeasible
+
 // All-lanes reductions over a group of G = 32 or 64 lanes without LDS traffic: four DPP butterfly levels inside
 // each row of 16 lanes (quad_perm x2, row_half_mirror, row_mirror: after level k every aligned block of 2^k
 // lanes holds its own reduction, so a mirror works as the next exchange), then gfx950's row swaps
@@ -720,8 +722,9 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
     }
     const double q_m = has_m ? Q.q[m] : 0.0;
     double u_m = has_m ? Q.u[m] : 0.0;
+    const double pscale = group_max<G>(has_m ? Prow[0] : 0.0);     // largest Hessian diagonal
     {
-        const double z0 = Q.initial_multiplier(group_max<G>(has_m ? Prow[0] : 0.0));
+        const double z0 = Q.initial_multiplier(pscale);
 #pragma unroll
         for (int f = 0; f < F; ++f) zu[f] = zl[f] = z0;
     }
@@ -821,6 +824,11 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
                 EMP_QP_DEBUG("it %d rd %.3e rp %.3e mu %.3e zmax %.3e\n", iters, rd_max, rp_max, mu, zmax);
                 if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
                 else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
+                // An infeasible problem shows long before that: its primal residual stalls while the multipliers grow
+                // without bound (x3..100 per iteration, 1e9 and more by iteration 8-12); those of the feasible benchmark
+                // problems stay below 250 Hessian diagonals.  Most of the batch's slowest problems were infeasible ones
+                // running into the iteration-16 rule above, and a kernel lasts as long as its slowest problem.
+                else if (rp_max > kQpStallResidual && zmax > kQpInfeasibleZ * pscale) state = 2;
                 else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
                 if (rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu)
                     acceptable = true;
