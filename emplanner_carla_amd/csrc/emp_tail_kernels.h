@@ -625,19 +625,18 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
     }
 }
 
-// monotone index walk of cal_proj_point from index 0 (ref path_planning.py:62-64); *off_end when it runs past
+// monotone index walk of cal_proj_point from index 0 (ref path_planning.py:62-64: `while s_map[idx + 1] < s: idx += 1`);
+// *off_end when it runs past the end.  s_map is a cumulative chord length, i.e. non-decreasing, so the walk's stopping
+// index is found by bisection (6 LDS round trips instead of up to P).
 __device__ inline int walk_from_zero(const double* sm, int P, double s, bool* off_end) {
-    int k = 0;
-    *off_end = false;
-    while (true) {
-        if (k + 1 >= P) {
-            *off_end = true;
-            break;
-        }
-        if (!(sm[k + 1] < s)) break;
-        ++k;
+    int lo = 0, hi = P - 1;                       // answer in [0, P-1]; P-1 = "no index stops the walk"
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sm[mid + 1] < s) lo = mid + 1;
+        else hi = mid;
     }
-    return k;
+    *off_end = lo + 1 >= P;
+    return lo;
 }
 
 // ---------------------------------------------------------------------------------------------
