@@ -36,6 +36,32 @@ struct QpDev {
 // minimum that keeps the FIRST occurrence, because only a strict '<' counts as an improvement), stop at the first
 // i with i - L_i >= 50, answer L_i there (or L_{P-1} if the scan never stops early).
 // ---------------------------------------------------------------------------------------------
+// Inclusive prefix minimum of (d, index) over the 64 lanes, the EARLIER lane winning ties, by DPP moves (no LDS
+// traffic, no address arithmetic): Hillis-Steele inside each row of 16 lanes (row_shr:1, 2, 4, 8; a lane without a
+// source keeps +inf), then the row totals travel on with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into
+// rows 2 and 3).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void prefix_min_step(double& d, int& li) {
+    union { double f; int w[2]; } a, r, inf;
+    a.f = d;
+    inf.f = __builtin_inf();
+    r.w[0] = __builtin_amdgcn_update_dpp(inf.w[0], a.w[0], CTRL, ROW_MASK, 0xF, false);
+    r.w[1] = __builtin_amdgcn_update_dpp(inf.w[1], a.w[1], CTRL, ROW_MASK, 0xF, false);
+    const int oi = __builtin_amdgcn_update_dpp(0, li, CTRL, ROW_MASK, 0xF, false);
+    if (!(d < r.f)) {                  // the value from the earlier lanes wins unless mine is strictly smaller;
+        d = r.f;                       // a lane without a source sees +inf and keeps its own unless that is +inf / NaN
+        li = oi;
+    }
+}
+__device__ __forceinline__ void prefix_min_first(double& d, int& li) {
+    prefix_min_step<0x111, 0xF>(d, li);   // row_shr:1
+    prefix_min_step<0x112, 0xF>(d, li);   // row_shr:2
+    prefix_min_step<0x114, 0xF>(d, li);   // row_shr:4
+    prefix_min_step<0x118, 0xF>(d, li);   // row_shr:8
+    prefix_min_step<0x142, 0xA>(d, li);   // row_bcast:15 -> rows 1, 3
+    prefix_min_step<0x143, 0xC>(d, li);   // row_bcast:31 -> rows 2, 3
+}
+
 __device__ inline int match_scan_wave(const double* lx, const double* ly, int P, double x, double y, int limit) {
     const int lane = threadIdx.x & 63;
     double cd = __builtin_inf();     // carry: prefix minimum and its first index over the previous chunks
@@ -48,15 +74,7 @@ __device__ inline int match_scan_wave(const double* lx, const double* ly, int P,
             const double dx = lx[i] - x, dy = ly[i] - y;
             d = sqrt(dx * dx + dy * dy);
         }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {           // inclusive prefix-min keeping the earlier index on ties
-            const double od = __shfl_up(d, off, 64);
-            const int oi = __shfl_up(li, off, 64);
-            if (lane >= off && !(d < od)) {
-                d = od;
-                li = oi;
-            }
-        }
+        prefix_min_first(d, li);                           // inclusive prefix-min keeping the earlier index on ties
         if (!(d < cd)) {                                   // fold the carry (earlier) in
             d = cd;
             li = ci;
