@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
                          pddl = start[b * 4 + 3];
             const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, i, P.sample_l), P.sample_s);
             start_cost[(size_t)b * row + i] =
-                segment_cost(q, ps, P.sample_s, t_obs_s + s * P.max_obs, t_obs_l + s * P.max_obs, n_obs[b],
+                segment_cost(q, ps, P.sample_s, t_obs_s + s * P.max_obs, t_obs_l + s * P.max_obs, min(max(n_obs[b], 0), P.max_obs),
                              P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
         }
     }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
     const int b = tile * P.S + s;
     if (lane >= lanes_used || b >= P.B) return;
     const double ps = start[b * 4 + 0];
-    const int nob = n_obs[b];
+    const int nob = min(max(n_obs[b], 0), P.max_obs);      // a count beyond the row's capacity is clamped, never followed
     const int nmask = min(nob, 64);
     const double* my_obs_s = t_obs_s + s * P.max_obs;
     const double* my_obs_l = t_obs_l + s * P.max_obs;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     double* lk = lth + max_ref;
     double* sm = lk + max_ref;
     const double* line = ref_line + (size_t)b * max_ref * 4;
-    const int P = n_ref[b];
+    const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
     for (int i = lane; i < P; i += 64) {
         lx[i] = line[4 * i];
         ly[i] = line[4 * i + 1];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     __syncthreads();
     // obstacles (ref test_9.py:122): matches one after the other (each scan is wave-parallel), then one
     // obstacle per lane for the projection arithmetic; l uses the FIRST obstacle's match (quirk :413)
-    const int k = n_obs ? n_obs[b] : 0;
+    const int k = n_obs ? min(max(n_obs[b], 0), max_obs) : 0;   // clamped to the row's capacity
     int my_match = 0, first_match = 0;
     for (int j = 0; j < k; ++j) {
         const double x = obs_xy[((size_t)b * max_obs + j) * 2], y = obs_xy[((size_t)b * max_obs + j) * 2 + 1];
@@ -225,7 +225,7 @@ __global__ void match_points_kernel(int B, int max_ref, int max_pts, const doubl
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* line = ref_line + (size_t)b * max_ref * 4;
-    const int P = n_ref[b];
+    const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
     const int k = n_pts[b];
     int m_first = 0;
     for (int j = 0; j < k; ++j) {
@@ -304,7 +304,7 @@ __global__ void lmin_lmax_kernel(int B, int max_pts, int max_obs, const double* 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const bool ok = lmin_lmax(dp_s + (size_t)b * max_pts, dp_l + (size_t)b * max_pts, 1, n_pts[b],
-                              obs_s + (size_t)b * max_obs, obs_l + (size_t)b * max_obs, n_obs[b], obs_length,
+                              obs_s + (size_t)b * max_obs, obs_l + (size_t)b * max_obs, min(max(n_obs[b], 0), max_obs), obs_length,
                               obs_width, l_min + (size_t)b * max_pts, l_max + (size_t)b * max_pts);
     status[b] = ok ? 0 : kStBoundIndex;
 }
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
     if (Q.use_qp) {
         // ---- cal_lmin_lmax (ref path_planning.py:222-273): one obstacle per lane finds its index range,
         // then one station per lane folds the (commutative) min / max over the obstacles covering it
-        const int nob = live ? n_obs[b] : 0;
+        const int nob = live ? min(max(n_obs[b], 0), max_obs) : 0;
         bool bad = false;
         for (int k = gl; k < nob; k += G) {
             const double os = obs_s[(size_t)b * max_obs + k], ol = obs_l[(size_t)b * max_obs + k];
@@ -683,7 +683,7 @@ __device__ __forceinline__ void cycle_cartesian_body(
     auto body = [&]() -> int {          // returns the number of trajectory points (0 = none); wave-uniform control flow
     if (st & (kStQpFailed | kStBoundIndex | kStTruncated)) return 0;
     const double* line = ref_line + (size_t)b * max_ref * 4;
-    const int P = n_ref[b];
+    const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
     const int n = path_len[b];
     for (int i = lane; i < P; i += 64) sm[i] = s_map[(size_t)b * max_ref + i];
     __syncthreads();
@@ -793,7 +793,7 @@ __global__ void s_l_kernel(int B, int max_ref, int max_pts, const double* __rest
     if (b >= B) return;
     const double* line = ref_line + (size_t)b * max_ref * 4;
     const double* sm = s_map + (size_t)b * max_ref;
-    const int P = n_ref[b], k = n_pts[b];
+    const int P = min(max(n_ref[b], 0), max_ref), k = n_pts[b];
     int m_first = 0;
     for (int j = 0; j < k; ++j) {
         const size_t o = (size_t)b * max_pts + j;
@@ -814,7 +814,7 @@ __global__ void s_l_deri_kernel(int B, int max_ref, int max_pts, const double* _
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double* line = ref_line + (size_t)b * max_ref * 4;
-    const int P = n_ref[b], k = n_pts[b];
+    const int P = min(max(n_ref[b], 0), max_ref), k = n_pts[b];
     int m_first = 0;
     for (int j = 0; j < k; ++j) {
         const size_t o = (size_t)b * max_pts + j;
@@ -870,7 +870,7 @@ __global__ void frenet2cartesian_kernel(int B, int max_ref, int max_pts, const d
     if (b >= B) return;
     const double* line = ref_line + (size_t)b * max_ref * 4;
     const double* sm = index2s + (size_t)b * max_ref;
-    const int P = n_ref[b];
+    const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
     const double qnan = __builtin_nan("");
     int st = 0;
     bool stopped = false;

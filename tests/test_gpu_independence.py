@@ -196,3 +196,35 @@ def test_speed_back_end_scenes_are_independent(pl):
     other = run(perm)
     for k, (a, b) in enumerate(zip(base, other)):
         _same(a[perm], b, f"output {k}")
+
+
+def test_garbage_scenes_neither_hang_nor_touch_their_neighbours(pl):
+    """NaN / Inf coordinates, absurd counts and degenerate reference lines in a few scenes of a batch: the call
+    returns (every loop of every kernel is bounded), those scenes come back refused or with whatever the arithmetic
+    yields, and every other scene is bit-identical to the clean batch."""
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg = S.CFG2
+    b = S.make_batch(range(300, 364), cfg)
+    B, P = b.ref.shape[:2]
+    clean = dict(ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
+                 start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+    want = pl.plan_cycle(p, q, sp, **clean)
+    bad = {k: v.copy() for k, v in clean.items()}
+    bad["ref_line"][3, 10, 0] = np.nan                       # a NaN in the reference line
+    bad["ref_line"][5, :, :2] = 0.0                          # every point the same: zero-length line
+    bad["obs_xy"][7, 2] = [np.inf, -np.inf]                  # an obstacle at infinity
+    bad["start_v"][9] = [np.nan, np.nan]
+    bad["n_ref"][11] = 1                                     # one-point line
+    bad["n_ref"][13] = 100000                                # a count beyond the row
+    bad["n_obs"][15] = 1 << 30                               # a count beyond the row
+    bad["n_obs"][17] = -5
+    bad["start_xy"][19] = [1e300, -1e300]
+    bad["n_ref"][21] = 0
+    touched = [3, 5, 7, 9, 11, 13, 15, 17, 19, 21]
+    got = pl.plan_cycle(p, q, sp, **bad)
+    pl.synchronize()
+    keep = np.setdiff1d(np.arange(B), touched)
+    for name in ("dp_rows", "traj", "traj_len", "status", "path_l"):
+        _same(getattr(want, name)[keep], getattr(got, name)[keep], name)
+    assert (want.status[keep] == 0).sum() > 30
