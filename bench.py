@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=4096)
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight instead of two (emp_set_pipeline off)")
     ap.add_argument("--cpu-sample", type=int, default=24)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -162,14 +163,21 @@ def main():
     p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
     M = max_path_points(p)
     mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
+    # Two batches in flight: the back stage (path QP, Cartesian tail) of step k runs on the planner's second stream
+    # while the front stage (projection, DP) of step k+1 runs on its first (include/emplanner.h, emp_set_pipeline).
+    # Every step is a complete pass over the batch; the K timed steps are all finished at the closing fence.
+    pipelined = not args.no_pipeline
+    pl.set_pipeline(pipelined)
     ts = pl.torch_stream()
 
     def step():
-        # torch work of a step (output allocation, and for N > 1 the packing + RCCL gather of the records) runs on
-        # the planner's own stream: ordered after its kernels without any cross-stream event
+        # torch work of a step runs on the planner's own streams, ordered with its kernels without any cross-stream
+        # event: output allocation on the first, and for N > 1 the packing + RCCL gather of the records on the stream
+        # on which the cycle's results become complete (the second one when pipelined)
         with torch.cuda.stream(ts):
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
-            if world > 1:
+        if world > 1:
+            with torch.cuda.stream(pl.torch_result_stream()):
                 rec = emp_dist.pack_records(res, p.col, M)
                 return emp_dist.gather_records(rec, total)
         return res
@@ -198,7 +206,13 @@ def main():
         elapsed = float(el.item())
 
     sweep_ms, sweep_launches = pl.kernel_ms("dp_sweep"), pl.kernel_launches("dp_sweep")
-    # Per-kernel breakdown: a separate diagnostic pass AFTER the timed region, every kernel bracketed.
+    # Per-kernel breakdown: a separate diagnostic pass AFTER the timed region, every kernel bracketed, one batch in
+    # flight (the durations of overlapping kernels would not add up to anything)
+    fence()
+    pl.set_pipeline(False)
+    for _ in range(2):
+        out = step()
+    fence()
     pl.set_timing(True)
     for _ in range(min(args.steps, 5)):
         out = step()
@@ -265,6 +279,7 @@ def main():
                        "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
                        "ref_line_points": int(P), "qp_stations": 21, "dp_mode": args.dp_mode,
+                       "batches_in_flight": 2 if pipelined else 1,
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
             **extra,

@@ -143,6 +143,8 @@ class _Args:
     def __init__(self, *inputs, planner=None):
         self.torch = any(_is_torch(x) for x in inputs if x is not None)
         self.keep = []
+        self.outs = []               # torch output tensors of this call
+        self.cycle = False           # set by Planner.plan_cycle: the call whose back stage may run on the second stream
         self.planner = planner
         self.same_stream = False
         if self.torch:
@@ -163,8 +165,20 @@ class _Args:
 
     def done(self):
         """After the library call: torch's current stream waits for the planner's stream, so that reading an output
-        tensor from torch code (``.cpu()``, another kernel) sees the finished result."""
-        if self.torch and self.planner is not None and not self.same_stream:
+        tensor from torch code (``.cpu()``, another kernel) sees the finished result.  In pipelined mode the results
+        of a cycle are produced on the planner's second stream: the outputs are tied to it (the caching allocator must
+        not hand their memory out again before that stream is done with it) and a caller on any OTHER stream waits
+        for it; a caller that works on the planner's own streams orders itself (``Planner.torch_result_stream``)."""
+        if not (self.torch and self.planner is not None):
+            return
+        piped = self.planner.pipelined and self.cycle
+        if piped:
+            rs = self.planner.torch_result_stream()
+            for o in self.outs:
+                o.record_stream(rs)
+            if not self.same_stream:
+                self.t.cuda.current_stream(self.device).wait_stream(rs)
+        elif not self.same_stream:
             self.t.cuda.current_stream(self.device).wait_stream(self.planner.torch_stream())
 
     def inp(self, x, dtype, shape=None):
@@ -192,6 +206,7 @@ class _Args:
             # empty, not zeros: a fill kernel on torch's stream would race with ours; the library zero-fills
             # its outputs on the context's stream
             a = self.t.empty(tuple(shape), dtype=td, device=self.device)
+            self.outs.append(a)
             return a, C.c_void_p(a.data_ptr())
         a = np.zeros(tuple(shape), dtype=dtype)
         return a, C.c_void_p(a.ctypes.data)
@@ -224,6 +239,8 @@ class Planner:
         self._h = h
         self.device_id = int(device_id)
         self._torch_stream = None
+        self._torch_result_stream = None
+        self.pipelined = False
         self._cur = None
 
     def close(self):
@@ -266,6 +283,24 @@ class Planner:
     def stream(self):
         """Raw hipStream_t of the context."""
         return self._lib.emp_stream(self._h)
+
+    def set_pipeline(self, enabled: bool):
+        """Two-stage pipelining of consecutive ``plan_cycle`` calls on device tensors (include/emplanner.h,
+        emp_set_pipeline): the path QP / Cartesian tail of one batch overlaps the projection / DP of the next.  The
+        outputs of a cycle are then complete on ``torch_result_stream()``; ``synchronize()`` waits for everything."""
+        self._check(self._lib.emp_set_pipeline(self._h, 1 if enabled else 0))
+        self.pipelined = bool(enabled)
+        self._torch_result_stream = None
+
+    def torch_result_stream(self):
+        """The stream on which a cycle's outputs become complete (the planner's second stream in pipelined mode)."""
+        if not self.pipelined:
+            return self.torch_stream()
+        if self._torch_result_stream is None:
+            import torch
+            self._torch_result_stream = torch.cuda.ExternalStream(int(self._lib.emp_result_stream(self._h)),
+                                                                  device=torch.device("cuda", self.device_id))
+        return self._torch_result_stream
 
     def torch_stream(self):
         """The context's stream as a torch stream: ``with torch.cuda.stream(pl.torch_stream()):`` orders torch
@@ -355,6 +390,7 @@ class Planner:
         """ref cal_s_map_fun + cal_s_l_fun (obstacles, start) + cal_s_l_deri_fun (start): test_9.py:113-177.
         returns s_map (B,P), obs_s (B,mo), obs_l (B,mo), begin_sl (B,2), start (B,4)."""
         a = self._args(ref_line, origin_xy)
+        a.cycle = True
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         sm, smp = a.out((B, P), np.float64)

@@ -236,8 +236,16 @@ void emp_destroy(emp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
+    for (auto& pool : ctx->cycle_pool)
+        for (auto& b : pool)
+            if (b.p) (void)hipFree(b.p);
+    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
+    for (auto& e : ctx->ev_back)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (auto& kv : ctx->named)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->events)
@@ -254,10 +262,36 @@ const char* emp_last_error(const emp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int emp_synchronize(emp_ctx* ctx) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     return EMP_OK;
 }
 
 void* emp_stream(emp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+void* emp_result_stream(emp_ctx* ctx) {
+    if (!ctx) return nullptr;
+    return (void*)((ctx->pipeline && ctx->stream2) ? ctx->stream2 : ctx->stream);
+}
+
+int emp_set_pipeline(emp_ctx* ctx, int enabled) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    if (enabled && !ctx->stream2) {
+        // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
+        // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
+        // stage's bulk work they overlap with
+        int prio_low = 0, prio_high = 0;
+        EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_high));
+        EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+        for (auto& e : ctx->ev_back) EMP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    ctx->pipeline = enabled != 0;
+    ctx->ev_back_valid[0] = ctx->ev_back_valid[1] = false;
+    return EMP_OK;
+}
 
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
     EMP_REQUIRE(ctx, ctx && out, "NULL argument");
@@ -814,7 +848,24 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     EMP_REQUIRE(ctx, io->traj && io->traj_len && io->status, "traj, traj_len and status are required outputs");
     EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
-    Stage st(ctx, where);
+    // Pipelined mode (device pointers only): this call's temporaries come from the pool of its parity, which the back
+    // stage of the call before the previous one was the last to read.
+    const bool piped = ctx->pipeline && where == EMP_DEVICE && B > 0;
+    struct PoolSwap {                       // the parity's pool stands in for ctx->pool during this call
+        emp_ctx* c;
+        int par;
+        bool on;
+        PoolSwap(emp_ctx* c_, bool on_) : c(c_), par(0), on(on_) {
+            if (!on) return;
+            par = (c->parity ^= 1);
+            std::swap(c->pool, c->cycle_pool[par]);
+        }
+        ~PoolSwap() {
+            if (on) std::swap(c->pool, c->cycle_pool[par]);
+        }
+    } swap_pool(ctx, piped);
+    if (piped && ctx->ev_back_valid[swap_pool.par]) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_back[swap_pool.par], 0));
+    Stage st(ctx, where, piped);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
     const int *d_nr, *d_no;
     if ((rc = st.in(io->ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
@@ -871,13 +922,33 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
     if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
     const QpDev Q = make_qp_dev(q);
-    if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
-                           d_st)))
-        return rc;
-    const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
-    if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
-                                  d_traj, d_tlen, d_st)))
-        return rc;
+    // back stage: on the second stream when pipelined, ordered behind this call's front stage only
+    struct StreamSwap {
+        emp_ctx* c;
+        hipStream_t saved;
+        StreamSwap(emp_ctx* c_, bool on) : c(c_), saved(c_->stream) {
+            if (on) c->stream = c->stream2;
+        }
+        ~StreamSwap() { c->stream = saved; }
+    };
+    if (piped) {
+        EMP_HIP(ctx, hipEventRecord(ctx->ev_front, ctx->stream));
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_front, 0));
+    }
+    {
+        StreamSwap back(ctx, piped);
+        if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
+                               d_st)))
+            return rc;
+        const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
+        if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
+                                      d_traj, d_tlen, d_st)))
+            return rc;
+        if (piped) {
+            EMP_HIP(ctx, hipEventRecord(ctx->ev_back[swap_pool.par], ctx->stream));
+            ctx->ev_back_valid[swap_pool.par] = true;
+        }
+    }
     return st.finish();
 }
 

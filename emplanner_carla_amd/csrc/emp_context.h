@@ -39,6 +39,16 @@ struct emp_ctx {
     };
     std::map<std::string, Ev> events;
     int cu_count = 0;
+    // Two-stage pipelining of consecutive emp_plan_cycle calls (emp_set_pipeline): the back stage (path QP, Cartesian
+    // tail) of call k runs on `stream2` while the front stage (projection, DP) of call k+1 already runs on `stream`.
+    // Each parity has its own pool of temporaries; ev_back[parity] marks the end of the back stage that read them.
+    bool pipeline = false;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_front = nullptr;
+    hipEvent_t ev_back[2] = {nullptr, nullptr};
+    bool ev_back_valid[2] = {false, false};
+    int parity = 0;
+    std::vector<Buf> cycle_pool[2];
 };
 
 namespace emp {
@@ -84,7 +94,14 @@ inline int pool_get(emp_ctx* ctx, size_t bytes, void** out) {
 // to pool buffers and outputs are copied back in finish().
 class Stage {
   public:
-    Stage(emp_ctx* c, emp_mem where) : ctx_(c), dev_(where == EMP_DEVICE) { c->cursor = 0; }
+    // in_cycle: the pipelined emp_plan_cycle orders itself; every OTHER call in pipelined mode first lets the main
+    // stream wait for the back stage still in flight, so that it may consume a cycle's outputs as before
+    Stage(emp_ctx* c, emp_mem where, bool in_cycle = false) : ctx_(c), dev_(where == EMP_DEVICE) {
+        c->cursor = 0;
+        if (!in_cycle && c->pipeline)
+            for (int par = 0; par < 2; ++par)
+                if (c->ev_back_valid[par]) (void)hipStreamWaitEvent(c->stream, c->ev_back[par], 0);
+    }
 
     template <typename T>
     int in(const T* host, size_t n, const T** out) {

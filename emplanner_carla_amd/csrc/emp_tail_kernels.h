@@ -532,6 +532,7 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
                                                            double* __restrict__ path_s, double* __restrict__ path_l,
                                                            int* __restrict__ path_len, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    __builtin_amdgcn_s_setprio(3);     // a chain of dependent instructions: issue ahead of bulk work sharing the SIMD
     constexpr int GPW = 64 / G;                                   // groups (scenes) per wavefront
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
     const int b = blockIdx.x * GPW + grp;
@@ -673,6 +674,7 @@ __device__ __forceinline__ void cycle_cartesian_body(
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
     double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __builtin_amdgcn_s_setprio(3);          // as in the path QP kernel
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     double* sm = lds;                       // [max_ref]
     double* txy = sm + max_ref;             // [cap][2] interleaved x, y

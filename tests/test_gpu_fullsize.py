@@ -244,3 +244,46 @@ def test_rigid_motion_of_the_scene_moves_the_plan_with_it(planner):
             assert np.abs(outm["traj"][sel][:, 2:m, 3] - out["traj"][sel][:, 2:m, 3]).max() < 5e-3
         else:                                          # the boxes bound how far the smoothed points can drift apart
             assert np.abs(moved_traj).max() < 0.4 * np.sqrt(2) + 1e-6
+
+
+def test_pipelined_cycles_equal_plain_cycles(planner):
+    """emp_set_pipeline: the back stage of one batch overlaps the front stage of the next.  Six DIFFERENT batches in
+    flight one after the other (every other call shares its pool of temporaries) give bit-identical results to the plain
+    calls, whether the caller works on the planner's own stream and reads after a synchronize, or on torch's default
+    stream and reads right away."""
+    import torch
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    dev = torch.device("cuda:0")
+    batches = []
+    for k in range(6):
+        b = S.make_batch(range(1000 * k, 1000 * k + 1536 + 64 * k), cfg)      # different sizes as well
+        batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+    torch.cuda.synchronize()
+    plain = []
+    for ins in batches:
+        r = planner.plan_cycle(p, q, sp, **ins)
+        planner.synchronize()
+        plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+    planner.set_pipeline(True)
+    try:
+        with torch.cuda.stream(planner.torch_stream()):                       # the bench's way: no cross-stream waits
+            res = [planner.plan_cycle(p, q, sp, **ins) for ins in batches]
+        planner.synchronize()
+        for k, r in enumerate(res):
+            _assert_same(plain[k], {kk: getattr(r, kk).cpu().numpy() for kk in OUTPUTS}, f"pipelined batch {k}")
+        for k, ins in enumerate(batches):                                       # default stream: results usable at once
+            r = planner.plan_cycle(p, q, sp, **ins)
+            _assert_same(plain[k], {kk: getattr(r, kk).cpu().numpy() for kk in OUTPUTS}, f"pipelined batch {k}, default stream")
+        # another entry point right behind a pipelined cycle sees its finished outputs
+        r = planner.plan_cycle(p, q, sp, **batches[2])
+        sm, _, _, bsl, _ = planner.frenet_project(**batches[2])
+        tgt = planner.frenet_path_to_xy(batches[2]["ref_line"], sm, batches[2]["n_ref"], bsl, r.path_s, r.path_l, r.path_len)[0]
+        planner.set_pipeline(False)
+        r0 = planner.plan_cycle(p, q, sp, **batches[2])
+        tgt0 = planner.frenet_path_to_xy(batches[2]["ref_line"], sm, batches[2]["n_ref"], bsl, r0.path_s, r0.path_l, r0.path_len)[0]
+        planner.synchronize()
+        ok = (plain[2]["status"] & ~1) == 0
+        assert np.array_equal(tgt.cpu().numpy()[ok], tgt0.cpu().numpy()[ok], equal_nan=True)
+    finally:
+        planner.set_pipeline(False)
