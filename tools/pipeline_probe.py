@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from emplanner_carla_amd import _lib
+if os.environ.get("EMP_DBG_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["EMP_DBG_LIB"])
 from emplanner_carla_amd import scenes as S
 from emplanner_carla_amd.api import Planner, dp_params_from_cfg, qp_params, smooth_params, max_path_points
 cfg = S.CFG2
