@@ -241,6 +241,7 @@ class Planner:
         self._torch_stream = None
         self._torch_result_stream = None
         self.pipelined = False
+        self._inflight = []
         self._cur = None
 
     def close(self):
@@ -291,6 +292,7 @@ class Planner:
         self._check(self._lib.emp_set_pipeline(self._h, 1 if enabled else 0))
         self.pipelined = bool(enabled)
         self._torch_result_stream = None
+        self._inflight = []                      # emp_set_pipeline has drained both streams
 
     def torch_result_stream(self):
         """The stream on which a cycle's outputs become complete (the planner's second stream in pipelined mode)."""
@@ -781,6 +783,14 @@ class Planner:
             setattr(io, name, ptr)
         self._check(self._lib.emp_plan_cycle(self._h, C.byref(p), C.byref(q), C.byref(sp), B, P, mo, M, int(mode),
                                              C.byref(io), a.where))
+        if self.pipelined and a.torch:
+            # The outputs of the two calls in flight stay referenced here even if the caller drops them at once:
+            # their memory must not come back from torch's allocator into the next call's outputs while this call's
+            # back stage, or a consumer queued behind it on the result stream, still uses it.  (The call after the
+            # next one waits for this call's back stage before its first kernel.)
+            self._inflight.append((list(res.values()), a.keep))
+            if len(self._inflight) > 2:
+                self._inflight.pop(0)
         return CycleResult(**res)
 
     # ---- scalar utilities -------------------------------------------------------------------

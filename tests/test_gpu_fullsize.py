@@ -287,3 +287,44 @@ def test_pipelined_cycles_equal_plain_cycles(planner):
         assert np.array_equal(tgt.cpu().numpy()[ok], tgt0.cpu().numpy()[ok], equal_nan=True)
     finally:
         planner.set_pipeline(False)
+
+
+def test_pipelined_records_packed_on_the_result_stream(planner):
+    """What a rank of the multi-GPU bench does per step when two batches are in flight: plan on the planner's first
+    stream, pack the result records on the stream on which the results become complete (the gather follows there).
+    The records of every step equal those of the plain call."""
+    import torch
+    from emplanner_carla_amd import dist as emp_dist
+    from emplanner_carla_amd.api import max_path_points
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    M = max_path_points(p)
+    dev = torch.device("cuda:0")
+    batches = []
+    for k in range(5):
+        b = S.make_batch(range(500 * k, 500 * k + 2048), cfg)
+        batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+    torch.cuda.synchronize()
+    want = []
+    for ins in batches:
+        r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+        planner.synchronize()
+        want.append(emp_dist.pack_records(r, p.col, M).cpu().numpy())
+    planner.set_pipeline(True)
+    try:
+        recs = []
+        for ins in batches:
+            with torch.cuda.stream(planner.torch_stream()):
+                r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+            with torch.cuda.stream(planner.torch_result_stream()):
+                recs.append(emp_dist.gather_records(emp_dist.pack_records(r, p.col, M), len(ins["n_obs"])))
+            del r                                       # the step's outputs are released while work is still queued
+        planner.synchronize()
+        torch.cuda.synchronize()
+        for k in range(5):
+            got = recs[k].cpu().numpy()
+            ok = (want[k][:, 0].astype(np.int64) & ~1) == 0
+            assert np.array_equal(got[:, :3], want[k][:, :3])                  # status, lengths
+            assert np.array_equal(got[ok], want[k][ok], equal_nan=True), f"step {k}"
+    finally:
+        planner.set_pipeline(False)
