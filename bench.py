@@ -178,7 +178,7 @@ def main():
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
         if world > 1:
             with torch.cuda.stream(pl.torch_result_stream()):
-                rec = emp_dist.pack_records(res, p.col, M)
+                rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M))
                 return emp_dist.gather_records(rec, total)
         return res
 
@@ -226,7 +226,7 @@ def main():
 
     # outcome statistics of the last step (sanity: the work was really done)
     if world > 1:
-        st = emp_dist.unpack_records(out, p.col, M)["status"].cpu().numpy()
+        st = emp_dist.unpack_records(out, p.col, M, path_cap=emp_dist.path_capacity(M))["status"].cpu().numpy()
     else:
         st = out.status.cpu().numpy()
     ok_frac = float(((st & ~1) == 0).mean())

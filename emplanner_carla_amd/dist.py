@@ -18,36 +18,46 @@ def shard_range(total: int, rank: int, world: int):
     return start, base + (1 if rank < rem else 0)
 
 
-def record_width(col: int, max_pts: int) -> int:
-    """float64 slots per scene: status, traj_len, path_len, dp rows, path (s, l), trajectory (x, y, theta, kappa)."""
-    return 3 + col + 2 * max_pts + 4 * (max_pts + 1)
+def path_capacity(max_pts: int, decimate: int = 2, midpoint: bool = True) -> int:
+    """Most stations a cycle's path can have: the DP path holds at most ``max_pts`` points, every ``decimate``-th goes
+    to the QP, the midpoint re-interleave adds one (test_9.py:187, :204-210); the trajectory has one point more."""
+    return (int(max_pts) + decimate - 1) // decimate + (1 if midpoint else 0)
 
 
-def pack_records(res, col: int, max_pts: int):
+def record_width(col: int, max_pts: int, path_cap: int | None = None) -> int:
+    """float64 slots per scene: status, traj_len, path_len, dp rows, path (s, l), trajectory (x, y, theta, kappa).
+    ``path_cap`` (see ``path_capacity``) trims the path and trajectory arrays to the entries a cycle can fill."""
+    cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
+    return 3 + col + 2 * cap + 4 * (cap + 1)
+
+
+def pack_records(res, col: int, max_pts: int, path_cap: int | None = None):
     """CycleResult (torch tensors or numpy arrays) -> one (B, record_width) float64 matrix."""
     import torch
     as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
     st, tl, pl_ = as_t(res.status), as_t(res.traj_len), as_t(res.path_len)
     B = st.shape[0]
     parts = [st.to(torch.float64).reshape(B, 1), tl.to(torch.float64).reshape(B, 1),
              pl_.to(torch.float64).reshape(B, 1), as_t(res.dp_rows).reshape(B, col),
-             as_t(res.path_s).reshape(B, max_pts), as_t(res.path_l).reshape(B, max_pts),
-             as_t(res.traj).reshape(B, 4 * (max_pts + 1))]
+             as_t(res.path_s).reshape(B, max_pts)[:, :cap], as_t(res.path_l).reshape(B, max_pts)[:, :cap],
+             as_t(res.traj).reshape(B, max_pts + 1, 4)[:, :cap + 1].reshape(B, 4 * (cap + 1))]
     return torch.cat(parts, dim=1).contiguous()
 
 
-def unpack_records(rec, col: int, max_pts: int):
-    """Inverse of pack_records: dict of arrays keyed like CycleResult."""
+def unpack_records(rec, col: int, max_pts: int, path_cap: int | None = None):
+    """Inverse of pack_records: dict of arrays keyed like CycleResult (path / trajectory arrays ``path_cap`` long)."""
+    cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
     B = rec.shape[0]
     o = 3
     out = {"status": rec[:, 0].round().long(), "traj_len": rec[:, 1].round().long(),
            "path_len": rec[:, 2].round().long(), "dp_rows": rec[:, o:o + col]}
     o += col
-    out["path_s"] = rec[:, o:o + max_pts]
-    o += max_pts
-    out["path_l"] = rec[:, o:o + max_pts]
-    o += max_pts
-    out["traj"] = rec[:, o:].reshape(B, max_pts + 1, 4)
+    out["path_s"] = rec[:, o:o + cap]
+    o += cap
+    out["path_l"] = rec[:, o:o + cap]
+    o += cap
+    out["traj"] = rec[:, o:].reshape(B, cap + 1, 4)
     return out
 
 

@@ -134,6 +134,15 @@ def test_pack_unpack_records_roundtrip():
     assert np.array_equal(back["status"].numpy(), res.status) and np.array_equal(back["traj_len"].numpy(), res.traj_len)
     assert np.array_equal(back["traj"].numpy(), res.traj) and np.array_equal(back["path_l"].numpy(), res.path_l)
     assert np.array_equal(back["dp_rows"].numpy(), res.dp_rows)
+    # trimmed to the stations a cycle can fill (what the multi-GPU bench gathers)
+    from emplanner_carla_amd.dist import path_capacity
+    assert path_capacity(41) == 22 and path_capacity(9) == 6 and path_capacity(9, decimate=1, midpoint=False) == 9
+    cap = 6
+    rec = pack_records(res, col, M, path_cap=cap)
+    assert tuple(rec.shape) == (B, record_width(col, M, cap)) and rec.shape[1] < record_width(col, M)
+    back = unpack_records(rec, col, M, path_cap=cap)
+    assert np.array_equal(back["traj"].numpy(), res.traj[:, :cap + 1]) and np.array_equal(back["path_s"].numpy(), res.path_s[:, :cap])
+    assert np.array_equal(back["status"].numpy(), res.status)
 
 
 def test_graft_entry_build_runs_on_cpu():
