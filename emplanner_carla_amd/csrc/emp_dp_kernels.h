@@ -177,10 +177,11 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
                     const double d_lon = os - sn[n];
                     const double d_lat = ol - tab[n * rr + p];
                     const double d2 = d_lon * d_lon + d_lat * d_lat;
-                    if (d2 <= kDanger2) {
-                        c = c + P.w_coll;
-                        break;
-                    } else if (d2 < kSafe2) {
+                    if (d2 < kSafe2) {                                   // most samples are beyond the 6 m reach: one test
+                        if (d2 <= kDanger2) {
+                            c = c + P.w_coll;
+                            break;
+                        }
                         c = c + soft_cost_quotient(d2);
                     }
                 }
