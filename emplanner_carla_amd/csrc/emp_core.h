@@ -95,7 +95,7 @@ EMP_HD double sample_t(int i, double sample_s) { return ((double)i * sample_s) /
 // The reference's third-derivative term is 6 c3 + 24 c4 s + 60 c5 (s * 2) with c_k the ABSOLUTE-s
 // coefficients (quirk, path_planning.py:498/:571).  Rebuild c3, c4, c5 from the shifted ones.
 struct JerkQuirk {
-    double k0, k1, k2;  // 6 c3, 24 c4, 60 c5
+    double k0, k1, k2x2;  // 6 c3, 24 c4, 2 * (60 c5): doubling is exact, so k2x2 * s == (60 c5) * (s * 2) bit for bit
 };
 EMP_HD JerkQuirk jerk_quirk(const Quintic& q, double s0) {
     const double c5 = q.a5;
@@ -104,10 +104,10 @@ EMP_HD JerkQuirk jerk_quirk(const Quintic& q, double s0) {
     JerkQuirk j;
     j.k0 = 6.0 * c3;
     j.k1 = 24.0 * c4;
-    j.k2 = 60.0 * c5;
+    j.k2x2 = (60.0 * c5) * 2.0;
     return j;
 }
-EMP_HD double jerk_quirk_at(const JerkQuirk& j, double s) { return (j.k0 + j.k1 * s) + j.k2 * (s * 2.0); }
+EMP_HD double jerk_quirk_at(const JerkQuirk& j, double s) { return (j.k0 + j.k1 * s) + j.k2x2 * s; }
 
 // ref: cal_obs_cost (path_planning.py:588-609) driven by the caller's d^2 loop (:503-509 / :577-583):
 // ordered scan of the 10 samples of ONE obstacle with the early break on the first hard hit.
