@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight instead of two (emp_set_pipeline off)")
+    ap.add_argument("--force-gather-path", action="store_true",
+                    help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
     ap.add_argument("--cpu-sample", type=int, default=24)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -170,17 +172,32 @@ def main():
     pl.set_pipeline(pipelined)
     ts = pl.torch_stream()
 
+    gather_path = world > 1 or args.force_gather_path
+    gs = torch.cuda.Stream(device=device) if gather_path else None        # the gather's own stream
+    in_flight = []                                                        # (tensors, event) of the last gathers
+
     def step():
         # torch work of a step runs on the planner's own streams, ordered with its kernels without any cross-stream
-        # event: output allocation on the first, and for N > 1 the packing + RCCL gather of the records on the stream
-        # on which the cycle's results become complete (the second one when pipelined)
+        # event: output allocation on the first; for N > 1 the records are packed on the stream on which the cycle's
+        # results become complete (the second one when pipelined) and gathered over RCCL on a third stream, so that
+        # the gather of step k overlaps the back stage of step k+1 as well as its front stage.
         with torch.cuda.stream(ts):
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
-        if world > 1:
-            with torch.cuda.stream(pl.torch_result_stream()):
-                rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M))
-                return emp_dist.gather_records(rec, total)
-        return res
+        if not gather_path:
+            return res
+        rs = pl.torch_result_stream()
+        with torch.cuda.stream(rs):
+            rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M))
+        gs.wait_stream(rs)
+        with torch.cuda.stream(gs):
+            out = emp_dist.gather_records(rec, total)
+            done = torch.cuda.Event()
+            done.record(gs)
+        # the packed records and the gathered matrix stay referenced until their gather has certainly finished
+        in_flight.append((rec, out, done))
+        if len(in_flight) > 3:
+            in_flight.pop(0)[2].synchronize()          # three steps old: long done, costs nothing
+        return out
 
     def fence():
         pl.synchronize()
@@ -225,7 +242,7 @@ def main():
     pl.set_timing(False)
 
     # outcome statistics of the last step (sanity: the work was really done)
-    if world > 1:
+    if gather_path:
         st = emp_dist.unpack_records(out, p.col, M, path_cap=emp_dist.path_capacity(M))["status"].cpu().numpy()
     else:
         st = out.status.cpu().numpy()
