@@ -601,3 +601,56 @@ def test_smoothing_active_set_on_hard_polylines(planner):
         at_bound += int((dev >= 0.2 - 1e-12).sum())
     assert at_bound > 500, "the hard cases really end on their bounds"
     assert iters.max() <= 16, "the active-set iteration settled everywhere (no interior-point fallback)"
+
+
+def test_full_cycle_on_the_wide_lattice_stage_by_stage(planner):
+    """BASELINE config 5's 120x21 lattice with 16 obstacles through the whole cycle: 121-point DP paths, 61-station path
+    QPs (one scene per wavefront) and 62-point trajectories (the wide Cartesian kernel).  The reference's own quintic is
+    too ill-conditioned on this lattice to be the yardstick for the DP (the DP is judged bit for
+    bit against oracle/exact.py in tests/test_gpu_dp.py), so the stages BEHIND the DP are checked against the port fed
+    with the GPU's DP path: bounds + path QP, midpoints, Frenet -> Cartesian + smoothing + heading / curvature."""
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params, max_path_points
+    cfg = S.CFG5
+    b = S.make_batch(range(70, 82), cfg)
+    B, P = b.ref.shape[:2]
+    p = dp_params_from_cfg(cfg)
+    M = max_path_points(p)
+    r = planner.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M,
+                           ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy,
+                           start_v=b.start_v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+    sm, os_, ol_, bsl, start = planner.frenet_project(b.ref, np.full(B, P, np.int32), b.origin_xy, b.start_xy, b.start_v,
+                                                      b.start_a, b.obs_xy, b.n_obs)
+    checked = 0
+    for i in range(B):
+        n = int(r.dp_len[i])
+        assert 100 <= n <= 121           # sample_s = 1.0: int(end_s - start_s) of every 1 m segment is 0 or 1 on a last bit
+        ds, dl = list(r.dp_s[i, :n:2]), list(r.dp_l[i, :n:2])
+        k = int(b.n_obs[i])
+        try:
+            l_min, l_max = op.cal_lmin_lmax(ds, dl, list(os_[i, :k]), list(ol_[i, :k]), cfg.obs_length, cfg.obs_width)
+        except IndexError:
+            assert r.status[i] & 4
+            continue
+        try:
+            ql, _, _, status = op.Quadratic_planning(l_min, l_max, start[i, 1], start[i, 2], start[i, 3], _return_status=True)
+        except np.linalg.LinAlgError:                  # the dense oracle's interior point diverged: infeasible corridor
+            status = "diverged"
+        if status == "diverged":
+            assert r.status[i] & 8, f"scene {i}: the port's QP diverged, the kernel reports {r.status[i]}"
+            continue
+        if status != "optimal":                           # the dense oracle could not certify its own answer: no yardstick
+            continue
+        assert (r.status[i] & ~1) == 0, f"scene {i}: status {r.status[i]}"
+        path_s = [ds[0]] + [(ds[j] + ds[j - 1]) / 2 for j in range(1, len(ql))] + [ds[-1]]
+        path_l = [ql[0]] + [(ql[j] + ql[j - 1]) / 2 for j in range(1, len(ql))] + [ql[-1]]
+        m = len(path_s)
+        assert r.path_len[i] == m and 50 <= m <= 62
+        assert_rel(r.path_l[i, :m], np.asarray(path_l), RTOL, 1.0, f"scene {i} path l")
+        want = np.asarray(op.frenet_2_x_y_theta_kappa(bsl[i, 0], bsl[i, 1], path_s, path_l, [tuple(x) for x in b.ref[i]],
+                                                      list(sm[i])), dtype=np.float64)
+        t = len(want)
+        assert r.traj_len[i] == t
+        assert_rel(r.traj[i, :t, :3], want[:, :3], RTOL, 1.0, f"scene {i} trajectory")
+        assert_rel(r.traj[i, 2:t, 3], want[2:, 3], RTOL, 1e-2, f"scene {i} curvature")
+        checked += 1
+    assert checked >= 4
