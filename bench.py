@@ -117,8 +117,8 @@ def cpu_baseline_pool(cfg_name, workers, per_worker):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scenes-per-gpu", type=int, default=4096)
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
