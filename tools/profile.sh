@@ -6,10 +6,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+STEPS=${STEPS:-100}; WARMUP=${WARMUP:-10}   # bench.py's defaults
+ARGS="bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $TAG -- python $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o $TAG -- python $ARGS > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o $TAG -- python $ARGS > $OUT/bench_pmc_write.log 2>&1
-python bench.py --steps 20 --warmup 5 > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+python bench.py --steps $STEPS --warmup $WARMUP > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 find $OUT -name "*.csv" | head -20
 grep -h '"metric"' $OUT/bench_trace.log | cut -c1-200

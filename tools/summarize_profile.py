@@ -14,6 +14,8 @@ import sys
 
 tag = sys.argv[1]
 scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+warmup = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -40,8 +42,8 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         pmc[k]["launches"] = len(v)
 
 stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
-lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps 20 --warmup 5` on one MI355X ({scenes} scenes/GPU)", "",
-         "`rocprofv3 --kernel-trace --stats` (all launches: 5 warm-up + 20 timed + 5 of the per-kernel diagnostic pass):", "",
+lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps {steps} --warmup {warmup}` on one MI355X ({scenes} scenes/GPU)", "",
+         f"`rocprofv3 --kernel-trace --stats` (all launches: {warmup} warm-up + {steps} timed + the per-kernel diagnostic pass):", "",
          "| kernel | calls | mean us | % of GPU time |", "|---|---|---|---|"]
 for r in stats:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
