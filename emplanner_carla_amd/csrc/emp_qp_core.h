@@ -144,6 +144,25 @@ struct RangeQp {
         wgt = mem; mem += ns * F;
     }
 
+    // Storage of the one-row-per-lane solver (emp_qp_wave.h, range_qp_solve_wave_fast): arrays at offsets that depend
+    // on the CAPACITY only, so that with a compile-time capacity every access is one per-lane base register plus an
+    // immediate offset.  M, s and z (scalar / strided solvers only) are not bound.
+    static constexpr int words_fast(int capN, int capS) { return capN * (KD + 1) + capN * 4 + capS * F * 5 + 4 * F; }   // + slack read past wgt
+    EMP_HD void bind_fast(double* mem, int capN, int capS, int N_, int ns_) {
+        N = N_;
+        ns = ns_;
+        P = mem; mem += capN * (KD + 1);
+        q = mem; mem += capN;
+        u = mem; mem += capN;
+        rhs = mem; mem += capN;
+        dua = mem; mem += capN;
+        c = mem; mem += capS * F;
+        lo = mem; mem += capS * F;
+        hi = mem; mem += capS * F;
+        tmp = mem; mem += capS * F;
+        wgt = mem; mem += capS * F;
+    }
+
     EMP_HD double form_val(int t, int f, const double* vec) const {      // sum_p g[f][p] vec[t+off0+p]
         double v = 0.0;
         for (int p = 0; p < W; ++p) {
@@ -426,6 +445,8 @@ EMP_HD void path_qp_finish(const double* cc, int n, double ds, double* out_l, do
 }
 
 // doubles of scratch path_qp_solve_scalar needs for n stations
+// two scenes per wavefront (n <= 34 stations: N, ns <= 32): fixed layout, 36 coefficient slots + the solver's arrays
+EMP_HD constexpr int path_qp_words_pair() { return 36 + PathRangeQp::words_fast(32, 32); }
 EMP_HD constexpr int path_qp_words(int n) { return PathRangeQp::words(n - 4 > 0 ? n - 4 : 0, n - 2 > 0 ? n - 2 : 0) + n + 2; }
 
 // complete scalar path QP on caller storage `mem` (path_qp_words(n) doubles)

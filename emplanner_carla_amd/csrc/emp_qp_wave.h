@@ -653,7 +653,20 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
 // with clamped indices and zeroed weights instead of bounds branches.  Divisions: four reciprocals per row per
 // iteration (1/s, 1/z); ratio tests use max(-d/x) with those reciprocals.
 // ---------------------------------------------------------------------------------------------
-template <int G, int KD, int F, int W>
+// A value every lane of the wavefront holds alike, moved to scalar registers (there is no scalar FP64 arithmetic, so a
+// uniform product computed by the vector unit would otherwise stay in a vector register for the whole solve).
+__device__ __forceinline__ double wave_uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// LIN: Q was bound with bind_fast at a compile-time capacity and may be read up to three rows outside its arrays
+// (the values are discarded): window and neighbour indices are then plain lane index + constant, not clamped, and
+// every LDS access of the iteration is one of three per-lane base registers plus an immediate offset.
+// UNI: Q.g is the same for every lane of the wavefront (path QP: a function of the launch parameters; NOT the speed
+// QP, whose time step is per scene).
+template <int G, bool LIN = false, bool UNI = false, int KD, int F, int W>
 __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live, int iter_cap) {
     constexpr int B = KD + 1;
     const int N = Q.N, ns = Q.ns, rows = ns * F * 2;
@@ -662,67 +675,75 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
     bool acceptable = false;
     // ---- station role: window of unknowns t+off0 .. t+off0+W-1 (clamped index, zero weight when outside)
     const bool has_t = live && gl < ns;
-    const int t = has_t ? gl : 0;
-    int kc[W];
-    double gm[F][W];
-#pragma unroll
-    for (int p = 0; p < W; ++p) {
-        const int k = t + Q.off0 + p;
-        const bool in = has_t && k >= 0 && k < N;
-        kc[p] = in ? k : 0;
-#pragma unroll
-        for (int f = 0; f < F; ++f) gm[f][p] = in ? Q.g[f][p] : 0.0;
-    }
-    double c_it[F], lo_it[F], hi_it[F], su[F], sl[F], zu[F], zl[F];
+    const int t = (LIN || has_t) ? gl : 0;
+    auto pick = [](const double* a, int i, bool ok, double other) {      // unconditional load, then select
+        const double raw = a[i];
+        return ok ? raw : other;
+    };
+    // When the form weights g[f][p] are the same for every lane (UNI) they and their products stay in scalar registers;
+    // what differs per lane is WHICH window entries exist, kept as bit masks and applied to the loaded values
+    // (0 x g == g x 0: the sums below are the ones a masked-weight form produces).
+    double g[F][W], gg[B][W][F];          // gg[d][p][f] = g[f][p] g[f][p+d]: normal-matrix weights
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        c_it[f] = has_t ? Q.c[t * F + f] : 0.0;
-        lo_it[f] = has_t ? Q.lo[t * F + f] : -1e300;
-        hi_it[f] = has_t ? Q.hi[t * F + f] : 1e300;
-        zu[f] = zl[f] = 1.0;
+#pragma unroll
+        for (int p = 0; p < W; ++p) g[f][p] = UNI ? wave_uniform(Q.g[f][p]) : Q.g[f][p];
     }
+#pragma unroll
+    for (int d = 0; d <= KD; ++d) {
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const double pr = (p + d < W) ? g[f][p] * g[f][(p + d < W) ? p + d : 0] : 0.0;
+                gg[d][p][f] = (UNI && p + d < W) ? wave_uniform(pr) : pr;
+            }
+        }
+    }
+    // Indices, bounds and Hessian rows are re-derived / re-read from LDS where an iteration needs them rather than
+    // held across it: the solve is a chain of dependent instructions, and what it keeps live decides how many other
+    // wavefronts (the next batch's front stage) fit beside it on the SIMD.
+    const int k0 = t + Q.off0;
+    unsigned kin = 0;
+#pragma unroll
+    for (int p = 0; p < W; ++p) kin |= (has_t && k0 + p >= 0 && k0 + p < N) ? (1u << p) : 0u;
+    auto kc = [&](int p) { return LIN ? k0 + p : min(max(k0 + p, 0), max(N - 1, 0)); };
+    double su[F], sl[F], zu[F], zl[F];
+    auto bounds = [&](double (&c_it)[F], double (&lo_it)[F], double (&hi_it)[F]) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            c_it[f] = pick(Q.c, t * F + f, has_t, 0.0);
+            lo_it[f] = pick(Q.lo, t * F + f, has_t, -1e300);
+            hi_it[f] = pick(Q.hi, t * F + f, has_t, 1e300);
+        }
+    };
     auto win = [&](const double* vec, double (&out)[F]) {
         double vals[W];
 #pragma unroll
-        for (int p = 0; p < W; ++p) vals[p] = vec[kc[p]];
+        for (int p = 0; p < W; ++p) vals[p] = pick(vec, kc(p), (kin >> p) & 1u, 0.0);
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             double v = 0.0;
 #pragma unroll
-            for (int p = 0; p < W; ++p) v += gm[f][p] * vals[p];
+            for (int p = 0; p < W; ++p) v += g[f][p] * vals[p];
             out[f] = v;
         }
     };
     // ---- unknown role: Hessian row, symmetric partners, and the stations whose windows contain unknown m
     const bool has_m = live && gl < N;
-    const int m = has_m ? gl : 0;
-    double Prow[B], Plow[B];
-    int up[B], dn[B];
+    const int m = (LIN || has_m) ? gl : 0;
+    auto p_row = [&](int d) { return pick(Q.P, m * B + d, has_m && m + d < N, 0.0); };                                  // P[m][m+d]
+    auto p_low = [&](int d) { return pick(Q.P, (LIN ? m - d : max(m - d, 0)) * B + d, has_m && m - d >= 0, 0.0); };     // P[m-d][m]
+    auto u_up = [&](int d) { return pick(Q.u, (LIN || m + d < N) ? m + d : m, has_m && m + d < N, 0.0); };             // u[m+d]
+    auto u_dn = [&](int d) { return pick(Q.u, (LIN || m - d >= 0) ? m - d : m, has_m && m - d >= 0, 0.0); };           // u[m-d]
+    const int t0 = m - Q.off0;
+    unsigned tin = 0;           // station m-off0-p exists
 #pragma unroll
-    for (int d = 0; d <= KD; ++d) {
-        Prow[d] = (has_m && m + d < N) ? Q.P[m * B + d] : 0.0;
-        Plow[d] = (has_m && d >= 1 && m - d >= 0) ? Q.P[(m - d) * B + d] : 0.0;
-        up[d] = (m + d < N) ? m + d : m;
-        dn[d] = (m - d >= 0) ? m - d : m;
-    }
-    int ti[W];
-    double gq[W][F];            // gather weights g[f][p] (0 when station m-off0-p does not exist)
-    double cM[B][W][F];         // normal-matrix weights g[f][p] g[f][p+d]
-#pragma unroll
-    for (int p = 0; p < W; ++p) {
-        const int tt = m - Q.off0 - p;
-        const bool in = has_m && tt >= 0 && tt < ns;
-        ti[p] = in ? tt : 0;
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            gq[p][f] = in ? Q.g[f][p] : 0.0;
-#pragma unroll
-            for (int d = 0; d <= KD; ++d) cM[d][p][f] = (in && p + d < W && m + d < N) ? Q.g[f][p] * Q.g[f][p + d] : 0.0;
-        }
-    }
-    const double q_m = has_m ? Q.q[m] : 0.0;
-    double u_m = has_m ? Q.u[m] : 0.0;
-    const double pscale = group_max<G>(has_m ? Prow[0] : 0.0);     // largest Hessian diagonal
+    for (int p = 0; p < W; ++p) tin |= (has_m && t0 - p >= 0 && t0 - p < ns) ? (1u << p) : 0u;
+    auto ti = [&](int p) { return LIN ? t0 - p : min(max(t0 - p, 0), max(ns - 1, 0)); };
+    const double q_m = pick(Q.q, m, has_m, 0.0);
+    double u_m = pick(Q.u, m, has_m, 0.0);
+    const double pscale = group_max<G>(p_row(0));     // largest Hessian diagonal
     {
         const double z0 = Q.initial_multiplier(pscale);
 #pragma unroll
@@ -733,14 +754,15 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
 #pragma unroll
         for (int p = 0; p < W; ++p) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) acc += gq[p][f] * coef[ti[p] * F + f];
+            for (int f = 0; f < F; ++f) acc += g[f][p] * pick(coef, ti(p) * F + f, (tin >> p) & 1u, 0.0);
         }
         return acc;
     };
     // ---- initial slacks (pushed to >= 1) and unit multipliers
     double qscale = fmax(group_max<G>(has_m ? fabs(q_m) : 0.0), 1.0);
     {
-        double v[F];
+        double v[F], c_it[F], lo_it[F], hi_it[F];
+        bounds(c_it, lo_it, hi_it);
         win(Q.u, v);
         double smin = 1e300;
 #pragma unroll
@@ -762,12 +784,19 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         EMP_QP_PROF(0);
         // ---- 1: stations: residuals, reciprocals, rd gather coefficient, barrier weight
         double v[F], rpu[F], rpl[F], isu[F], isl[F], izu[F], izl[F], wu[F], wl[F];
-        win(Q.u, v);
+        {
+            double c_it[F], lo_it[F], hi_it[F];
+            bounds(c_it, lo_it, hi_it);
+            win(Q.u, v);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                rpu[f] = (c_it[f] + v[f]) - hi_it[f] + su[f];
+                rpl[f] = lo_it[f] - (c_it[f] + v[f]) + sl[f];
+            }
+        }
         double rp_max = 0.0, zmax = 0.0, mu = 0.0;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            rpu[f] = (c_it[f] + v[f]) - hi_it[f] + su[f];
-            rpl[f] = lo_it[f] - (c_it[f] + v[f]) + sl[f];
             isu[f] = fast_rcp(su[f]);
             isl[f] = fast_rcp(sl[f]);
             izu[f] = fast_rcp(zu[f]);
@@ -792,23 +821,23 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         if (run && has_m) {
             double acc = q_m;
 #pragma unroll
-            for (int d = 0; d <= KD; ++d) acc += Prow[d] * Q.u[up[d]];
+            for (int d = 0; d <= KD; ++d) acc += p_row(d) * u_up(d);
 #pragma unroll
-            for (int d = 1; d <= KD; ++d) acc += Plow[d] * Q.u[dn[d]];
+            for (int d = 1; d <= KD; ++d) acc += p_low(d) * u_dn(d);
             rd_m = acc + gather(Q.tmp);
             double wv[W][F];
 #pragma unroll
             for (int p = 0; p < W; ++p)
 #pragma unroll
-                for (int f = 0; f < F; ++f) wv[p][f] = Q.wgt[ti[p] * F + f];
+                for (int f = 0; f < F; ++f) wv[p][f] = pick(Q.wgt, ti(p) * F + f, (tin >> p) & 1u, 0.0);
 #pragma unroll
             for (int d = 0; d <= KD; ++d) {
-                double e = Prow[d];
+                double e = p_row(d);
 #pragma unroll
                 for (int p = 0; p < W; ++p)
 #pragma unroll
-                    for (int f = 0; f < F; ++f) e += wv[p][f] * cM[d][p][f];
-                fa[d] = e;
+                    for (int f = 0; f < F; ++f) e += wv[p][f] * gg[d][p][f];
+                fa[d] = (m + d < N) ? e : 0.0;
             }
         }
         EMP_QP_PROF(2);
@@ -1004,7 +1033,7 @@ __device__ inline int path_qp_setup_group(PathRangeQp& Q, double* cc, const doub
 
 // ---------------------------------------------------------------------------------------------
 // Path QP on one GROUP of G lanes (G = 64: one scene per wavefront, G = 32: two scenes side by side).
-// lds: this group's path_qp_words(n) doubles.  l_min / l_max / outputs may be LDS or global.  EVERY lane of the
+// lds: this group's path_qp_words(n) doubles (G = 32: path_qp_words_pair()).  l_min / l_max / outputs may be LDS or global.  EVERY lane of the
 // wavefront must call this (it contains barriers); a group with live == false only takes part in them.
 // G = 32 requires n <= 34 (N, ns <= 32).  returns (per group) 0 ok, 1 infeasible, 2 failed.
 // ---------------------------------------------------------------------------------------------
@@ -1017,7 +1046,8 @@ __device__ inline int path_qp_group(double* lds, const double* l_min, const doub
     PathRangeQp Q;
     double* cc = lds;
     const int nn = live ? n : 4;
-    Q.bind(lds + nn + 2, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
+    if constexpr (G == 32) Q.bind_fast(lds + 36, 32, 32, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);   // path_qp_words_pair()
+    else Q.bind(lds + nn + 2, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
     int rc = path_qp_setup_group<G>(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm, gl, live);
     if (!live) rc = 2;
     if (debug_stage == 2) rc = 2;
@@ -1054,7 +1084,7 @@ __device__ inline int path_qp_group(double* lds, const double* l_min, const doub
     ok = rc == 0;
     const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
     int rs;
-    if (small || G == 32) rs = range_qp_solve_wave_fast<G>(Q, gl, ok && Q.N > 0, cap_it);
+    if (small || G == 32) rs = range_qp_solve_wave_fast<G, G == 32, true>(Q, gl, ok && Q.N > 0, cap_it);
     else rs = range_qp_solve_wave<G>(Q, gl, ok && Q.N > 0, cap_it);
     if (ok && Q.N > 0) {
         *iters_out = Q.iters;

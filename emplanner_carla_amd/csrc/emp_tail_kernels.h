@@ -518,10 +518,15 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 // ---------------------------------------------------------------------------------------------
 // One cycle, middle part (ref test_9.py:187-210): decimate -> bounds -> path QP -> midpoints.
 // One scene per GROUP of G lanes (G = 32: two scenes per wavefront when cap <= 34 stations, else G = 64).
-// dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)
+// dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)  (G = 32: + path_qp_words_pair() instead)
 // ---------------------------------------------------------------------------------------------
+#ifdef EMP_QP_WAVES      // development switch: force the register budget of N wavefronts per SIMD
+#define EMP_QP_OCC __attribute__((amdgpu_waves_per_eu(EMP_QP_WAVES, EMP_QP_WAVES)))
+#else
+#define EMP_QP_OCC
+#endif
 template <int G>
-__global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, int max_obs, int cap, QpDev Q,
+__global__ __launch_bounds__(64) EMP_QP_OCC void cycle_qp_wave_kernel(int B, int max_pts, int max_obs, int cap, QpDev Q,
                                                            const double* __restrict__ dp_s,
                                                            const double* __restrict__ dp_l,
                                                            const int* __restrict__ dp_len,
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(int B, int max_pts, i
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
     const int b = blockIdx.x * GPW + grp;
     const bool present = b < B;
-    const int per_group = 5 * cap + 4 * max_obs + path_qp_words(cap);
+    const int per_group = 5 * cap + 4 * max_obs + (G == 32 ? path_qp_words_pair() : path_qp_words(cap));
     double* lds = lds_all + (size_t)grp * per_group;
     const size_t o = (size_t)(present ? b : 0) * max_pts;
     double* sd = lds;                 // decimated station s   [cap]

@@ -71,10 +71,11 @@ def _assert_same(a, b, what):
     a, b = _masked(a), _masked(b)
     for k in OUTPUTS:
         ok = (a["status"] & ~1) == 0                       # refused scenes: only the status is specified
-        if k in ("status", "dp_rows"):
-            assert np.array_equal(a[k], b[k]), f"{what}: {k}"
-        else:
-            assert np.array_equal(a[k][ok], b[k][ok]), f"{what}: {k}"
+        x, y = (a[k], b[k]) if k in ("status", "dp_rows") else (a[k][ok], b[k][ok])
+        if not np.array_equal(x, y):
+            rows = np.nonzero(np.any(x.reshape(len(x), -1) != y.reshape(len(y), -1), axis=1))[0]
+            raise AssertionError(f"{what}: {k} differs in {rows.size} of {len(x)} scenes, first {rows[:8].tolist()}; "
+                                 f"status there {a['status'][ok][rows[:8]].tolist() if k not in ('status', 'dp_rows') else a['status'][rows[:8]].tolist()}")
 
 
 def _check_golden_subset(out):
