@@ -921,9 +921,9 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         return rc;
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
     if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
-    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
     const QpDev Q = make_qp_dev(q);
-    // back stage: on the second stream when pipelined, ordered behind this call's front stage only
+    // back stage (densified DP path, path QP, Cartesian tail: short kernels that last as long as their slowest scene):
+    // on the second stream when pipelined, ordered behind this call's front stage only
     struct StreamSwap {
         emp_ctx* c;
         hipStream_t saved;
@@ -938,6 +938,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     }
     {
         StreamSwap back(ctx, piped);
+        if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
         if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
                                d_st)))
             return rc;

@@ -122,11 +122,11 @@ int emp_set_timing(emp_ctx* ctx, int enabled);
 int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
 
 /* Two-stage pipelining of CONSECUTIVE emp_plan_cycle calls with device pointers (off by default).  The cycle is a
- * front stage (projection, S-L DP: FP64-issue and HBM bound) and a back stage (path QP, Cartesian tail: bound by the
- * latency of their slowest scene, the GPU mostly idle).  When enabled, the back stage of call k runs on a second
+ * front stage (projection, S-L DP edge costs and sweep: FP64-issue and HBM bound) and a back stage (densified DP path,
+ * path QP, Cartesian tail: bound by the latency of their slowest scene, the GPU mostly idle).  When enabled, the back stage of call k runs on a second
  * stream while the front stage of call k+1 already runs on emp_stream(): two batches are in flight.  Consequences for
  * the caller: the outputs of a call are complete on emp_result_stream() (emp_synchronize waits for both streams); each
- * call in flight needs its OWN output buffers (the next call's front stage writes dp_rows / dp_s / dp_l / status while
+ * call in flight needs its OWN output buffers (the next call's front stage writes dp_rows / status while
  * the previous call's back stage still reads its own); the inputs of a call must stay unchanged until its back stage
  * is done.  A third call waits for the first one's back stage.  Results are bit-identical to the unpipelined call. */
 int emp_set_pipeline(emp_ctx* ctx, int enabled);
