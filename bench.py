@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight instead of two (emp_set_pipeline off)")
     ap.add_argument("--force-gather-path", action="store_true",
                     help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
-    ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
     ap.add_argument("--cpu-pool-scenes", type=int, default=16, help="scenes per pool process")
