@@ -5,7 +5,7 @@
 // (Mehrotra predictor-corrector on the reduced normal equations) and stopping rule as RangeQp::solve_scalar:
 //   * range_qp_solve_wave_fast - one station and one unknown per lane (N, ns <= G): per-station and per-unknown
 //     state, the normal matrix and its factor in registers; vectors that lanes of different roles exchange go
-//     through LDS.  The path QP of the cycle runs here.
+//     through LDS.  The path QP of the cycle runs here (two scenes per wavefront: LIN / UNI variants, 163 VGPRs).
 //   * box_qp_lanes / smooth_pair_lanes - the smoothing QP (G = I): registers only.
 //   * range_qp_solve_wave - any size: arrays in LDS, serial factorisation by lane 0 of the group.
 // The banded Cholesky and the substitutions of the first two tiers are lane-shift sweeps (band_chol_group /
@@ -673,7 +673,8 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
     int state = (live && N > 0) ? 1 : 0;
     int iters = 0;
     bool acceptable = false;
-    // ---- station role: window of unknowns t+off0 .. t+off0+W-1 (clamped index, zero weight when outside)
+    // ---- station role: window of unknowns t+off0 .. t+off0+W-1 (entries outside 0..N-1 are loaded from a valid address
+    // and replaced by zero)
     const bool has_t = live && gl < ns;
     const int t = (LIN || has_t) ? gl : 0;
     auto pick = [](const double* a, int i, bool ok, double other) {      // unconditional load, then select
