@@ -654,3 +654,46 @@ def test_full_cycle_on_the_wide_lattice_stage_by_stage(planner):
         assert_rel(r.traj[i, 2:t, 3], want[2:, 3], RTOL, 1e-2, f"scene {i} curvature")
         checked += 1
     assert checked >= 4
+
+
+@pytest.mark.parametrize("col,max_pts,stations", [(33, None, 33), (34, 68, 34), (34, None, 34)])
+def test_paired_path_qp_at_its_size_limits(planner, col, max_pts, stations):
+    """The cycle's path QP packs two scenes into a wavefront while a scene has at most 34 stations (32 free
+    coefficients, 32 constrained stations: every lane of both half-waves busy) and its LDS arrays are addressed with
+    fixed strides and unclamped neighbour indices.  33 and 34 stations through that kernel, 34 through the
+    one-scene-per-wavefront kernel (the output capacity decides), each against oracle/ref_port.plan_cycle."""
+    from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
+    cfg = S.LatticeConfig(f"limits_{col}x5", row=5, col=col, sample_s=2.0, sample_l=1.0, sampling_res=1, n_obs=4)
+    seeds = list(range(300, 316))
+    b = S.make_batch(seeds, cfg)
+    B, P = b.ref.shape[:2]
+    kwargs = {} if max_pts is None else {"max_pts": max_pts}
+    r = planner.plan_cycle(dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width),
+                           smooth_params(), ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy,
+                           start_xy=b.start_xy, start_v=b.start_v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs,
+                           **kwargs)
+    kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
+    compared = at_size = 0
+    for i in range(B):
+        try:
+            want = op.plan_cycle([tuple(x) for x in b.ref[i]], b.origin_xy[i], b.start_xy[i], b.start_v[i], b.start_a[i],
+                                 b.obs_xy[i, :b.n_obs[i]], dp_kwargs=kw, obs_length=cfg.obs_length,
+                                 obs_width=cfg.obs_width, verbose=False)
+        except IndexError:
+            assert r.status[i] & (2 | 4), f"scene {i}: the reference raises IndexError"
+            continue
+        assert np.array_equal(r.dp_rows[i], np.asarray(want["dp_rows"], dtype=np.float64)), f"scene {i}: DP rows"
+        if want.get("qp_status") not in (None, "optimal"):
+            assert r.status[i] & 8
+            continue
+        if max_pts is not None and len(want["dp_s"]) > max_pts:
+            assert r.status[i] & 32, f"scene {i}: {len(want['dp_s'])} DP points do not fit {max_pts}: EMP_ST_TRUNCATED"
+            continue
+        assert (r.status[i] & ~1) == 0, f"scene {i}: status {r.status[i]}"
+        n = len(want["qp_l"])
+        at_size += n == stations
+        m = len(want["trajectory"])
+        assert r.traj_len[i] == m
+        assert_rel(r.traj[i, :m, :3], np.asarray(want["trajectory"], dtype=np.float64)[:, :3], RTOL, 1.0, f"scene {i} trajectory")
+        compared += 1
+    assert compared >= 10 and at_size >= 8
