@@ -166,18 +166,17 @@ class _Args:
     def done(self):
         """After the library call: torch's current stream waits for the planner's stream, so that reading an output
         tensor from torch code (``.cpu()``, another kernel) sees the finished result.  In pipelined mode the results
-        of a cycle are produced on the planner's second stream: the outputs are tied to it (the caching allocator must
-        not hand their memory out again before that stream is done with it) and a caller on any OTHER stream waits
-        for it; a caller that works on the planner's own streams orders itself (``Planner.torch_result_stream``)."""
+        of a cycle are produced on the planner's second stream: a caller on any OTHER stream waits for it; a caller
+        that works on the planner's own streams orders itself (``Planner.torch_result_stream``)."""
         if not (self.torch and self.planner is not None):
             return
         piped = self.planner.pipelined and self.cycle
         if piped:
-            rs = self.planner.torch_result_stream()
-            for o in self.outs:
-                o.record_stream(rs)
+            # (No Tensor.record_stream on the outputs: it would tie their memory to a stream that dies with the planner
+            # while the caching allocator still wants to record events on it; Planner.plan_cycle keeps the outputs of
+            # the calls in flight referenced instead.)
             if not self.same_stream:
-                self.t.cuda.current_stream(self.device).wait_stream(rs)
+                self.t.cuda.current_stream(self.device).wait_stream(self.planner.torch_result_stream())
         elif not self.same_stream:
             self.t.cuda.current_stream(self.device).wait_stream(self.planner.torch_stream())
 
@@ -392,7 +391,6 @@ class Planner:
         """ref cal_s_map_fun + cal_s_l_fun (obstacles, start) + cal_s_l_deri_fun (start): test_9.py:113-177.
         returns s_map (B,P), obs_s (B,mo), obs_l (B,mo), begin_sl (B,2), start (B,4)."""
         a = self._args(ref_line, origin_xy)
-        a.cycle = True
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         sm, smp = a.out((B, P), np.float64)
@@ -759,6 +757,7 @@ class Planner:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
         of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169."""
         a = self._args(ref_line, origin_xy)
+        a.cycle = True               # pipelined mode: the outputs become complete on the result stream (see _Args.done)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         M = int(max_pts) if max_pts else max_path_points(p)

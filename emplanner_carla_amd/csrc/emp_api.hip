@@ -62,11 +62,8 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
     emp_ctx::Buf& tb = ctx->named["dp_pair_table"];
     if (tb.bytes < tab_bytes) {
-        if (tb.p) EMP_HIP(ctx, hipFree(tb.p));
-        tb.p = nullptr;
-        tb.bytes = 0;
-        EMP_HIP(ctx, hipMalloc(&tb.p, tab_bytes));
-        tb.bytes = tab_bytes;
+        const int grc = grow_buffer(ctx, tb, tab_bytes);
+        if (grc) return grc;
         ctx->pair_table_valid = false;
     }
     if (!ctx->pair_table_valid || memcmp(key, ctx->pair_table_key, sizeof(key)) != 0) {
@@ -135,23 +132,26 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
 }
 
 // DP_algorithm up to the backtrack.  `edge_scratch` may be NULL: taken from the named scratch.
+// The edge tensor (and the start costs behind it) of the current call.  One per pipeline parity: with two batches in
+// flight the sweep of call k may still read its tensor while the edge kernel of call k+1 writes the other one.
+static int dp_edge_tensor(emp_ctx* ctx, const DpDev& d, double** edge, double** start_cost) {
+    const size_t need = (tiled_elems(d) + (size_t)d.B * d.row) * sizeof(double);
+    emp_ctx::Buf& sc = ctx->named[ctx->parity ? "dp_edge_tensor_1" : "dp_edge_tensor_0"];
+    const int grc = grow_buffer(ctx, sc, need);
+    if (grc) return grc;
+    *edge = (double*)sc.p;
+    *start_cost = *edge + tiled_elems(d);
+    return EMP_OK;
+}
+
 static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, emp_dp_mode mode, double* rows, double* min_cost, int* status) {
     (void)mode;  // EMP_DP_FUSED currently shares the two-kernel path
     if (d.B == 0) return EMP_OK;
-    const size_t need = (tiled_elems(d) + (size_t)d.B * d.row) * sizeof(double);
-    emp_ctx::Buf& sc = ctx->named["dp_edge_tensor"];
-    if (sc.bytes < need) {
-        if (sc.p) EMP_HIP(ctx, hipFree(sc.p));
-        sc.p = nullptr;
-        sc.bytes = 0;
-        EMP_HIP(ctx, hipMalloc(&sc.p, need));
-        sc.bytes = need;
-    }
-    double* edge = (double*)sc.p;
-    double* start_cost = edge + tiled_elems(d);
-    int rc = dev_dp_edge(ctx, d, obs_s, obs_l, n_obs, start, start_cost, edge, true);
+    double *edge, *start_cost;
+    int rc = dp_edge_tensor(ctx, d, &edge, &start_cost);
     if (rc) return rc;
+    if ((rc = dev_dp_edge(ctx, d, obs_s, obs_l, n_obs, start, start_cost, edge, true))) return rc;
     return dev_dp_sweep(ctx, d, start_cost, edge, n_obs, rows, min_cost, status);
 }
 
@@ -302,6 +302,7 @@ int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
 int emp_device_free(emp_ctx* ctx, void* ptr) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     EMP_HIP(ctx, hipFree(ptr));
     return EMP_OK;
 }
@@ -920,7 +921,11 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                           d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
-    if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
+    (void)mode;
+    double *d_edge, *d_start_cost;
+    if ((rc = dp_edge_tensor(ctx, d, &d_edge, &d_start_cost))) return rc;
+    if ((rc = dev_dp_edge(ctx, d, d_os, d_ol, d_no, d_start, d_start_cost, d_edge, true))) return rc;
+    if ((rc = dev_dp_sweep(ctx, d, d_start_cost, d_edge, d_no, d_rows, nullptr, d_st))) return rc;
     const QpDev Q = make_qp_dev(q);
     // back stage (densified DP path, path QP, Cartesian tail: short kernels that last as long as their slowest scene):
     // on the second stream when pipelined, ordered behind this call's front stage only

@@ -73,19 +73,31 @@ inline int fail(emp_ctx* ctx, int code, const std::string& msg) {
         if (!(cond)) return emp::fail((ctx), EMP_ERR_INVALID, std::string(msg));                   \
     } while (0)
 
+// Grow-only device buffer with 25 % headroom.  A buffer is replaced only once nothing queued on either of the context's
+// streams can still touch it: with two batches in flight the back stage of an earlier call may be reading the very
+// temporaries a larger batch now outgrows, and hipFree's own implicit synchronisation is not relied upon.
+inline int grow_buffer(emp_ctx* ctx, emp_ctx::Buf& b, size_t bytes) {
+    if (b.bytes >= bytes) return EMP_OK;
+    if (b.p) {
+        EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        EMP_HIP(ctx, hipFree(b.p));
+    }
+    b.p = nullptr;
+    b.bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    EMP_HIP(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return EMP_OK;
+}
+
 // device scratch from the per-call pool
 inline int pool_get(emp_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 8;
     if (ctx->cursor == ctx->pool.size()) ctx->pool.push_back({});
     emp_ctx::Buf& b = ctx->pool[ctx->cursor++];
-    if (b.bytes < bytes) {
-        if (b.p) EMP_HIP(ctx, hipFree(b.p));
-        b.p = nullptr;
-        b.bytes = 0;
-        size_t want = bytes + bytes / 4;
-        EMP_HIP(ctx, hipMalloc(&b.p, want));
-        b.bytes = want;
-    }
+    const int rc = grow_buffer(ctx, b, bytes);
+    if (rc) return rc;
     *out = b.p;
     return EMP_OK;
 }
