@@ -187,7 +187,7 @@ def main():
             return res
         rs = pl.torch_result_stream()
         with torch.cuda.stream(rs):
-            rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M))
+            rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M), planner=pl)
         gs.wait_stream(rs)
         with torch.cuda.stream(gs):
             out = emp_dist.gather_records(rec, total)

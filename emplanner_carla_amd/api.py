@@ -792,6 +792,33 @@ class Planner:
                 self._inflight.pop(0)
         return CycleResult(**res)
 
+    def pack_records(self, res: "CycleResult", col: int, max_pts: int, path_cap=None):
+        """One fixed-stride float64 record per scene from a cycle's outputs on the device, in ONE launch
+        (emp_pack_records; layout of ``emplanner_carla_amd.dist.record_width``).  The launch goes to the stream on which
+        the cycle's outputs become complete (``torch_result_stream()``); a caller on another stream is ordered with it."""
+        import torch
+        cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
+        B = int(res.status.shape[0])
+        dev = res.status.device
+        width = 3 + int(col) + 2 * cap + 4 * (cap + 1)
+        cur = torch.cuda.current_stream(dev)
+        target = self.torch_result_stream()
+        foreign = int(cur.cuda_stream) != int(target.cuda_stream)
+        if foreign:
+            target.wait_stream(cur)
+        rec = torch.empty((B, width), dtype=torch.float64, device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        arrs = [res.status, res.traj_len, res.path_len, res.dp_rows, res.path_s, res.path_l, res.traj]
+        for t_ in arrs:
+            if not (t_.is_cuda and t_.is_contiguous()):
+                raise ValueError("pack_records takes the contiguous device tensors plan_cycle returned")
+        self._cur = None
+        self._check(self._lib.emp_pack_records(self._h, B, int(col), int(max_pts), cap, *[ptr(t_) for t_ in arrs], ptr(rec),
+                                               1 if self.pipelined else 0, L.EMP_DEVICE))
+        if foreign:
+            cur.wait_stream(target)
+        return rec
+
     # ---- scalar utilities -------------------------------------------------------------------
     def quintic_coefficients(self, bc):
         """ref cal_quintic_coefficient: bc (n,8) -> coeff (n,6) in the absolute-s basis."""

@@ -273,6 +273,66 @@ void* emp_result_stream(emp_ctx* ctx) {
     return (void*)((ctx->pipeline && ctx->stream2) ? ctx->stream2 : ctx->stream);
 }
 
+// one thread per record slot; consecutive threads write consecutive doubles
+__global__ __launch_bounds__(256) void pack_records_kernel(int B, int col, int max_pts, int cap, const int* __restrict__ status,
+                                                           const int* __restrict__ traj_len,
+                                                           const int* __restrict__ path_len,
+                                                           const double* __restrict__ dp_rows,
+                                                           const double* __restrict__ path_s,
+                                                           const double* __restrict__ path_l,
+                                                           const double* __restrict__ traj, double* __restrict__ rec) {
+    const int width = 3 + col + 2 * cap + 4 * (cap + 1);
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * width) return;
+    const int b = (int)(idx / width);
+    int c = (int)(idx - (size_t)b * width);
+    double v;
+    if (c < 3) {
+        v = (double)(c == 0 ? status[b] : c == 1 ? traj_len[b] : path_len[b]);
+    } else if ((c -= 3) < col) {
+        v = dp_rows[(size_t)b * col + c];
+    } else if ((c -= col) < cap) {
+        v = path_s[(size_t)b * max_pts + c];
+    } else if ((c -= cap) < cap) {
+        v = path_l[(size_t)b * max_pts + c];
+    } else {
+        v = traj[(size_t)b * (max_pts + 1) * 4 + (c - cap)];
+    }
+    rec[idx] = v;
+}
+
+int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int32_t path_cap, const int32_t* status,
+                     const int32_t* traj_len, const int32_t* path_len, const double* dp_rows, const double* path_s,
+                     const double* path_l, const double* traj, double* rec, int on_result_stream, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && col >= 1 && max_pts >= 1 && path_cap >= 1 && path_cap <= max_pts, "bad sizes");
+    EMP_REQUIRE(ctx, status && traj_len && path_len && dp_rows && path_s && path_l && traj && rec, "NULL array");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    const bool on_rs = on_result_stream && ctx->pipeline && ctx->stream2 && where == EMP_DEVICE;
+    Stage st(ctx, where, on_rs);             // on the result stream the launch is ordered behind the cycle by the stream itself
+    int rc;
+    const int *d_st, *d_tl, *d_pl;
+    const double *d_rows, *d_ps, *d_pll, *d_traj;
+    double* d_rec;
+    const size_t width = 3 + (size_t)col + 2 * (size_t)path_cap + 4 * ((size_t)path_cap + 1);
+    if ((rc = st.in(status, (size_t)B, &d_st))) return rc;
+    if ((rc = st.in(traj_len, (size_t)B, &d_tl))) return rc;
+    if ((rc = st.in(path_len, (size_t)B, &d_pl))) return rc;
+    if ((rc = st.in(dp_rows, (size_t)B * col, &d_rows))) return rc;
+    if ((rc = st.in(path_s, (size_t)B * max_pts, &d_ps))) return rc;
+    if ((rc = st.in(path_l, (size_t)B * max_pts, &d_pll))) return rc;
+    if ((rc = st.in(traj, (size_t)B * (max_pts + 1) * 4, &d_traj))) return rc;
+    if ((rc = st.out(rec, (size_t)B * width, &d_rec))) return rc;
+    if (B) {
+        const size_t total = (size_t)B * width;
+        hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           on_rs ? ctx->stream2 : ctx->stream, B, col, max_pts, path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll,
+                           d_traj, d_rec);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
 int emp_set_pipeline(emp_ctx* ctx, int enabled) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_HIP(ctx, hipSetDevice(ctx->device));

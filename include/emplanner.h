@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 4
+#define EMP_ABI_VERSION 5
 
 typedef struct emp_ctx emp_ctx;
 
@@ -131,6 +131,16 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  * is done.  A third call waits for the first one's back stage.  Results are bit-identical to the unpipelined call. */
 int emp_set_pipeline(emp_ctx* ctx, int enabled);
 void* emp_result_stream(emp_ctx* ctx);
+
+/* One fixed-stride record per scene for the multi-GPU gather (no reference counterpart: the reference plans one scene
+ * per process; this is the result exchange of the batched form, emplanner_carla_amd/dist.py):
+ *   rec [B][3 + col + 2*path_cap + 4*(path_cap+1)] doubles = status, traj_len, path_len, dp_rows [col],
+ *   path_s [path_cap], path_l [path_cap], traj [path_cap+1][4]
+ * from the outputs of emp_plan_cycle (arrays with max_pts / max_pts+1 entries per scene, path_cap <= max_pts of them
+ * kept).  One launch; on_result_stream != 0 queues it on emp_result_stream(), behind the cycle that produced them. */
+int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int32_t path_cap, const int32_t* status,
+                     const int32_t* traj_len, const int32_t* path_len, const double* dp_rows, const double* path_s,
+                     const double* path_l, const double* traj, double* rec, int on_result_stream, emp_mem where);
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
 int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
 

@@ -338,3 +338,50 @@ def test_pipelined_records_packed_on_the_result_stream(planner):
             assert np.array_equal(got[ok], want[k][ok], equal_nan=True), f"step {k}"
     finally:
         planner.set_pipeline(False)
+
+
+def test_native_record_packing_equals_the_torch_form(planner):
+    """emp_pack_records (one launch) against the torch concatenation of emplanner_carla_amd.dist.pack_records, bit for
+    bit, full and trimmed records: plain mode from torch's default stream, pipelined mode from the result stream (the
+    bench's per-step pattern, the step's outputs dropped at once) and from the default stream."""
+    import torch
+    from emplanner_carla_amd import dist as emp_dist
+    from emplanner_carla_amd.api import max_path_points
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    M = max_path_points(p)
+    dev = torch.device("cuda:0")
+    batches = []
+    for k in range(4):
+        b = S.make_batch(range(700 * k, 700 * k + 1500 + 32 * k), cfg)
+        batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+    torch.cuda.synchronize()
+    same = lambda x, y: np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    want = []
+    for ins in batches:
+        r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+        for cap in (None, emp_dist.path_capacity(M)):
+            ref = emp_dist.pack_records(r, p.col, M, path_cap=cap).cpu().numpy()
+            got = emp_dist.pack_records(r, p.col, M, path_cap=cap, planner=planner).cpu().numpy()
+            assert got.shape == (len(ins["n_obs"]), emp_dist.record_width(p.col, M, cap)) and same(got, ref)
+        want.append(ref)
+    planner.set_pipeline(True)
+    try:
+        recs = []
+        for ins in batches:
+            with torch.cuda.stream(planner.torch_stream()):
+                r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+            with torch.cuda.stream(planner.torch_result_stream()):
+                recs.append(emp_dist.pack_records(r, p.col, M, path_cap=emp_dist.path_capacity(M), planner=planner))
+            del r
+        planner.synchronize()
+        torch.cuda.synchronize()
+        for k, ins in enumerate(batches):
+            ok = (want[k][:, 0].astype(np.int64) & ~1) == 0
+            got = recs[k].cpu().numpy()
+            assert np.array_equal(got[:, :3], want[k][:, :3]) and same(got[ok], want[k][ok]), f"step {k}"
+            r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)                  # default stream, used at once
+            got = planner.pack_records(r, p.col, M, emp_dist.path_capacity(M)).cpu().numpy()
+            assert np.array_equal(got[:, :3], want[k][:, :3]) and same(got[ok], want[k][ok]), f"default stream, step {k}"
+    finally:
+        planner.set_pipeline(False)
