@@ -796,11 +796,19 @@ class Planner:
         """One fixed-stride float64 record per scene from a cycle's outputs on the device, in ONE launch
         (emp_pack_records; layout of ``emplanner_carla_amd.dist.record_width``).  The launch goes to the stream on which
         the cycle's outputs become complete (``torch_result_stream()``); a caller on another stream is ordered with it."""
-        import torch
         cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
         B = int(res.status.shape[0])
-        dev = res.status.device
         width = 3 + int(col) + 2 * cap + 4 * (cap + 1)
+        if not _is_torch(res.status):                       # host arrays: staged through the library like any other call
+            a = self._args(res.status)
+            ptrs = [a.inp(res.status, np.int32, (B,)), a.inp(res.traj_len, np.int32, (B,)), a.inp(res.path_len, np.int32, (B,)),
+                    a.inp(res.dp_rows, np.float64, (B, int(col))), a.inp(res.path_s, np.float64, (B, int(max_pts))),
+                    a.inp(res.path_l, np.float64, (B, int(max_pts))), a.inp(res.traj, np.float64, (B, int(max_pts) + 1, 4))]
+            rec, rp = a.out((B, width), np.float64)
+            self._check(self._lib.emp_pack_records(self._h, B, int(col), int(max_pts), cap, *ptrs, rp, 0, a.where))
+            return rec
+        import torch
+        dev = res.status.device
         cur = torch.cuda.current_stream(dev)
         target = self.torch_result_stream()
         foreign = int(cur.cuda_stream) != int(target.cuda_stream)

@@ -35,7 +35,7 @@ def pack_records(res, col: int, max_pts: int, path_cap: int | None = None, plann
     """CycleResult (torch tensors or numpy arrays) -> one (B, record_width) float64 matrix.  With ``planner`` and device
     tensors the packing is one kernel of the library (``Planner.pack_records``) instead of a handful of torch ops."""
     import torch
-    if planner is not None and torch.is_tensor(res.status) and res.status.is_cuda:
+    if planner is not None and (isinstance(res.status, np.ndarray) or (torch.is_tensor(res.status) and res.status.is_cuda)):
         return planner.pack_records(res, col, max_pts, path_cap)
     as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
     cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))

@@ -365,6 +365,11 @@ def test_native_record_packing_equals_the_torch_form(planner):
             got = emp_dist.pack_records(r, p.col, M, path_cap=cap, planner=planner).cpu().numpy()
             assert got.shape == (len(ins["n_obs"]), emp_dist.record_width(p.col, M, cap)) and same(got, ref)
         want.append(ref)
+    # host arrays in, host records out (staged by the library)
+    from emplanner_carla_amd.api import CycleResult
+    host = CycleResult(**{k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+    got = emp_dist.pack_records(host, p.col, M, path_cap=emp_dist.path_capacity(M), planner=planner)
+    assert isinstance(got, np.ndarray) and same(got, want[-1])
     planner.set_pipeline(True)
     try:
         recs = []
