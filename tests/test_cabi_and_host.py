@@ -149,3 +149,19 @@ def test_graft_entry_build_runs_on_cpu():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.build()
+
+
+def test_only_the_cycle_call_is_ordered_on_the_result_stream():
+    """Host logic of the two-batches-in-flight mode (emplanner_carla_amd/api.py): `_Args.done` makes a caller on a
+    foreign torch stream wait for the RESULT stream only for the call whose back stage runs there - `plan_cycle` and
+    nothing else marks itself so.  (The mark once sat in `frenet_project`: `plan_cycle` then waited for the front stage
+    only, and a tensor read right after the call raced with the back stage.)"""
+    import inspect
+    from emplanner_carla_amd import api
+    marked = [name for name, fn in inspect.getmembers(api.Planner, inspect.isfunction)
+              if re.search(r"^\s*a\.cycle\s*=\s*True", inspect.getsource(fn), re.M)]
+    assert marked == ["plan_cycle"]
+    done = inspect.getsource(api._Args.done)
+    assert "self.planner.pipelined and self.cycle" in done and "torch_result_stream()" in done
+    code = "\n".join(line.split("#")[0] for line in done.split('"""')[2].splitlines())
+    assert ".record_stream(" not in code, "outputs are kept alive by Planner.plan_cycle, not tied to a stream"
