@@ -1,0 +1,38 @@
+"""Per-kernel means of the SQ counter passes written by tools/pmc_sq.sh -> <dir>/summary.csv and a table on stdout.
+
+Derived columns (MI355X_MICROARCH.md, rocprofv3 PMC slots): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+quad-cycles per wave; lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) is the mean fraction of a
+wavefront's lanes enabled while a VALU instruction executes (both count instruction issue quad-cycles; the
+thread counter weighs them by the exec mask: the min-plus sweep, 63 of 64 lanes live, reads 0.956)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = {}
+dur = collections.defaultdict(list)
+for path in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].replace("void ", "").replace("emp::", "").split("(")[0]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
+for path in sorted(glob.glob(os.path.join(root, "p1", "**", "*kernel_trace.csv"), recursive=True)):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].replace("void ", "").replace("emp::", "").split("(")[0]
+        dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+names = sorted({c for v in agg.values() for c in v})
+with open(os.path.join(root, "summary.csv"), "w") as f:
+    f.write("kernel,launches,mean_us_under_pmc,vgpr,agpr,sgpr,lds_bytes,wg_size,grid," + ",".join(names) + ",lanes_active_frac,valu_insts_per_wave\n")
+    for k in sorted(agg):
+        v = {c: sum(x) / len(x) for c, x in agg[k].items()}
+        n = max(len(x) for x in agg[k].values())
+        la = ""
+        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
+            la = f"{v['SQ_THREAD_CYCLES_VALU'] / (64.0 * v['SQ_ACTIVE_INST_VALU']):.4f}"
+        ipw = f"{v['SQ_INSTS_VALU'] / v['SQ_WAVES']:.1f}" if v.get("SQ_WAVES") and v.get("SQ_INSTS_VALU") else ""
+        d = sum(dur[k]) / len(dur[k]) if dur.get(k) else float("nan")
+        f.write(",".join([k.replace(",", ";"), str(n), f"{d:.2f}", *meta[k]] + [f"{v.get(c, float('nan')):.6g}" for c in names] + [la, ipw]) + "\n")
+print(open(os.path.join(root, "summary.csv")).read())
