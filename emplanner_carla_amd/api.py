@@ -188,7 +188,14 @@ class _Args:
                 raise ValueError("mixing torch device tensors and host arrays in one call is not supported")
             td = {np.float64: self.t.float64, np.int32: self.t.int32}[dtype]
             if x.dtype != td or not x.is_contiguous():
+                # the conversion kernel runs on torch's current stream AFTER the wait issued in __init__: order the
+                # planner's stream behind it as well, or its kernels could read the copy before it is written
                 x = x.to(td).contiguous()
+                cur = self.t.cuda.current_stream(self.device)
+                if self.planner is None:
+                    cur.synchronize()
+                elif not self.same_stream:
+                    self.planner.torch_stream().wait_stream(cur)
             if shape is not None and tuple(x.shape) != tuple(shape):
                 raise ValueError(f"expected shape {tuple(shape)}, got {tuple(x.shape)}")
             self.keep.append(x)

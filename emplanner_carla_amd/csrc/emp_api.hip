@@ -322,7 +322,9 @@ int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int3
     if ((rc = st.in(path_s, (size_t)B * max_pts, &d_ps))) return rc;
     if ((rc = st.in(path_l, (size_t)B * max_pts, &d_pll))) return rc;
     if ((rc = st.in(traj, (size_t)B * (max_pts + 1) * 4, &d_traj))) return rc;
-    if ((rc = st.out(rec, (size_t)B * width, &d_rec))) return rc;
+    // the kernel writes every slot of rec: no zero fill (it would be queued on ctx->stream, unordered with a launch on
+    // the result stream)
+    if ((rc = st.out(rec, (size_t)B * width, &d_rec, false))) return rc;
     if (B) {
         const size_t total = (size_t)B * width;
         hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
         const int last_col = P.col - 1;
         double ring[PD][ROW];
         auto load_col = [&](double (&dst)[ROW], int jcol) {
+            if (last_col < 1) return;                    // one-column lattice (the drop-in cal_start_cost): no edges at all
             const int j = min(jcol, last_col);
             const double* src = tile_edge + (size_t)(j - 1) * ROW * 64;
 #pragma unroll

@@ -226,12 +226,24 @@ __global__ void match_points_kernel(int B, int max_ref, int max_pts, const doubl
     if (b >= B) return;
     const double* line = ref_line + (size_t)b * max_ref * 4;
     const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
-    const int k = n_pts[b];
+    const int k = min(max(n_pts[b], 0), max_pts);       // a count beyond the row's capacity is clamped, never followed
     int m_first = 0;
+    // The windowed search starts at pre_match_index: the reference indexes the path with it (planning_utils.py:123)
+    // and raises IndexError past the end; an index outside [0, P) - or an empty path - yields match_index = -1 for
+    // every point of the scene (the drop-in turns that into IndexError) and touches no node.
+    const bool windowed = windowed_api && !is_first_run[b];
+    if (P < 1 || (windowed && (pre_match_index[b] < 0 || pre_match_index[b] >= P))) {
+        for (int j = 0; j < k; ++j) {
+            match_index[(size_t)b * max_pts + j] = -1;
+            double* o = proj + ((size_t)b * max_pts + j) * 4;
+            o[0] = o[1] = o[2] = o[3] = __builtin_nan("");
+        }
+        return;
+    }
     for (int j = 0; j < k; ++j) {
         const double x = xy[((size_t)b * max_pts + j) * 2], y = xy[((size_t)b * max_pts + j) * 2 + 1];
         int m;
-        if (!windowed_api || is_first_run[b]) {
+        if (!windowed) {
             m = match_scan(line, P, x, y, 0, 1, 50);                               // ref planning_utils.py:72-92 / :383-402
         } else {
             const int st = pre_match_index[b];                                     // ref :123-167

@@ -64,6 +64,8 @@ def find_match_points(xy_list, frenet_path_node_list, is_first_run, pre_match_in
     xy, n = xy_array(xy_list)
     mi, pr = planner().find_match_points(line, n_ref, xy, n, np.array([1 if is_first_run is True else 0], np.int32),
                                          np.array([int(pre_match_index)], np.int32))
+    if len(mi[0]) and mi[0][0] < 0:
+        raise IndexError("list index out of range")                 # ref :123 frenet_path_node_list[pre_match_index]
     return list(mi[0].astype(np.int32)), [tuple(f64(v) for v in p) for p in pr[0]]
 
 
@@ -72,6 +74,8 @@ def match_projection_points(xy_list, frenet_path_node_list):
     line, n_ref = line_array(frenet_path_node_list)
     xy, n = xy_array(xy_list)
     mi, pr = planner().match_projection(line, n_ref, xy, n)
+    if len(mi[0]) and mi[0][0] < 0:
+        raise IndexError("list index out of range")                 # ref :383 on an empty path
     return list(mi[0].astype(np.int32)), [tuple(f64(v) for v in p) for p in pr[0]]
 
 

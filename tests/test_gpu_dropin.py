@@ -222,3 +222,50 @@ def test_integration_md_binding_example_runs():
     want_l = (np.float64(9 + 1) / 2 - 1 - rows) * 1.5
     got = np.interp(np.asarray(s_list[0]) + 2.5 * np.arange(1, 41), s_list, l_list)
     assert np.allclose(got, want_l, atol=1e-9)
+
+
+def test_find_match_points_rejects_an_index_off_the_path(mods):
+    """ref planning_utils.py:123 indexes the path with pre_match_index: past the end it raises IndexError; the
+    kernel must not follow the index (round-1 advisor finding) and the drop-in raises the same exception."""
+    _, pu = mods
+    g = load_golden("cycle_default_6x12_3obs.npz")
+    ref = _tl(g["in_ref"][0])
+    pt = tuple(g["in_start_xy"][0])
+    idx, proj = pu.find_match_points([pt], ref, False, 5)
+    assert 0 <= idx[0] < len(ref) and np.isfinite(proj[0]).all()
+    for bad in (len(ref), len(ref) + 1000, -1, -10 ** 6):
+        with pytest.raises(IndexError):
+            pu.find_match_points([pt], ref, False, bad)
+    with pytest.raises(IndexError):
+        pu.match_projection_points([pt], [])
+
+
+def test_wrong_dtype_device_inputs_from_a_foreign_stream_are_ordered():
+    """Device tensors that need a dtype / contiguity fix are converted on torch's current stream AFTER the planner's
+    stream was told to wait for it (round-1 advisor finding): the planner must be ordered behind the conversion too.
+    int64 counts (what torch.tensor([...]) yields) and a strided obstacle view, issued from a side stream that is
+    kept busy, must give the results of clean inputs."""
+    import torch
+    from emplanner_carla_amd.api import Planner, dp_params_from_cfg
+    cfg = S.CFG2
+    B = 2048
+    batch = S.make_batch(range(B), cfg)
+    dev = torch.device("cuda:0")
+    pl = Planner(0)
+    p = dp_params_from_cfg(cfg)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    want, _, want_st = pl.dp_plan(p, batch.sl_obs_s, batch.sl_obs_l, batch.n_obs, batch.sl_start)
+    side = torch.cuda.Stream(device=dev)
+    wide = t(np.concatenate([batch.sl_obs_s[:, :, None], batch.sl_obs_l[:, :, None]], axis=2))   # [B][max_obs][2]
+    n64 = t(batch.n_obs.astype(np.int64))
+    start = t(batch.sl_start)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        with torch.cuda.stream(side):
+            junk = torch.randn(4096, 4096, device=dev)
+            for _ in range(4):
+                junk = junk @ junk                                   # keeps the side stream busy ahead of the conversions
+            rows, _, st = pl.dp_plan(p, wide[:, :, 0], wide[:, :, 1], n64, start)
+            got, got_st = rows.cpu().numpy(), st.cpu().numpy()
+        assert np.array_equal(got, want) and np.array_equal(got_st, want_st)
+    pl.close()
