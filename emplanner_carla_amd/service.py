@@ -23,41 +23,46 @@ from .api import Planner, dp_params, max_path_points, qp_params, smooth_params
 INFEASIBLE_BANNER = "********************     can't find a feasible path      ********************"
 
 
-def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None):
+def pack_requests(requests):
+    """The request tuples of a batch as the padded arrays the two device calls take (host logic of test_9.py:
+    95-131, 141-142 only: which obstacles count, which dynamic obstacle is used)."""
+    B = len(requests)
+    G = max(len(r[6]) for r in requests)
+    K = max(1, max((len(r[0]) for r in requests), default=1))
+    a = dict(global_path=np.zeros((B, G, 4)), n_global=np.zeros(B, np.int32), pred=np.zeros((B, 2)),
+             veh=np.zeros((B, 2)), v=np.zeros((B, 2)), a=np.zeros((B, 2)), pre_match=np.zeros(B, np.int32),
+             obs_xy=np.zeros((B, K, 2)), n_obs=np.zeros(B, np.int32), dyn=np.full((B, 2), np.nan))
+    for b, (static, dynamic, vehicle_loc, pred_loc, vehicle_v, vehicle_a, path, match_list) in enumerate(requests):
+        a["n_global"][b] = len(path)
+        a["global_path"][b, :len(path)] = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path])
+        a["pred"][b], a["veh"][b], a["v"][b], a["a"][b] = pred_loc, vehicle_loc, vehicle_v, vehicle_a
+        a["pre_match"][b] = int(match_list[0])
+        if len(static) != 0 and static[0][-1] <= 30:                       # test_9.py:117
+            a["n_obs"][b] = len(static)
+            a["obs_xy"][b, :len(static)] = [(float(o[0]), float(o[1])) for o in static]
+        if len(dynamic) != 0:                                               # test_9.py:141-142
+            a["dyn"][b] = (float(dynamic[0][2]), float(dynamic[0][3]))
+    return a
+
+
+def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=None):
     """requests: list of request tuples.  Returns a list of (reply tuple or None, status): None where the reference
-    would have raised (IndexError paths) or where a QP is infeasible."""
+    would have raised (IndexError paths) or where a QP is infeasible.  ``stages``: a dict that receives the packed
+    inputs and the raw outputs of the two device calls (for the stage-by-stage parity tests)."""
     dp = dp or dp_params()
     qp = qp or qp_params()
     sp = sp or smooth_params()
     B = len(requests)
     if B == 0:
         return []
-    G = max(len(r[6]) for r in requests)
-    K = max(1, max((len(r[0]) for r in requests), default=1))
-    gp = np.zeros((B, G, 4))
-    n_global = np.zeros(B, np.int32)
-    pred = np.zeros((B, 2))
-    veh = np.zeros((B, 2))
-    v = np.zeros((B, 2))
-    a = np.zeros((B, 2))
-    pre = np.zeros(B, np.int32)
-    obs = np.zeros((B, K, 2))
-    n_obs = np.zeros(B, np.int32)
-    dyn = np.full((B, 2), np.nan)
-    for b, (static, dynamic, vehicle_loc, pred_loc, vehicle_v, vehicle_a, path, match_list) in enumerate(requests):
-        n_global[b] = len(path)
-        gp[b, :len(path)] = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path])
-        pred[b], veh[b], v[b], a[b] = pred_loc, vehicle_loc, vehicle_v, vehicle_a
-        pre[b] = int(match_list[0])
-        if len(static) != 0 and static[0][-1] <= 30:                       # test_9.py:117
-            n_obs[b] = len(static)
-            obs[b, :len(static)] = [(float(o[0]), float(o[1])) for o in static]
-        if len(dynamic) != 0:                                               # test_9.py:141-142
-            dyn[b] = (float(dynamic[0][2]), float(dynamic[0][3]))
-    ref, n_ref, match, _, st_ref = planner.reference_line(sp, gp, n_global, pred, pre)
+    a = pack_requests(requests)
+    ref, n_ref, match, _, st_ref = planner.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
     M = max_path_points(dp)
-    res = planner.plan_cycle(dp, qp, sp, max_pts=M, ref_line=ref, n_ref=np.where(st_ref == 0, n_ref, 2).astype(np.int32),
-                             origin_xy=veh, start_xy=pred, start_v=v, start_a=a, obs_xy=obs, n_obs=n_obs, dyn_dis_speed=dyn)
+    n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
+    res = planner.plan_cycle(dp, qp, sp, max_pts=M, ref_line=ref, n_ref=n_ref_used, origin_xy=a["veh"], start_xy=a["pred"],
+                             start_v=a["v"], start_a=a["a"], obs_xy=a["obs_xy"], n_obs=a["n_obs"], dyn_dis_speed=a["dyn"])
+    if stages is not None:
+        stages.update(inputs=a, ref_line=ref, n_ref=n_ref_used, match=match, ref_status=st_ref, cycle=res)
     out = []
     for b in range(B):
         status = int(st_ref[b]) | int(res.status[b])
@@ -71,19 +76,26 @@ def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None):
     return out
 
 
-def motion_planning(conn, device_id: int = 0, dp=None):
+def motion_planning(conn, device_id: int = 0, dp=None, strict: bool = False):
     """Drop-in for the reference's planning process (test_9.py:92-220): ``multiprocessing.Process(target=
-    motion_planning, args=(conn,))``.  Blocks on ``conn.recv()`` like the reference; a request the reference would fail
-    on raises the same exception type here.  ``dp`` overrides the lattice (default: the reference's keyword defaults,
-    path_planning.py:218)."""
+    motion_planning, args=(conn,))``.  Blocks on ``conn.recv()`` like the reference and creates its device context here,
+    in the child.  A request on which the reference raises IndexError (path_planning.py:63, :267) raises IndexError
+    here too - the child ends, as the reference's does.  A request whose path or smoothing QP is infeasible has no
+    faithful answer: the reference ignores cvxopt's status (path_planning.py:211-218) and sends whatever its last
+    iterate was.  Here the loop stays alive and answers ``(None, match_point_list, [], [])`` - the parent keeps its
+    previous path - unless ``strict``, which raises ValueError instead.  ``dp`` overrides the lattice
+    (default: the reference's keyword defaults, path_planning.py:277-279)."""
     planner = Planner(device_id)                                            # created in the child process
     while 1:
         request = conn.recv()
-        reply, status = plan_requests(planner, [request], dp=dp)[0]
+        stages = {}
+        reply, status = plan_requests(planner, [request], dp=dp, stages=stages)[0]
         if status & 1:
             print(INFEASIBLE_BANNER)                                        # path_planning.py:351
         if reply is None:
             if status & (2 | 4):
                 raise IndexError("list index out of range")
-            raise ValueError("path or smoothing QP infeasible")
+            if strict:
+                raise ValueError("path or smoothing QP infeasible")
+            reply = (None, [int(stages["match"][0])], [], [])            # the new match index is still valid (test_9.py:99)
         conn.send(reply)
