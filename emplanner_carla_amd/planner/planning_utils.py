@@ -60,6 +60,8 @@ def predict_block_based_on_frenet(vehicle_loc, vehicle_velocity, local_frenet_pa
 # ---- matching / projection --------------------------------------------------------------------
 def find_match_points(xy_list, frenet_path_node_list, is_first_run, pre_match_index):
     """ref :49-182."""
+    if len(frenet_path_node_list) == 0:
+        raise IndexError("list index out of range")                 # ref :103 / :123 on an empty path
     line, n_ref = line_array(frenet_path_node_list)
     xy, n = xy_array(xy_list)
     mi, pr = planner().find_match_points(line, n_ref, xy, n, np.array([1 if is_first_run is True else 0], np.int32),
@@ -71,6 +73,8 @@ def find_match_points(xy_list, frenet_path_node_list, is_first_run, pre_match_in
 
 def match_projection_points(xy_list, frenet_path_node_list):
     """ref :364-426."""
+    if len(frenet_path_node_list) == 0:
+        raise IndexError("list index out of range")                 # ref :413 frenet_path_node_list[match_point_index_list[0]]
     line, n_ref = line_array(frenet_path_node_list)
     xy, n = xy_array(xy_list)
     mi, pr = planner().match_projection(line, n_ref, xy, n)
