@@ -342,7 +342,7 @@ class Planner:
             e = e.reshape(B, p.col - 1, p.row, p.row)
         return c0, e
 
-    def dp_plan(self, p: DpParams, obs_s, obs_l, n_obs, start, mode=L.EMP_DP_FUSED):
+    def dp_plan(self, p: DpParams, obs_s, obs_l, n_obs, start, mode=L.EMP_DP_TWO_KERNEL):
         """ref DP_algorithm up to the backtrack: returns rows (B,col) f64, min_cost (B,), status (B,)."""
         a = self._args(obs_s, obs_l, n_obs, start)
         B = int(start.shape[0])
@@ -760,7 +760,7 @@ class Planner:
 
     # ---- whole cycle ------------------------------------------------------------------------
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
-                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_FUSED, dyn_dis_speed=None) -> CycleResult:
+                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None) -> CycleResult:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
         of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169."""
         a = self._args(ref_line, origin_xy)

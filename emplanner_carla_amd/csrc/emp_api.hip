@@ -40,6 +40,27 @@ static int make_dp_dev(emp_ctx* ctx, const emp_dp_params* p, int B, int max_obs,
 static size_t tiled_elems(const DpDev& d) { return (size_t)d.tiles * (size_t)(d.col - 1) * d.row * 64; }
 
 // ---- device-level stage launchers (all pointers are device memory; nothing synchronises) -----
+// pair table of the lattice (emp_dp_kernels.h dp_pair_table_kernel): rebuilt only when the lattice parameters change,
+// stream-ordered before its first use
+static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
+    const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
+    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
+    emp_ctx::Buf& tb = ctx->named["dp_pair_table"];
+    if (tb.bytes < tab_bytes) {
+        const int grc = grow_buffer(ctx, tb, tab_bytes);
+        if (grc) return grc;
+        ctx->pair_table_valid = false;
+    }
+    if (!ctx->pair_table_valid || memcmp(key, ctx->pair_table_key, sizeof(key)) != 0) {
+        hipLaunchKernelGGL(dp_pair_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d, (double*)tb.p);
+        EMP_LAUNCH_CHECK(ctx);
+        memcpy(ctx->pair_table_key, key, sizeof(key));
+        ctx->pair_table_valid = true;
+    }
+    *out = (const double*)tb.p;
+    return EMP_OK;
+}
+
 static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, double* start_cost, double* edge, bool tiled) {
     if (d.B == 0) return EMP_OK;
@@ -57,22 +78,8 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     cols_per_chunk = cols_per_chunk >= 4 ? (cols_per_chunk / 4) * 4 : 4;
     chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
     dim3 grid(d.tiles, chunks), block(256);
-    // pair table: rebuilt only when the lattice parameters change (stream-ordered before its first use)
-    const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
-    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
-    emp_ctx::Buf& tb = ctx->named["dp_pair_table"];
-    if (tb.bytes < tab_bytes) {
-        const int grc = grow_buffer(ctx, tb, tab_bytes);
-        if (grc) return grc;
-        ctx->pair_table_valid = false;
-    }
-    if (!ctx->pair_table_valid || memcmp(key, ctx->pair_table_key, sizeof(key)) != 0) {
-        hipLaunchKernelGGL(dp_pair_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d, (double*)tb.p);
-        EMP_LAUNCH_CHECK(ctx);
-        memcpy(ctx->pair_table_key, key, sizeof(key));
-        ctx->pair_table_valid = true;
-    }
-    const double* pair_tab = (const double*)tb.p;
+    const double* pair_tab = nullptr;
+    { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
     auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -144,10 +151,46 @@ static int dp_edge_tensor(emp_ctx* ctx, const DpDev& d, double** edge, double** 
     return EMP_OK;
 }
 
+// EMP_DP_FUSED: one kernel, edge costs staged in LDS and swept in place (emp_dp_kernels.h dp_fused_kernel)
+static int dev_dp_fused(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
+                        const double* start, double* rows, double* min_cost, int* status) {
+    if (d.B == 0) return EMP_OK;
+    const double* pair_tab = nullptr;
+    int rc = dp_pair_table(ctx, d, &pair_tab);
+    if (rc) return rc;
+    // columns per chunk: 4 (one per wavefront) while two buffers of them leave room for three blocks per CU, fewer on wide
+    // lattices whose pair table fills the LDS
+    static const int nc_env = getenv("EMP_FUSED_NC") ? atoi(getenv("EMP_FUSED_NC")) : 0;   // development
+    int nc = nc_env > 0 ? nc_env : 4;
+    while (nc > 1 && fused_lds(d.row, d.col, d.S, d.max_obs, nc).total > 53 * 1024 && nc_env <= 0) nc /= 2;
+    const size_t lds = (size_t)fused_lds(d.row, d.col, d.S, d.max_obs, nc).total;
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the fused DP kernel's LDS working set");
+    KernelTimer t(ctx, "dp_fused");
+#define EMP_FUSED(R)                                                                                                  \
+    do {                                                                                                              \
+        if (lds > 48 * 1024)                                                                                          \
+            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_fused_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                             (int)lds));                                                              \
+        hipLaunchKernelGGL(dp_fused_kernel<R>, dim3(d.tiles), dim3(256), lds, ctx->stream, d, pair_tab, obs_s, obs_l,   \
+                           n_obs, start, rows, min_cost, status, nc);                                                 \
+    } while (0)
+    switch (d.row) {
+        case 5: EMP_FUSED(5); break;
+        case 9: EMP_FUSED(9); break;
+        case 12: EMP_FUSED(12); break;
+        case 21: EMP_FUSED(21); break;
+        default: EMP_FUSED(0); break;
+    }
+#undef EMP_FUSED
+    EMP_LAUNCH_CHECK(ctx);
+    return EMP_OK;
+}
+
+// DP_algorithm up to the backtrack, in either form.
 static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, emp_dp_mode mode, double* rows, double* min_cost, int* status) {
-    (void)mode;  // EMP_DP_FUSED currently shares the two-kernel path
     if (d.B == 0) return EMP_OK;
+    if (mode == EMP_DP_FUSED) return dev_dp_fused(ctx, d, obs_s, obs_l, n_obs, start, rows, min_cost, status);
     double *edge, *start_cost;
     int rc = dp_edge_tensor(ctx, d, &edge, &start_cost);
     if (rc) return rc;
@@ -983,11 +1026,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                           d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
-    (void)mode;
-    double *d_edge, *d_start_cost;
-    if ((rc = dp_edge_tensor(ctx, d, &d_edge, &d_start_cost))) return rc;
-    if ((rc = dev_dp_edge(ctx, d, d_os, d_ol, d_no, d_start, d_start_cost, d_edge, true))) return rc;
-    if ((rc = dev_dp_sweep(ctx, d, d_start_cost, d_edge, d_no, d_rows, nullptr, d_st))) return rc;
+    if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
     const QpDev Q = make_qp_dev(q);
     // back stage (densified DP path, path QP, Cartesian tail: short kernels that last as long as their slowest scene):
     // on the second stream when pipelined, ordered behind this call's front stage only

@@ -123,6 +123,58 @@ __device__ __forceinline__ bool obstacle_box_in_reach(double os, double ol, doub
     return dx * dx + dy * dy < 36.5;
 }
 
+// The `row` neighbour edges from column j-1 into row i of column j for one scene (ref: cal_neighbor_cost,
+// path_planning.py:517-585), handed to `store(k, cost)` for k = 0..row-1 (k = source row).  What depends on (scene,
+// column) only - the sample abscissae and which obstacles are within longitudinal reach - is set up once and reused
+// for the source rows.  tab / t_smp: the pair table and the sample offsets in LDS; my_obs_s / my_obs_l: the scene's
+// obstacles in LDS; ps = plan_start_s; nob = the scene's obstacle count (clamped to the row's capacity).
+template <typename Store>
+__device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, double ps, int nob, const double* tab,
+                                               const double* t_smp, const double* my_obs_s, const double* my_obs_l,
+                                               Store&& store) {
+    const int row = P.row, rr = P.row * P.row;
+    const int nmask = min(nob, 64);
+    const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
+    double sn[kSamples];
+#pragma unroll
+    for (int n = 0; n < kSamples; ++n) sn[n] = s0 + t_smp[n];
+    // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
+    unsigned long long near_s = 0;
+    for (int m = 0; m < nmask; ++m) {
+        const double os = my_obs_s[m];
+        if (os > s0 - 6.5 && os < sn[kSamples - 1] + 6.5) near_s |= 1ull << m;
+    }
+    for (int k = 0; k < row; ++k) {
+        const int p = k * row + i;
+        Quintic q;
+        q.a3 = tab[(kSamples + 0) * rr + p];
+        q.a4 = tab[(kSamples + 1) * rr + p];
+        q.a5 = tab[(kSamples + 2) * rr + p];
+        const JerkQuirk jq = jerk_quirk(q, s0);
+        double S_d3 = 0.0;
+#pragma unroll
+        for (int n = 0; n < kSamples; ++n) {
+            const double d3 = jerk_quirk_at(jq, sn[n]);
+            S_d3 = S_d3 + d3 * d3;
+        }
+        const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
+        const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
+        double coll = 0.0;
+        for (unsigned long long rest = near_s; rest; rest &= rest - 1) {   // ascending m, as the reference
+            const int m = __ffsll((long long)rest) - 1;
+            const double os = my_obs_s[m], ol = my_obs_l[m];
+            if (!obstacle_box_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;   // contributes exactly 0
+            coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
+        }
+        for (int m = 64; m < nob; ++m) {                                  // beyond the mask: full test per edge
+            const double os = my_obs_s[m], ol = my_obs_l[m];
+            if (!obstacle_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;
+            coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
+        }
+        store(k, (smooth + coll) + tab[(kSamples + 4) * rr + p]);
+    }
+}
+
 // grid = (tiles, column chunks), block = 256.  Dynamic LDS: the pair table (copied from `pair_tab`),
 // followed by the tile's obstacles [S][max_obs] x2 doubles and the sample offsets.
 template <bool TILED>
@@ -180,54 +232,16 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
     if (lane >= lanes_used || b >= P.B) return;
     const double ps = start[b * 4 + 0];
     const int nob = min(max(n_obs[b], 0), P.max_obs);      // a count beyond the row's capacity is clamped, never followed
-    const int nmask = min(nob, 64);
     const double* my_obs_s = t_obs_s + s * P.max_obs;
     const double* my_obs_l = t_obs_l + s * P.max_obs;
     for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
-        const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
-        double sn[kSamples];
-#pragma unroll
-        for (int n = 0; n < kSamples; ++n) sn[n] = s0 + t_smp[n];
-        // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
-        unsigned long long near_s = 0;
-        for (int m = 0; m < nmask; ++m) {
-            const double os = my_obs_s[m];
-            if (os > s0 - 6.5 && os < sn[kSamples - 1] + 6.5) near_s |= 1ull << m;
-        }
-        for (int k = 0; k < row; ++k) {
-            const int p = k * row + i;
-            Quintic q;
-            q.a3 = tab[(kSamples + 0) * rr + p];
-            q.a4 = tab[(kSamples + 1) * rr + p];
-            q.a5 = tab[(kSamples + 2) * rr + p];
-            const JerkQuirk jq = jerk_quirk(q, s0);
-            double S_d3 = 0.0;
-#pragma unroll
-            for (int n = 0; n < kSamples; ++n) {
-                const double d3 = jerk_quirk_at(jq, sn[n]);
-                S_d3 = S_d3 + d3 * d3;
-            }
-            const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
-            const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
-            double coll = 0.0;
-            for (unsigned long long rest = near_s; rest; rest &= rest - 1) {   // ascending m, as the reference
-                const int m = __ffsll((long long)rest) - 1;
-                const double os = my_obs_s[m], ol = my_obs_l[m];
-                if (!obstacle_box_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;   // contributes exactly 0
-                coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
-            }
-            for (int m = 64; m < nob; ++m) {                                  // beyond the mask: full test per edge
-                const double os = my_obs_s[m], ol = my_obs_l[m];
-                if (!obstacle_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;
-                coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
-            }
-            const double cost = (smooth + coll) + tab[(kSamples + 4) * rr + p];
+        dp_edge_column(P, j, i, ps, nob, tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) {
             if (TILED) {
                 edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
             } else {
                 edge[(size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + i * row + k] = cost;
             }
-        }
+        });
     }
 }
 
@@ -389,6 +403,206 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
             int idx = arg;
             out[P.col - 1] = (double)idx;
             for (int j = P.col - 1; j >= 1; --j) {        // ref :355-359
+                idx = pre[j * 64 + base + idx];
+                out[j - 1] = (double)idx;
+            }
+            if (min_cost_out) min_cost_out[b] = best;
+            status_out[b] = (best > P.w_coll) ? 1 : 0;    // ref :351 (EMP_ST_DP_INFEASIBLE)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused DP: edge costs staged in LDS and swept in place (EMP_DP_FUSED)
+// ---------------------------------------------------------------------------------------------
+// ref: DP_algorithm up to the backtrack, path_planning.py:301-361, as ONE kernel that never writes the edge tensor.
+// Block = one tile of S scenes (the sweep's unit: lane = (scene, destination row)), four wavefronts.  The columns are
+// taken NC at a time: all four wavefronts cost the chunk's columns into an LDS buffer [NC][row][64] (columns handed
+// out by an LDS counter, so that wavefront 0, which arrives late, takes fewer), a barrier, then wavefront 0 runs
+// the min-plus recurrence over those NC columns while the other three already cost the next chunk into the second
+// buffer.  Same arithmetic as dp_edge_kernel + dp_sweep_kernel (dp_edge_column, the v_min tree with the
+// lowest-k predecessor, first-minimum terminal), so rows, min_cost and status are bit-identical to the two-kernel
+// path.  Trade: no 8 E bytes per scene written and read back, against one block per tile - 586 blocks at 4096
+// scenes 40x9, two or three per CU instead of the edge kernel's sixteen wavefronts per CU.
+struct FusedLds {
+    int off_smp, off_obs_s, off_obs_l, off_buf, off_front, off_pre, off_ctr, total;   // bytes
+};
+__host__ __device__ inline FusedLds fused_lds(int row, int col, int S, int max_obs, int nc) {
+    FusedLds L;
+    int o = kTableFields * row * row * 8;
+    L.off_smp = o;   o += kSamples * 8;
+    L.off_obs_s = o; o += S * max_obs * 8;
+    L.off_obs_l = o; o += S * max_obs * 8;
+    L.off_buf = o;   o += 2 * nc * row * 64 * 8;
+    L.off_front = o; o += 64 * 8;
+    L.off_pre = o;   o += ((col * 64 + 7) / 8) * 8;
+    L.off_ctr = o;   o += 8;
+    L.total = o;
+    return L;
+}
+
+template <int ROW>
+__global__ __launch_bounds__(256, 4) void dp_fused_kernel(DpDev P, const double* __restrict__ pair_tab,
+                                                          const double* __restrict__ obs_s,
+                                                          const double* __restrict__ obs_l,
+                                                          const int* __restrict__ n_obs,
+                                                          const double* __restrict__ start,
+                                                          double* __restrict__ rows_out,
+                                                          double* __restrict__ min_cost_out,
+                                                          int* __restrict__ status_out, int nc) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int row = ROW > 0 ? ROW : P.row, rr = row * row;
+    const FusedLds L = fused_lds(row, P.col, P.S, P.max_obs, nc);
+    unsigned char* base_b = reinterpret_cast<unsigned char*>(lds);
+    double* tab = lds;
+    double* t_smp = reinterpret_cast<double*>(base_b + L.off_smp);
+    double* t_obs_s = reinterpret_cast<double*>(base_b + L.off_obs_s);
+    double* t_obs_l = reinterpret_cast<double*>(base_b + L.off_obs_l);
+    double* buf = reinterpret_cast<double*>(base_b + L.off_buf);                  // [2][nc][row][64]
+    double* front = reinterpret_cast<double*>(base_b + L.off_front);              // [64] cost front of the previous column
+    unsigned char* pre = base_b + L.off_pre;                                      // [col][64] predecessor rows
+    int* ctr = reinterpret_cast<int*>(base_b + L.off_ctr);                        // [2] column counters, one per buffer
+    const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
+    if (tid < kSamples) t_smp[tid] = pair_tab[kTableFields * rr + tid];
+    for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
+        const int sc = x / P.max_obs, m = x - sc * P.max_obs;
+        const int bb = tile * P.S + sc;
+        t_obs_s[x] = (bb < P.B) ? obs_s[(size_t)bb * P.max_obs + m] : 0.0;
+        t_obs_l[x] = (bb < P.B) ? obs_l[(size_t)bb * P.max_obs + m] : 0.0;
+    }
+    if (tid < 2) ctr[tid] = 0;
+    __syncthreads();
+
+    const int s = lane / row, i = lane - s * row;
+    const int b = tile * P.S + s;
+    const bool live = (lane < P.S * row) && (b < P.B);
+    const int sl = live ? s : 0;
+    const double ps = live ? start[b * 4 + 0] : 0.0;
+    const int nob = live ? min(max(n_obs[b], 0), P.max_obs) : 0;   // a count beyond the row's capacity is clamped, never followed
+    const double* my_obs_s = t_obs_s + sl * P.max_obs;
+    const double* my_obs_l = t_obs_l + sl * P.max_obs;
+    const int base = s * row;
+    const bool left = i < (row >> 1);                    // ref :317 / :341 lane penalty rows
+    const double INF = __builtin_inf();
+    const double pen = left ? kLanePenalty : 0.0;
+
+    // ---- sweep state, used by wavefront 0 only
+    double cost = INF;
+    constexpr int HR = ROW > 0 ? ROW : 1;
+    double held[HR], held_best = INF;                    // candidates of the previous column and their minimum
+    int held_j = 0;
+#pragma unroll
+    for (int k = 0; k < HR; ++k) held[k] = INF;
+    auto publish = [&]() {
+        front[lane] = cost;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto settle = [&]() {                                // see dp_sweep_kernel: the lowest k that attains the minimum
+        if constexpr (ROW > 0) {
+            int arg = ROW - 1;
+#pragma unroll
+            for (int k = ROW - 2; k >= 0; --k) arg = (held[k] == held_best) ? k : arg;
+            if (held_j > 0) pre[held_j * 64 + lane] = (unsigned char)((held_best < INF) ? arg : 1);
+        }
+    };
+    auto relax_col = [&](const double* e /* [row][64] at this lane */, int j) {
+        if constexpr (ROW > 0) {
+            publish();
+            double cand[ROW];
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) cand[k] = front[base + k];
+            settle();
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) cand[k] = (cand[k] + e[k * 64]) + pen;      // ref :340, :342
+            double tree[ROW];
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) tree[k] = cand[k];
+#pragma unroll
+            for (int span = 1; span < ROW; span <<= 1) {
+#pragma unroll
+                for (int k = 0; k + span < ROW; k += 2 * span) tree[k] = __builtin_fmin(tree[k], tree[k + span]);
+            }
+            cost = __builtin_fmin(tree[0], INF);
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) held[k] = cand[k];
+            held_best = cost;
+            held_j = j;
+        } else {
+            double best = INF;
+            int arg = 1;                                 // ref :304 predecessor initialised to 1
+            publish();
+            for (int k = 0; k < row; ++k) {
+                double cand = front[base + k] + e[k * 64];                           // ref :340
+                if (left) cand = cand + kLanePenalty;                                // ref :342
+                if (cand < best) {                                                   // strict, k ascending (:344)
+                    best = cand;
+                    arg = k;
+                }
+            }
+            cost = best;
+            pre[j * 64 + lane] = (unsigned char)arg;
+        }
+    };
+
+    if (wave == 0 && live) {                             // ref :306-318 start column
+        const Quintic q = quintic_shifted(start[b * 4 + 1], start[b * 4 + 2], start[b * 4 + 3], lattice_l(row, i, P.sample_l),
+                                          P.sample_s);
+        cost = segment_cost(q, ps, P.sample_s, my_obs_s, my_obs_l, nob, P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+        if (left) cost = cost + kLanePenalty;
+    }
+
+    const int ncol = P.col - 1;
+    const int nchunks = (ncol + nc - 1) / nc;
+    for (int c = 0; c < nchunks; ++c) {
+        const int par = c & 1;
+        const int j0 = 1 + c * nc;
+        const int cols = min(nc, P.col - j0);
+        double* cbuf = buf + (size_t)par * nc * row * 64;
+        if (tid == 0) ctr[par ^ 1] = 0;                  // the other buffer's counter is idle between its two barriers
+        for (;;) {
+            int jj = 0;
+            if (lane == 0) jj = atomicAdd(&ctr[par], 1);
+            jj = __builtin_amdgcn_readfirstlane(jj);
+            if (jj >= cols) break;
+            double* dst = cbuf + (size_t)jj * row * 64 + lane;
+            if (live) dp_edge_column(P, j0 + jj, i, ps, nob, tab, t_smp, my_obs_s, my_obs_l, [&](int k, double v) { dst[k * 64] = v; });
+        }
+        __syncthreads();                                 // chunk c is complete in cbuf
+        if (wave == 0)
+            for (int jj = 0; jj < cols; ++jj) relax_col(cbuf + (size_t)jj * row * 64 + lane, j0 + jj);
+    }
+    if (wave != 0) return;
+    settle();                                            // the last column's predecessor
+
+    // ---- terminal argmin (first minimum, ref :349), backtrack (:355-359), outputs: as dp_sweep_kernel
+    double best = INF;
+    int arg = 0;
+    bool first = true;
+    publish();
+    for (int k = 0; k < row; ++k) {
+        const double ck = front[base + k];
+        if (first || ck < best) {
+            best = ck;
+            arg = k;
+            first = false;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (live && i == 0) {
+        const bool bypass = n_obs[b] == 0;
+        double* out = rows_out + (size_t)b * P.col;
+        if (bypass) {                                     // ref :362-363 no obstacles: centre row, DP skipped
+            const double centre = (double)(row + 1) / 2.0 - 1.0;
+            for (int j = 0; j < P.col; ++j) out[j] = centre;
+            if (min_cost_out) min_cost_out[b] = INF;
+            status_out[b] = 0;
+        } else {
+            int idx = arg;
+            out[P.col - 1] = (double)idx;
+            for (int j = P.col - 1; j >= 1; --j) {
                 idx = pre[j * 64 + base + idx];
                 out[j - 1] = (double)idx;
             }

@@ -193,3 +193,39 @@ def test_cfg5_wide_lattice_matches_exact_oracle(planner):
         xs, xl = xpaths[i]
         assert ln[i] == len(xs) == 121
         assert np.array_equal(ps[i, :121], np.asarray(xs)) and np.array_equal(pl[i, :121], np.asarray(xl))
+
+
+@pytest.mark.parametrize("cfg,B", [(S.CFG2, 4096), (S.CFG_DEFAULT, 1000), (S.CFG5, 40),
+                                   (S.LatticeConfig("odd_7x11", row=7, col=11, sample_s=3.0, sample_l=1.2, sampling_res=1, n_obs=5), 333),
+                                   (S.LatticeConfig("one_column", row=9, col=1, sample_s=2.5, sample_l=1.5, sampling_res=1, n_obs=3), 20),
+                                   (S.LatticeConfig("two_columns", row=5, col=2, sample_s=5.0, sample_l=1.0, sampling_res=1, n_obs=2), 20)],
+                         ids=["cfg2_4096", "default_1000", "cfg5_40", "generic_rows_7x11", "one_column", "two_columns"])
+def test_fused_dp_is_bit_identical_to_the_two_kernel_dp(planner, cfg, B):
+    """EMP_DP_FUSED (edge costs staged in LDS and swept in place, no HBM tensor) against EMP_DP_TWO_KERNEL on the same
+    scenes: rows, minimum cost and status bit for bit - compiled row counts (5, 9, 12, 21), the generic row path, chunk
+    remainders (39, 5, 119 and 10 edge columns against chunks of 4), a ragged last tile, lattices of one and two columns
+    - and the two-kernel rows against the exact oracle (ref: path_planning.py:301-361)."""
+    batch = S.make_batch(range(500, 500 + B), cfg)
+    p = _params(cfg)
+    a = planner.dp_plan(p, batch.sl_obs_s, batch.sl_obs_l, batch.n_obs, batch.sl_start, mode=0)
+    b = planner.dp_plan(p, batch.sl_obs_s, batch.sl_obs_l, batch.n_obs, batch.sl_start, mode=1)
+    for x, y, what in zip(a, b, ("rows", "min_cost", "status")):
+        assert np.array_equal(x, y, equal_nan=True), f"fused and two-kernel {what} differ"
+    n = min(B, 64)
+    xrows, xfeas, _ = ex.dp_plan(batch.sl_obs_s[:n], batch.sl_obs_l[:n], batch.n_obs[:n], batch.sl_start[:n], cfg.row, cfg.col,
+                                 cfg.sample_s, cfg.sample_l, cfg.sampling_res)
+    assert np.array_equal(a[0][:n], xrows)
+
+
+def test_fused_cycle_equals_two_kernel_cycle(planner):
+    """The whole planning cycle with either DP form: every output identical (the stages behind the DP see the same rows)."""
+    from emplanner_carla_amd.api import qp_params, smooth_params
+    cfg = S.CFG2
+    b = S.make_batch(range(256), cfg)
+    B, P = b.ref.shape[:2]
+    kw = dict(ref_line=b.ref, n_ref=np.full(B, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
+              start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+    r0 = planner.plan_cycle(_params(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), mode=0, **kw)
+    r1 = planner.plan_cycle(_params(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), mode=1, **kw)
+    for f in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status"):
+        assert np.array_equal(getattr(r0, f), getattr(r1, f), equal_nan=True), f
