@@ -7,18 +7,32 @@
 
 One *step* = one pass of the whole planning cycle (projection -> S-L lattice DP -> QP bounds -> path QP ->
 midpoints -> Frenet->Cartesian -> smoothing QP -> heading/kappa; reference test_9.py:113-218) over one batch
-of synthetic scenes per GPU, with every input already resident in HBM.  Workload = BASELINE.json
+of synthetic scenes per GPU, with every input already resident in HBM.  Default workload = BASELINE.json
 configs[2] on one GPU (4096 scenes, 40x9 lattice, 8 obstacles) and configs[3] across GPUs (weak scaling:
 4096 scenes per GPU, i.e. 32768 at 8 GPUs), plus the RCCL gather of the result records when N > 1.
 
+Other lines (one JSON line per invocation, same keys):
+    --config cfg5      BASELINE configs[4]: 120x21 lattice, 16 obstacles, full cycle + the S-T speed DP (40x16 grid, 16
+                       dynamic-obstacle slots; reference speed_planning_test.py:38-188) per scene, 1024 scenes per GPU
+    --latency          BASELINE configs[1]: ONE scene on the 40x9 lattice, synchronous calls (metric: ms per cycle)
+    --scene-dist X     obstacle layout of the synthetic scenes: corridor (default, emplanner_carla_amd/scenes.py), survey
+                       (s_k = 12 + 11 k +- 2, l_k = +-U(2.5, 5)), worst (all obstacles within reach
+                       of the same columns)
+    --dp-mode fused    the single-kernel DP (no HBM edge tensor; no sweep kernel, so `roofline` is null)
+
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      the DP min-plus sweep kernel (HBM bound): algorithmic bytes / mean HIP-event duration of its
-                launches INSIDE the timed region (the only kernel bracketed by events there)
+                launches INSIDE the timed region (the only kernel bracketed by events there); `traffic` = HBM bytes
+                per launch from the rocprofv3 PMC passes named in `traffic_source`, or null when no profile of this
+                workload is committed
   cpu_baseline  the reference-structured CPU port (oracle/ref_port.py), one core, bounded sample
   cpu_baseline_pool   the same port on a pool of single-threaded processes (up to 64 host cores), whole-pool rate
   kernels_ms    mean duration of every kernel of the cycle, from a short diagnostic pass after the timed region
-                with every kernel bracketed by events (the brackets themselves cost ~7 % of a step)
-  roofline_dp_edge, dp_only   the FP64-VALU-bound edge kernel against the vector peak, and the DP alone (same pass)
+                with every kernel bracketed by events, one batch in flight
+  roofline_dp_edge, dp_only   the FP64-issue-bound edge kernel (algorithmic flops of SURVEY.md 8d AND the executed
+                wave-level instruction / active-lane counts of the committed SQ counter profile), and the DP alone
+  fully_planned_cycles_per_s  value x the fraction of scenes whose cycle ran to the end (the rest are refused: walls,
+                blocked corridors, infeasible QPs - they were computed too, and are part of `value`)
 """
 from __future__ import annotations
 
@@ -38,14 +52,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (public spec figure)
 
 
-def cpu_baseline(cfg, n_scenes, seed0):
+def cpu_baseline(cfg, n_scenes, seed0, dist_name="corridor", budget_s=25.0):
     """Time the reference-structured CPU path (the oracle's faithful port) on a bounded sample."""
     import contextlib
     import io
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
     kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
-    scenes = [S.make_scene(seed0 + i, cfg) for i in range(n_scenes)]
+    scenes = [S.make_scene(seed0 + i, cfg, dist=dist_name) for i in range(n_scenes)]
     t0 = time.perf_counter()
     done = 0
     for sc in scenes:
@@ -53,10 +67,10 @@ def cpu_baseline(cfg, n_scenes, seed0):
             with contextlib.redirect_stdout(io.StringIO()):
                 op.plan_cycle([tuple(r) for r in sc.ref], sc.origin_xy, sc.start_xy, sc.start_v, sc.start_a, sc.obs_xy,
                               dp_kwargs=kw, obs_length=cfg.obs_length, obs_width=cfg.obs_width, verbose=False)
-        except IndexError:
+        except (IndexError, np.linalg.LinAlgError):
             pass
         done += 1
-        if time.perf_counter() - t0 > 25.0:
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "planning cycles/s", "cores": 1, "kind": "port",
@@ -89,7 +103,7 @@ def cpu_baseline_pool(cfg_name, workers, per_worker):
     try:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.map(cpu_pool.warm, range(workers), chunksize=1)           # processes up, modules imported
-            jobs = [("CFG2", list(range(10000 + w * per_worker, 10000 + (w + 1) * per_worker))) for w in range(workers)]
+            jobs = [(cfg_name, list(range(10000 + w * per_worker, 10000 + (w + 1) * per_worker))) for w in range(workers)]
             t0 = time.perf_counter()
             done = pool.map(cpu_pool.plan_seeds, jobs, chunksize=1)
             dt = time.perf_counter() - t0
@@ -114,29 +128,106 @@ def cpu_baseline_pool(cfg_name, workers, per_worker):
                       f"{dt:.1f} s wall"}
 
 
+def committed_profile(kind, **match):
+    """An entry of profiles/counters.json (written by tools/summarize_profile.py / tools/summarize_sq.py from rocprofv3
+    passes on the GPU box) whose workload keys equal `match`; None when no such profile is committed."""
+    side = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        for e in json.load(open(side)).get(kind, []):
+            if all(e.get(k) == v for k, v in match.items()):
+                return e
+    except Exception:
+        pass
+    return None
+
+
+def latency_main(args):
+    """BASELINE configs[1]: one scene on the 40x9 lattice, one synchronous call per cycle (what a driver that plans for
+    one vehicle sees).  Prints one JSON line; `value` is the mean wall time of a cycle in milliseconds."""
+    import torch
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params
+    cfg = S.CFG2
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    batch = S.make_batch([7], cfg, dist=args.scene_dist)
+    P = batch.ref.shape[1]
+    host = dict(ref_line=batch.ref, n_ref=np.full(1, P, np.int32), origin_xy=batch.origin_xy, start_xy=batch.start_xy,
+                start_v=batch.start_v, start_a=batch.start_a, obs_xy=batch.obs_xy, n_obs=batch.n_obs)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in host.items()}
+    pl = Planner(0)
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+    M = max_path_points(p)
+    steps, warm = max(args.steps, 20), max(args.warmup, 5)
+    out = {}
+    for name, inputs in (("device_resident_inputs", dev), ("host_arrays_in_and_out", host)):
+        for _ in range(warm):
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **inputs)
+            pl.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **inputs)
+            pl.synchronize()
+        out[name] = (time.perf_counter() - t0) / steps * 1e3
+    pl.set_timing(True)
+    for _ in range(5):
+        r = pl.plan_cycle(p, q, sp, max_pts=M, **dev)
+        pl.synchronize()
+    kernels = {n: round(pl.kernel_ms(n), 6) for n in ("project", "dp_edge", "dp_sweep", "dp_enrich", "path_qp", "to_cartesian")
+               if pl.kernel_ms(n) >= 0}
+    st = int(np.asarray(r.status.cpu() if hasattr(r.status, "cpu") else r.status)[0])
+    line = {"metric": "planning cycle latency (DP+QP, 40x9 S-L lattice, 8 obs, ONE scene)", "value": round(out["device_resident_inputs"], 4),
+            "unit": "ms per planning cycle", "n_gpus": 1, "steps": steps, "warmup": warm,
+            "ms_per_step": round(out["device_resident_inputs"], 4), "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: one scene, full planning cycle, one synchronous call per cycle, inputs "
+                                   "resident in HBM", "scenes_per_gpu": 1, "lattice": f"col={cfg.col} x row={cfg.row}",
+                       "obstacles": cfg.n_obs, "scene_dist": args.scene_dist},
+            "roofline": None, "latency_ms": {k: round(v, 4) for k, v in out.items()}, "kernels_ms": kernels,
+            "scene_status": st,
+            "note": "a single scene occupies one wavefront per kernel: the cycle is launch and dependent-instruction latency, "
+                    "no roofline applies"}
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(cfg, 8, 7, args.scene_dist, budget_s=10.0)
+        line["cpu_baseline"] = {**cb, "value": round(1e3 / cb["value"], 2), "unit": "ms per planning cycle"}
+    print(json.dumps(line), flush=True)
+    pl.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scenes-per-gpu", type=int, default=4096)
+    ap.add_argument("--config", choices=["cfg2", "cfg5"], default="cfg2", help="cfg2 = BASELINE configs[2]/[3] (default); cfg5 = configs[4]")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="default 4096 (cfg2) / 1024 (cfg5)")
+    ap.add_argument("--scene-dist", choices=["corridor", "survey", "worst"], default="corridor")
+    ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight instead of two (emp_set_pipeline off)")
     ap.add_argument("--force-gather-path", action="store_true",
                     help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
+    ap.add_argument("--gather", choices=["rank0", "all"], default="rank0",
+                    help="N > 1: gather the records to rank 0 (default: what BASELINE's 'RCCL gather' asks for) or all_gather them")
+    ap.add_argument("--records", choices=["full", "trajectory"], default="full",
+                    help="what a record carries: everything a cycle returns (179 doubles per scene at 40x9) or status + "
+                         "trajectory only (94)")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
     ap.add_argument("--cpu-pool-scenes", type=int, default=16, help="scenes per pool process")
     args = ap.parse_args()
+    if args.latency:
+        return latency_main(args)
 
     import torch
     import torch.distributed as dist
     from emplanner_carla_amd import _lib as L
     from emplanner_carla_amd import dist as emp_dist
     from emplanner_carla_amd import scenes as S
-    from emplanner_carla_amd.api import (Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params)
+    from emplanner_carla_amd.api import (Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params,
+                                         speed_dp_params)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,20 +240,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    cfg = S.CFG2
-    B = args.scenes_per_gpu
+    wide = args.config == "cfg5"
+    cfg = S.CFG5 if wide else S.CFG2
+    B = args.scenes_per_gpu or (1024 if wide else 4096)
     total = B * world
     start, count = emp_dist.shard_range(total, rank, world)
-    batch = S.make_batch(range(start, start + count), cfg)
+    batch = S.make_batch(range(start, start + count), cfg, dist=args.scene_dist)
     P = batch.ref.shape[1]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(count, P, np.int32)), origin_xy=t(batch.origin_xy),
                   start_xy=t(batch.start_xy), start_v=t(batch.start_v), start_a=t(batch.start_a),
                   obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
+    st_inputs = None
+    if wide:    # the S-T half of configs[4]: 16 dynamic-obstacle slots per scene (reference speed_planning_test.py:38-188)
+        dyn = S.make_dynamic_batch(range(start, start + count), 16)
+        st_inputs = [t(a) for a in dyn[:4]], t(dyn[4])
     torch.cuda.synchronize()
 
     pl = Planner(local_rank)
     p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+    sdp = speed_dp_params()
     M = max_path_points(p)
     mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
     # Two batches in flight: the back stage (path QP, Cartesian tail) of step k runs on the planner's second stream
@@ -173,8 +270,10 @@ def main():
     ts = pl.torch_stream()
 
     gather_path = world > 1 or args.force_gather_path
-    gs = torch.cuda.Stream(device=device) if gather_path else None        # the gather's own stream
-    in_flight = []                                                        # (tensors, event) of the last gathers
+    sg = None
+    if gather_path:      # the per-step result exchange (emplanner_carla_amd/dist.py StepGather): pack on the result stream,
+        sg = emp_dist.StepGather(p.col, M, total, planner=pl, fields=args.records, device=device,     # gather on its own
+                                 dst=0 if args.gather == "rank0" else None)
 
     def step():
         # torch work of a step runs on the planner's own streams, ordered with its kernels without any cross-stream
@@ -183,21 +282,10 @@ def main():
         # the gather of step k overlaps the back stage of step k+1 as well as its front stage.
         with torch.cuda.stream(ts):
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
-        if not gather_path:
-            return res
-        rs = pl.torch_result_stream()
-        with torch.cuda.stream(rs):
-            rec = emp_dist.pack_records(res, p.col, M, path_cap=emp_dist.path_capacity(M), planner=pl)
-        gs.wait_stream(rs)
-        with torch.cuda.stream(gs):
-            out = emp_dist.gather_records(rec, total)
-            done = torch.cuda.Event()
-            done.record(gs)
-        # the packed records and the gathered matrix stay referenced until their gather has certainly finished
-        in_flight.append((rec, out, done))
-        if len(in_flight) > 3:
-            in_flight.pop(0)[2].synchronize()          # three steps old: long done, costs nothing
-        return out
+            if wide:
+                sets = pl.st_graph(*st_inputs[0])
+                pl.speed_dp(sdp, *sets, st_inputs[1], tables=False)
+        return sg.submit(res) if gather_path else res, res
 
     def fence():
         pl.synchronize()
@@ -207,14 +295,14 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        out = step()
+        out, res = step()
     fence()
     # Inside the timed region only the roofline kernel is bracketed by HIP events (an event pair costs a few
     # microseconds of stream time per launch; six bracketed kernels per step cost ~7 % of the step).
     pl.set_timing(True, only="dp_sweep")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out, res = step()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,25 +316,34 @@ def main():
     fence()
     pl.set_pipeline(False)
     for _ in range(2):
-        out = step()
+        out, res = step()
     fence()
     pl.set_timing(True)
     for _ in range(min(args.steps, 5)):
-        out = step()
+        out, res = step()
     fence()
     kernels = {}
-    for name in ("project", "dp_edge", "dp_sweep", "dp_fused", "dp_enrich", "path_qp", "to_cartesian", "heading"):
+    for name in ("project", "dp_edge", "dp_sweep", "dp_fused", "dp_enrich", "path_qp", "to_cartesian", "heading", "st_graph",
+                 "speed_dp"):
         ms = pl.kernel_ms(name)
         if ms >= 0:
             kernels[name] = round(ms, 6)
     pl.set_timing(False)
 
-    # outcome statistics of the last step (sanity: the work was really done)
-    if gather_path:
-        st = emp_dist.unpack_records(out, p.col, M, path_cap=emp_dist.path_capacity(M))["status"].cpu().numpy()
-    else:
-        st = out.status.cpu().numpy()
-    ok_frac = float(((st & ~1) == 0).mean())
+    # outcome statistics of the last step (sanity: the work was really done); every rank looks at its own shard and the
+    # fractions are averaged over the ranks
+    stl = res.status.cpu().numpy()
+    ok_frac = float(((stl & ~1) == 0).mean())
+    if world > 1:
+        okt = torch.tensor([ok_frac * count, float(count)], dtype=torch.float64, device=device)
+        dist.all_reduce(okt)
+        ok_frac = float(okt[0].item() / okt[1].item())
+    gathered_ok = None
+    if gather_path and out is not None:                    # on the destination rank: the gathered records are complete
+        gst = sg.unpack(out)["status"].cpu().numpy()
+        gathered_ok = bool(gst.shape[0] == total)
+    if sg is not None:
+        sg.drain()
 
     if rank == 0:
         E = cfg.row + (cfg.col - 1) * cfg.row ** 2
@@ -254,59 +351,78 @@ def main():
         roof = None
         if sweep_ms > 0:
             ach = bytes_dp / (sweep_ms * 1e-3) / 1e9
-            traffic = None
-            side = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(side):
-                try:
-                    tj = json.load(open(side))
-                    if tj.get("scenes_per_gpu") == count and tj.get("kernel") == "dp_sweep":
-                        traffic = tj.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            prof = committed_profile("dp_sweep_traffic", config=cfg.name, scenes_per_gpu=count)
             roof = {"kernel": "dp_sweep_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": prof["hbm_bytes_per_launch"] if prof else None,
+                    "traffic_source": prof["source"] if prof else None,
                     "algorithmic_bytes_per_launch": bytes_dp, "launches_timed": sweep_launches,
                     "mean_launch_us": round(sweep_ms * 1e3, 2)}
         # Secondary figures from the diagnostic pass (event-bracketed kernels; not part of the timed region):
-        # the edge-cost kernel against the FP64 vector peak with SURVEY.md 8(d)'s ALGORITHMIC flop count (obstacles
-        # out of reach are skipped at run time, so fewer are executed), and the DP alone.
+        # the edge-cost kernel against the FP64 vector peak with SURVEY.md 8(d)'s ALGORITHMIC flop count next to what
+        # the committed SQ counter profile says was executed (obstacles out of reach are skipped at run time and
+        # 40-45 % of the lanes of an executed instruction are masked off), and the DP alone.
         extra = {}
         if "dp_edge" in kernels:
             flops = E * (40 + 10 * (36 + 7 * cfg.n_obs)) * count
             tf = flops / (kernels["dp_edge"] * 1e-3) / 1e12
-            extra["roofline_dp_edge"] = {"kernel": "dp_edge_kernel", "bound": "fp64_valu", "achieved": round(tf, 2),
-                                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-                                         "algorithmic_flops_per_launch": flops,
-                                         "mean_launch_us": round(kernels["dp_edge"] * 1e3, 2),
-                                         "source": "diagnostic pass after the timed region"}
+            cprof = committed_profile("dp_edge_counters", config=cfg.name, scenes_per_gpu=count, scene_dist=args.scene_dist)
+            e = {"kernel": "dp_edge_kernel", "bound": "fp64_valu_issue", "achieved": round(tf, 2),
+                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s (ALGORITHMIC flops; fewer are executed)",
+                 "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops,
+                 "mean_launch_us": round(kernels["dp_edge"] * 1e3, 2), "source": "diagnostic pass after the timed region"}
+            if cprof:
+                busy = cprof["valu_busy_quad_cycles"] * 4 / (1024 * 2.4e3) / (kernels["dp_edge"] * 1e3)
+                e.update(executed_wave_instructions_valu=cprof["insts_valu"], active_lane_frac=cprof["lanes_active_frac"],
+                         executed_lane_ops=int(cprof["insts_valu"] * 64 * cprof["lanes_active_frac"]),
+                         valu_issue_busy_frac=round(busy, 3), counters_source=cprof["source"])
+            extra["roofline_dp_edge"] = e
         if all(k in kernels for k in ("dp_edge", "dp_sweep", "dp_enrich")):
             dp_ms = kernels["dp_edge"] + kernels["dp_sweep"] + kernels["dp_enrich"]
             extra["dp_only"] = {"value": round(count / (dp_ms * 1e-3), 1), "unit": "DP plans/s per GPU",
                                 "source": "sum of the three DP kernels' mean durations in the diagnostic pass"}
+        if wide and "speed_dp" in kernels:
+            e_st = 40 + 15 * 40 * 40
+            extra["speed_dp"] = {"value": round(count / (kernels["speed_dp"] * 1e-3), 1), "unit": "S-T speed DPs/s per GPU",
+                                 "edges_per_dp": e_st, "bound": "fp64_valu_issue",
+                                 "hbm_bytes_per_scene": 16 * 4 * 8 + 8 + 2 * 16 * 8 + 8,
+                                 "source": "diagnostic pass; tables stay in LDS (emp_st_kernels.h)"}
         value = total * args.steps / elapsed
+        gather_note = ""
+        if world > 1:
+            gather_note = f"; + RCCL {'gather to rank 0' if args.gather == 'rank0' else 'all_gather'} of {args.records} result records"
         line = {
-            "metric": "planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)", "value": round(value, 1),
+            "metric": ("planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)" if not wide else
+                       "planning cycles/sec (DP+QP on the 120x21 S-L lattice, 16 obs, + S-T speed DP 40x16, 16 dynamic obstacles)"),
+            "value": round(value, 1),
             "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]/[3]: full planning cycle per scene (projection, S-L DP, path QP, "
-                                   "Frenet->Cartesian, smoothing QP, heading/kappa), inputs resident in HBM"
-                                   + ("; + RCCL all_gather of result records" if world > 1 else ""),
+            "config": {"workload": ("BASELINE configs[2]/[3]" if not wide else "BASELINE configs[4]")
+                                   + ": full planning cycle per scene (projection, S-L DP, path QP, Frenet->Cartesian, "
+                                     "smoothing QP, heading/kappa)" + (", then generate_st_graph + the S-T speed DP" if wide else "")
+                                   + ", inputs resident in HBM" + gather_note,
                        "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
-                       "ref_line_points": int(P), "qp_stations": 21, "dp_mode": args.dp_mode,
+                       "scene_dist": args.scene_dist, "ref_line_points": int(P), "dp_mode": args.dp_mode,
                        "batches_in_flight": 2 if pipelined else 1,
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
             **extra,
             "kernels_ms": kernels,
             "scenes_fully_planned_frac": round(ok_frac, 4),
+            "fully_planned_cycles_per_s": round(value * ok_frac, 1),
         }
+        if gather_path:
+            line["gather"] = {"mode": args.gather, "records": args.records, "doubles_per_scene": sg.width,
+                              "bytes_sent_per_rank_and_step": sg.bytes_per_rank_and_step(count),
+                              "bytes_received_by_rank0_per_step": sg.bytes_per_rank_and_step(count) * (world - 1)
+                              if args.gather == "rank0" else sg.bytes_per_rank_and_step(count) * (world - 1),
+                              "records_complete_on_rank0": gathered_ok}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, 0)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample if not wide else 2, 0, args.scene_dist)
             workers = usable_cores(64) if args.cpu_pool < 0 else args.cpu_pool
-            if workers > 0:
+            if workers > 0 and not wide:
                 try:
                     line["cpu_baseline_pool"] = cpu_baseline_pool("CFG2", workers, args.cpu_pool_scenes)
                 except Exception as exc:                                       # informational: never fails the bench

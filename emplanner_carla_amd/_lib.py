@@ -95,6 +95,7 @@ PROTOTYPES = {
     "emp_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "emp_result_stream": (_vp, [_vp]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
+    "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
     "emp_kernel_launches": (C.c_int, [_vp, C.c_char_p]),
     "emp_edge_tensor_elems": (_u64, [C.POINTER(DpParams), _i32, C.c_int]),
@@ -166,7 +167,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 5:
+    if lib.emp_abi_version() != 6:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

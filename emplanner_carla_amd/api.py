@@ -799,20 +799,33 @@ class Planner:
                 self._inflight.pop(0)
         return CycleResult(**res)
 
-    def pack_records(self, res: "CycleResult", col: int, max_pts: int, path_cap=None):
+    def pack_records(self, res: "CycleResult", col: int, max_pts: int, path_cap=None, fields: str = "full"):
         """One fixed-stride float64 record per scene from a cycle's outputs on the device, in ONE launch
-        (emp_pack_records; layout of ``emplanner_carla_amd.dist.record_width``).  The launch goes to the stream on which
-        the cycle's outputs become complete (``torch_result_stream()``); a caller on another stream is ordered with it."""
+        (emp_pack_records / emp_pack_trajectory_records; layouts of ``emplanner_carla_amd.dist.record_width``).  The
+        launch goes to the stream on which the cycle's outputs become complete (``torch_result_stream()``); a caller on
+        another stream is ordered with it.  ``fields``: "full" or "trajectory" (status, traj_len, trajectory only)."""
+        if fields not in ("full", "trajectory"):
+            raise ValueError("fields must be 'full' or 'trajectory'")
         cap = int(max_pts) if path_cap is None else min(int(path_cap), int(max_pts))
         B = int(res.status.shape[0])
-        width = 3 + int(col) + 2 * cap + 4 * (cap + 1)
+        full = fields == "full"
+        width = (3 + int(col) + 2 * cap if full else 2) + 4 * (cap + 1)
+        shapes = [(res.status, np.int32, (B,)), (res.traj_len, np.int32, (B,))]
+        if full:
+            shapes += [(res.path_len, np.int32, (B,)), (res.dp_rows, np.float64, (B, int(col))),
+                       (res.path_s, np.float64, (B, int(max_pts))), (res.path_l, np.float64, (B, int(max_pts)))]
+        shapes.append((res.traj, np.float64, (B, int(max_pts) + 1, 4)))
+
+        def call(ptrs, rp, on_rs, where):
+            if full:
+                return self._lib.emp_pack_records(self._h, B, int(col), int(max_pts), cap, *ptrs, rp, on_rs, where)
+            return self._lib.emp_pack_trajectory_records(self._h, B, int(max_pts), cap, *ptrs, rp, on_rs, where)
+
         if not _is_torch(res.status):                       # host arrays: staged through the library like any other call
             a = self._args(res.status)
-            ptrs = [a.inp(res.status, np.int32, (B,)), a.inp(res.traj_len, np.int32, (B,)), a.inp(res.path_len, np.int32, (B,)),
-                    a.inp(res.dp_rows, np.float64, (B, int(col))), a.inp(res.path_s, np.float64, (B, int(max_pts))),
-                    a.inp(res.path_l, np.float64, (B, int(max_pts))), a.inp(res.traj, np.float64, (B, int(max_pts) + 1, 4))]
+            ptrs = [a.inp(x, dt, shp) for x, dt, shp in shapes]
             rec, rp = a.out((B, width), np.float64)
-            self._check(self._lib.emp_pack_records(self._h, B, int(col), int(max_pts), cap, *ptrs, rp, 0, a.where))
+            self._check(call(ptrs, rp, 0, a.where))
             return rec
         import torch
         dev = res.status.device
@@ -823,13 +836,12 @@ class Planner:
             target.wait_stream(cur)
         rec = torch.empty((B, width), dtype=torch.float64, device=dev)
         ptr = lambda t: C.c_void_p(t.data_ptr())
-        arrs = [res.status, res.traj_len, res.path_len, res.dp_rows, res.path_s, res.path_l, res.traj]
+        arrs = [x for x, _, _ in shapes]
         for t_ in arrs:
             if not (t_.is_cuda and t_.is_contiguous()):
                 raise ValueError("pack_records takes the contiguous device tensors plan_cycle returned")
         self._cur = None
-        self._check(self._lib.emp_pack_records(self._h, B, int(col), int(max_pts), cap, *[ptr(t_) for t_ in arrs], ptr(rec),
-                                               1 if self.pipelined else 0, L.EMP_DEVICE))
+        self._check(call([ptr(t_) for t_ in arrs], ptr(rec), 1 if self.pipelined else 0, L.EMP_DEVICE))
         if foreign:
             cur.wait_stream(target)
         return rec

@@ -109,19 +109,32 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     // Ring depth PD (columns in flight per wavefront), measured at 4096 scenes: 2 is best for rows 5..12 (row 9:
     // 20.4 us against 23.2 at PD = 8, 21.4 at PD = 1), 3 for the 21-row lattice; nontemporal loads change nothing.
     // EMP_SWEEP_VARIANT selects alternatives for the 9-row lattice (development).
+    // Load policy, measured on the 40x9 lattice (sweep alone, TB/s of algorithmic bytes; plain / nontemporal): 4096 scenes
+    // (105 MB tensor) 5.45 / 4.74, 8192 (226 MB) 6.47 / 6.21, 12288 (331 MB) 5.04 / 6.45, 16384 4.47 / 6.40, 32768 (883 MB)
+    // 4.52 / 6.03.  A tensor that fits the 256 MiB Infinity Cache is still there when the sweep follows the edge kernel
+    // that wrote it, and plain loads hit it; a larger one streams from HBM, where plain loads also drag every line through
+    // the cache hierarchy they will never hit again: nontemporal from 256 MiB on.
+    const bool nt = tiled_elems(d) * sizeof(double) > ((size_t)256 << 20);
+#define EMP_SWEEP_AUTO(R, PD)                      \
+    do {                                           \
+        if (nt) EMP_SWEEP_NT(R, PD, 1, true);      \
+        else EMP_SWEEP_NT(R, PD, 1, false);        \
+    } while (0)
     switch (d.row) {
-        case 5: EMP_SWEEP(5, 2, 1); break;
+        case 5: EMP_SWEEP_AUTO(5, 2); break;
         case 9:
             if (variant == 1) EMP_SWEEP(9, 3, 1);
             else if (variant == 2) EMP_SWEEP(9, 4, 1);
             else if (variant == 3) EMP_SWEEP(9, 8, 1);
             else if (variant == 4) EMP_SWEEP_NT(9, 2, 1, true);
-            else EMP_SWEEP(9, 2, 1);
+            else if (variant == 5) EMP_SWEEP_NT(9, 2, 1, false);
+            else EMP_SWEEP_AUTO(9, 2);
             break;
-        case 12: EMP_SWEEP(12, 2, 1); break;
-        case 21: EMP_SWEEP(21, 3, 1); break;
+        case 12: EMP_SWEEP_AUTO(12, 2); break;
+        case 21: EMP_SWEEP_AUTO(21, 3); break;
         default: EMP_SWEEP(0, 1, 1); break;
     }
+#undef EMP_SWEEP_AUTO
 #undef EMP_SWEEP
 #undef EMP_SWEEP_NT
     EMP_LAUNCH_CHECK(ctx);
@@ -373,6 +386,46 @@ int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int3
         hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                            on_rs ? ctx->stream2 : ctx->stream, B, col, max_pts, path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll,
                            d_traj, d_rec);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+// trajectory-only record: status, traj_len, traj [cap + 1][4]
+__global__ __launch_bounds__(256) void pack_trajectory_records_kernel(int B, int max_pts, int cap, const int* __restrict__ status,
+                                                                      const int* __restrict__ traj_len,
+                                                                      const double* __restrict__ traj,
+                                                                      double* __restrict__ rec) {
+    const int width = 2 + 4 * (cap + 1);
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * width) return;
+    const int b = (int)(idx / width);
+    const int c = (int)(idx - (size_t)b * width);
+    rec[idx] = c == 0 ? (double)status[b] : c == 1 ? (double)traj_len[b] : traj[(size_t)b * (max_pts + 1) * 4 + (c - 2)];
+}
+
+int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_t path_cap, const int32_t* status,
+                                const int32_t* traj_len, const double* traj, double* rec, int on_result_stream,
+                                emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, B >= 0 && max_pts >= 1 && path_cap >= 1 && path_cap <= max_pts, "bad sizes");
+    EMP_REQUIRE(ctx, status && traj_len && traj && rec, "NULL array");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    const bool on_rs = on_result_stream && ctx->pipeline && ctx->stream2 && where == EMP_DEVICE;
+    Stage st(ctx, where, on_rs);
+    int rc;
+    const int *d_st, *d_tl;
+    const double* d_traj;
+    double* d_rec;
+    const size_t width = 2 + 4 * ((size_t)path_cap + 1);
+    if ((rc = st.in(status, (size_t)B, &d_st))) return rc;
+    if ((rc = st.in(traj_len, (size_t)B, &d_tl))) return rc;
+    if ((rc = st.in(traj, (size_t)B * (max_pts + 1) * 4, &d_traj))) return rc;
+    if ((rc = st.out(rec, (size_t)B * width, &d_rec, false))) return rc;      // every slot is written by the kernel
+    if (B) {
+        const size_t total = (size_t)B * width;
+        hipLaunchKernelGGL(pack_trajectory_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           on_rs ? ctx->stream2 : ctx->stream, B, max_pts, path_cap, d_st, d_tl, d_traj, d_rec);
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();

@@ -259,6 +259,10 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
                                                        double* __restrict__ min_cost_out,
                                                        int* __restrict__ status_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];   // [WPB][64] doubles, then [WPB][col][64] bytes
+    // One wavefront per tile, ~75 instructions per column between two waits for HBM: with two batches in flight it shares
+    // its SIMD with the previous batch's path-QP / Cartesian wavefronts, which raise their priority to 3; at priority 0
+    // every one of its short bursts queued behind them and the stream slowed from 20.5 to 22.5-25 us.
+    __builtin_amdgcn_s_setprio(3);
     const int row = ROW > 0 ? ROW : P.row;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* cost_lds = reinterpret_cast<double*>(pre_lds);

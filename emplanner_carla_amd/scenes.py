@@ -100,8 +100,38 @@ def _arc_point(arc, s, l):
     return np.array([x - l * np.sin(th), y + l * np.cos(th)]), th
 
 
+#: obstacle layouts: "corridor" (default, below), "survey" (SURVEY.md section 8d), "worst" (every obstacle within reach
+#: of the same stretch of lattice)
+SCENE_DISTS = ("corridor", "survey", "worst")
+
+
+def _survey_obstacles(rng, n, horizon):
+    """``s_k = 12 + 11 k + U(-2, 2)`` metres ahead of the planning start (k = 0..7, all <= 91 m
+    on the 100 m horizon; scaled with the horizon for other lattices), ``l_k = +-U(2.5, 5.0)`` with the sign alternating
+    with probability 0.7."""
+    scale = horizon / 100.0
+    k = np.arange(n)
+    obs_s = (12.0 + 11.0 * k * (8.0 / max(n, 1)) + rng.uniform(-2.0, 2.0, n)) * scale
+    sign = np.empty(n)
+    cur = 1.0 if rng.random() < 0.5 else -1.0
+    for j in range(n):
+        if j and rng.random() < 0.7:
+            cur = -cur
+        sign[j] = cur
+    return obs_s, sign * rng.uniform(2.5, 5.0, n)
+
+
+def _worst_obstacles(rng, n, horizon):
+    """Every obstacle within reach of the same lattice columns: 1.5 m apart from 30 % of the horizon on, alternating
+    sides just outside the hard radius of the centre row, so that the centre line stays drivable while every edge of
+    some fifteen metres of lattice scans all of them."""
+    obs_s = 0.3 * horizon + 1.5 * np.arange(n) + rng.uniform(-0.2, 0.2, n)
+    side = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    return obs_s, side * rng.uniform(5.2, 5.8, n)
+
+
 def make_scene(seed: int, cfg: LatticeConfig = CFG2, origin_index: int = 5, start_ahead: float = 2.0,
-               blocked_fraction: float = 0.1) -> Scene:
+               blocked_fraction: float = 0.1, dist: str = "corridor") -> Scene:
     """Scene ``seed``.
 
     Obstacle layout: the reference's quirked smoothness cost makes lateral moves beyond
@@ -155,7 +185,15 @@ def make_scene(seed: int, cfg: LatticeConfig = CFG2, origin_index: int = 5, star
             obs_l[1] = corridor + rng.uniform(0.55, 1.3)
             for k in (0, 2):
                 obs_l[k] = corridor + side[k] * (8.0 + drift[k] + rng.uniform(0.0, 2.0))
-        if n >= 3 and rng.random() < blocked_fraction:
+        if dist == "survey":
+            rel_s, obs_l = _survey_obstacles(rng, n, horizon)
+            obs_s = start_ahead + rel_s
+        elif dist == "worst":
+            rel_s, obs_l = _worst_obstacles(rng, n, horizon)
+            obs_s = start_ahead + rel_s
+        elif dist != "corridor":
+            raise ValueError(f"unknown scene distribution {dist!r}: one of {SCENE_DISTS}")
+        if n >= 3 and dist != "worst" and rng.random() < blocked_fraction:
             # a wall: three obstacles abreast cover every lattice row within the 4 m hard radius
             k = int(rng.integers(0, n - 2))
             obs_s[k:k + 3] = obs_s[k + 1]

@@ -45,17 +45,12 @@ def pack_requests(requests):
     return a
 
 
-def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=None):
-    """requests: list of request tuples.  Returns a list of (reply tuple or None, status): None where the reference
-    would have raised (IndexError paths) or where a QP is infeasible.  ``stages``: a dict that receives the packed
-    inputs and the raw outputs of the two device calls (for the stage-by-stage parity tests)."""
+def plan_arrays(planner: Planner, a, dp=None, qp=None, sp=None, stages=None):
+    """The two device calls on packed request arrays (the dict of ``pack_requests``; also what the wire server decodes
+    its fixed-stride records into).  Returns (reference-line status (B,), match index (B,), CycleResult, max_pts)."""
     dp = dp or dp_params()
     qp = qp or qp_params()
     sp = sp or smooth_params()
-    B = len(requests)
-    if B == 0:
-        return []
-    a = pack_requests(requests)
     ref, n_ref, match, _, st_ref = planner.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
     M = max_path_points(dp)
     n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
@@ -63,6 +58,17 @@ def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=
                              start_v=a["v"], start_a=a["a"], obs_xy=a["obs_xy"], n_obs=a["n_obs"], dyn_dis_speed=a["dyn"])
     if stages is not None:
         stages.update(inputs=a, ref_line=ref, n_ref=n_ref_used, match=match, ref_status=st_ref, cycle=res)
+    return st_ref, match, res, M
+
+
+def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=None):
+    """requests: list of request tuples.  Returns a list of (reply tuple or None, status): None where the reference
+    would have raised (IndexError paths) or where a QP is infeasible.  ``stages``: a dict that receives the packed
+    inputs and the raw outputs of the two device calls (for the stage-by-stage parity tests)."""
+    B = len(requests)
+    if B == 0:
+        return []
+    st_ref, match, res, _ = plan_arrays(planner, pack_requests(requests), dp, qp, sp, stages)
     out = []
     for b in range(B):
         status = int(st_ref[b]) | int(res.status[b])

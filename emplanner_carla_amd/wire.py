@@ -1,0 +1,344 @@
+"""Planner service over a socket: the reference's Pipe protocol as a versioned, fixed-stride binary record format.
+
+The reference's driver and its planning process exchange Python tuples over a ``multiprocessing.Pipe`` - pickle over a
+socketpair inside one host (test_9.py:225-227; request :390-392, reply :220).  This module is the same exchange for a
+driver on ANOTHER host: little-endian frames over TCP, no pickle, one planner process
+serving any number of vehicles per frame through the batched device calls of ``service.plan_arrays``.
+
+Frame = 16-byte header + payload:
+
+    magic   u32  0x31504D45 ("EMP1")          version u16 (= WIRE_VERSION)       type u16
+    length  u32  payload bytes                count   u32 records in the payload (PLAN / REPLY), else 0
+
+    HELLO     client -> server: lattice and record capacities (``HELLO`` struct); the server answers with a HELLO
+              carrying the strides it derived - both sides must agree on every stride before a record is sent
+    SET_PATH  client -> server: path_id u32, n u32, then n x (x, y, theta, kappa) f64 - a global path is sent once and
+              referenced by id afterwards (it is 240 x 32 B in the reference's driver and does not change between cycles)
+    PLAN      ``count`` request records of ``request_stride`` bytes:
+                  request_id u64, path_id u32, pre_match i32, n_static u32, n_dynamic u32,
+                  vehicle_loc, pred_loc, vehicle_v, vehicle_a (8 f64: test_9.py:390-392),
+                  static [max_static] x (x, y, distance) f64, dynamic [max_dynamic] x (x, y, distance, speed) f64
+    REPLY     ``count`` reply records of ``reply_stride`` bytes, in request order:
+                  request_id u64, match_index i32, ok u32 (1: the f64 part is a plan), then the f64 part in the layout
+                  of emp_pack_records (include/emplanner.h): status, traj_len, path_len, dp_rows [col], path_s [cap],
+                  path_l [cap], traj [cap + 1] x (x, y, theta, kappa)
+    ERROR     utf-8 text; BYE closes the connection
+
+A reply with ok = 0 is a request the reference would have failed on (its status bits say why: include/emplanner.h
+EMP_ST_*); ``PlannerClient.plan`` turns records back into the reference's reply tuples
+``(trajectory, match_point_list, path_s, path_l)`` (test_9.py:220) or None.
+"""
+from __future__ import annotations
+
+import socket
+import struct
+import threading
+
+import numpy as np
+
+WIRE_MAGIC = 0x31504D45
+WIRE_VERSION = 1
+T_HELLO, T_SET_PATH, T_PLAN, T_REPLY, T_ERROR, T_BYE = 1, 2, 3, 4, 5, 6
+_HEADER = struct.Struct("<IHHII")
+# lattice (emp_dp_params), capacities, then the strides derived from them
+_HELLO = struct.Struct("<iiddddddddIIIIII")
+
+
+class WireError(RuntimeError):
+    pass
+
+
+class Layout:
+    """Record strides of one session: a function of the lattice (``DpParams``) and the obstacle capacities."""
+
+    def __init__(self, dp, max_static: int = 8, max_dynamic: int = 4):
+        from .api import max_path_points
+        from .dist import path_capacity, record_width
+        self.dp = dp
+        self.max_static, self.max_dynamic = int(max_static), int(max_dynamic)
+        self.col, self.max_pts = int(dp.col), int(max_path_points(dp))
+        self.cap = path_capacity(self.max_pts)
+        self.width = record_width(self.col, self.max_pts, self.cap)
+        self.request_dtype = np.dtype([("request_id", "<u8"), ("path_id", "<u4"), ("pre_match", "<i4"), ("n_static", "<u4"),
+                                       ("n_dynamic", "<u4"), ("veh", "<f8", (2,)), ("pred", "<f8", (2,)), ("v", "<f8", (2,)),
+                                       ("a", "<f8", (2,)), ("static", "<f8", (self.max_static, 3)),
+                                       ("dynamic", "<f8", (self.max_dynamic, 4))])
+        self.reply_dtype = np.dtype([("request_id", "<u8"), ("match", "<i4"), ("ok", "<u4"), ("rec", "<f8", (self.width,))])
+        self.request_stride, self.reply_stride = self.request_dtype.itemsize, self.reply_dtype.itemsize
+
+    def hello(self) -> bytes:
+        p = self.dp
+        return _HELLO.pack(p.row, p.col, p.sample_s, p.sample_l, p.sampling_res, p.w_collision, p.w_smooth[0], p.w_smooth[1],
+                           p.w_smooth[2], p.w_ref, self.max_static, self.max_dynamic, self.request_stride, self.reply_stride,
+                           self.cap, self.width)
+
+    @staticmethod
+    def from_hello(payload: bytes) -> "Layout":
+        from .api import dp_params
+        f = _HELLO.unpack(payload)
+        dp = dp_params(row=f[0], col=f[1], sample_s=f[2], sample_l=f[3], sampling_res=f[4], w_collision_cost=f[5],
+                       w_smooth_cost=[f[6], f[7], f[8]], w_reference_cost=f[9])
+        lay = Layout(dp, f[10], f[11])
+        if (lay.request_stride, lay.reply_stride, lay.cap, lay.width) != tuple(f[12:16]):
+            raise WireError(f"record strides disagree: peer says {f[12:16]}, this build derives "
+                            f"{(lay.request_stride, lay.reply_stride, lay.cap, lay.width)}")
+        return lay
+
+    # ---- requests
+    def encode_requests(self, requests, path_ids, request_ids=None) -> bytes:
+        """Reference request tuples (test_9.py:390-392) -> request records.  The global path of request k is referenced by
+        ``path_ids[k]`` (sent beforehand with SET_PATH)."""
+        rec = np.zeros(len(requests), self.request_dtype)
+        for k, (static, dynamic, veh, pred, v, a, _path, match_list) in enumerate(requests):
+            if len(static) > self.max_static or len(dynamic) > self.max_dynamic:
+                raise WireError(f"request {k}: {len(static)} static / {len(dynamic)} dynamic obstacles exceed the session's "
+                                f"capacities ({self.max_static}, {self.max_dynamic})")
+            r = rec[k]
+            r["request_id"] = k if request_ids is None else request_ids[k]
+            r["path_id"], r["pre_match"] = path_ids[k], int(match_list[0])
+            r["n_static"], r["n_dynamic"] = len(static), len(dynamic)
+            r["veh"], r["pred"], r["v"], r["a"] = veh, pred, v, a
+            if len(static):
+                r["static"][:len(static)] = np.asarray(static, dtype=np.float64).reshape(len(static), 3)
+            if len(dynamic):
+                r["dynamic"][:len(dynamic)] = np.asarray(dynamic, dtype=np.float64).reshape(len(dynamic), 4)
+        return rec.tobytes()
+
+    def decode_requests(self, payload: bytes, count: int, paths: dict):
+        """Request records -> the packed arrays of ``service.pack_requests`` (same host logic: static obstacles count only
+        if the nearest is within 30 m, test_9.py:117; only the first dynamic obstacle is used, :141-142)."""
+        if len(payload) != count * self.request_stride:
+            raise WireError(f"PLAN payload of {len(payload)} bytes is not {count} records of {self.request_stride}")
+        rec = np.frombuffer(payload, self.request_dtype, count)
+        for pid in np.unique(rec["path_id"]):
+            if int(pid) not in paths:
+                raise WireError(f"unknown path id {int(pid)}: send SET_PATH first")
+        if (rec["n_static"] > self.max_static).any() or (rec["n_dynamic"] > self.max_dynamic).any():
+            raise WireError("obstacle count beyond the session's capacity")
+        G = max(len(paths[int(p)]) for p in rec["path_id"])
+        a = dict(global_path=np.zeros((count, G, 4)), n_global=np.zeros(count, np.int32),
+                 pred=rec["pred"].astype(np.float64), veh=rec["veh"].astype(np.float64), v=rec["v"].astype(np.float64),
+                 a=rec["a"].astype(np.float64), pre_match=rec["pre_match"].astype(np.int32),
+                 obs_xy=np.zeros((count, max(self.max_static, 1), 2)), n_obs=np.zeros(count, np.int32),
+                 dyn=np.full((count, 2), np.nan))
+        for k in range(count):
+            path = paths[int(rec["path_id"][k])]
+            a["n_global"][k] = len(path)
+            a["global_path"][k, :len(path)] = path
+            ns, nd = int(rec["n_static"][k]), int(rec["n_dynamic"][k])
+            if ns and rec["static"][k, 0, 2] <= 30:                            # test_9.py:117
+                a["n_obs"][k] = ns
+                a["obs_xy"][k, :ns] = rec["static"][k, :ns, :2]
+            if nd:                                                              # test_9.py:141-142
+                a["dyn"][k] = rec["dynamic"][k, 0, 2:4]
+        return rec["request_id"].copy(), a
+
+    # ---- replies
+    def encode_replies(self, request_ids, st_ref, match, res) -> bytes:
+        """The outputs of ``service.plan_arrays`` (host arrays) -> reply records."""
+        from .api import CycleResult  # noqa: F401  (documentation of `res`)
+        B = len(request_ids)
+        out = np.zeros(B, self.reply_dtype)
+        out["request_id"], out["match"] = request_ids, match
+        status = np.asarray(st_ref, np.int64) | np.asarray(res.status, np.int64)
+        out["ok"] = ((np.asarray(st_ref) == 0) & ((np.asarray(res.status) & ~1) == 0)).astype(np.uint32)
+        cap, col, M = self.cap, self.col, self.max_pts
+        rec = out["rec"]
+        rec[:, 0], rec[:, 1], rec[:, 2] = status, res.traj_len, res.path_len
+        o = 3
+        rec[:, o:o + col] = res.dp_rows
+        o += col
+        rec[:, o:o + cap] = np.asarray(res.path_s).reshape(B, M)[:, :cap]
+        o += cap
+        rec[:, o:o + cap] = np.asarray(res.path_l).reshape(B, M)[:, :cap]
+        o += cap
+        rec[:, o:] = np.asarray(res.traj).reshape(B, M + 1, 4)[:, :cap + 1].reshape(B, 4 * (cap + 1))
+        return out.tobytes()
+
+    def decode_replies(self, payload: bytes, count: int):
+        """Reply records -> list of (reference reply tuple or None, status, request_id) (test_9.py:220)."""
+        if len(payload) != count * self.reply_stride:
+            raise WireError(f"REPLY payload of {len(payload)} bytes is not {count} records of {self.reply_stride}")
+        out = []
+        rec = np.frombuffer(payload, self.reply_dtype, count)
+        cap, col = self.cap, self.col
+        for r in rec:
+            d = r["rec"]
+            status = int(round(d[0]))
+            if not r["ok"]:
+                out.append((None, status, int(r["request_id"])))
+                continue
+            m, k = int(round(d[1])), int(round(d[2]))
+            o = 3 + col
+            ps, pl = d[o:o + cap], d[o + cap:o + 2 * cap]
+            traj = d[o + 2 * cap:].reshape(cap + 1, 4)
+            out.append((([tuple(float(x) for x in row) for row in traj[:m]], [int(r["match"])], [float(x) for x in ps[:k]],
+                         [float(x) for x in pl[:k]]), status, int(r["request_id"])))
+        return out
+
+
+def send_frame(sock, ftype: int, payload: bytes = b"", count: int = 0):
+    sock.sendall(_HEADER.pack(WIRE_MAGIC, WIRE_VERSION, ftype, len(payload), count) + payload)
+
+
+def _recv_exact(sock, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def recv_frame(sock, max_payload: int = 1 << 30):
+    magic, version, ftype, length, count = _HEADER.unpack(_recv_exact(sock, _HEADER.size))
+    if magic != WIRE_MAGIC:
+        raise WireError(f"bad magic {magic:#x}")
+    if version != WIRE_VERSION:
+        raise WireError(f"wire version {version}, this build speaks {WIRE_VERSION}")
+    if length > max_payload:
+        raise WireError(f"frame of {length} bytes refused")
+    return ftype, count, _recv_exact(sock, length) if length else b""
+
+
+class PlannerServer:
+    """``PlannerServer(plan_arrays).serve_forever()``: ``plan_arrays(arrays, dp) -> (st_ref, match, CycleResult, max_pts)``
+    is what answers a batch (``serve`` below binds it to a GPU planner; tests bind a stub).  One thread per connection;
+    the planner call itself is serialised (one device context)."""
+
+    def __init__(self, plan_arrays, host: str = "127.0.0.1", port: int = 0):
+        self.plan_arrays = plan_arrays
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        self.sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self.sock.bind((host, port))
+        self.sock.listen(16)
+        self.address = self.sock.getsockname()
+        self._lock = threading.Lock()
+        self._stop = False
+
+    def serve_forever(self):
+        while not self._stop:
+            try:
+                conn, _ = self.sock.accept()
+            except OSError:
+                break
+            threading.Thread(target=self._session, args=(conn,), daemon=True).start()
+
+    def shutdown(self):
+        self._stop = True
+        try:
+            self.sock.close()
+        except OSError:
+            pass
+
+    def _session(self, conn):
+        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        layout, paths = None, {}
+        try:
+            while True:
+                ftype, count, payload = recv_frame(conn)
+                try:
+                    if ftype == T_HELLO:
+                        layout = Layout.from_hello(payload)
+                        send_frame(conn, T_HELLO, layout.hello())
+                    elif ftype == T_SET_PATH:
+                        pid, n = struct.unpack_from("<II", payload)
+                        if len(payload) != 8 + n * 32:
+                            raise WireError("SET_PATH length does not match its point count")
+                        paths[pid] = np.frombuffer(payload, "<f8", n * 4, 8).reshape(n, 4).copy()
+                    elif ftype == T_PLAN:
+                        if layout is None:
+                            raise WireError("PLAN before HELLO")
+                        ids, arrays = layout.decode_requests(payload, count, paths)
+                        with self._lock:
+                            st_ref, match, res, _ = self.plan_arrays(arrays, layout.dp)
+                        send_frame(conn, T_REPLY, layout.encode_replies(ids, st_ref, match, res), count)
+                    elif ftype == T_BYE:
+                        return
+                    else:
+                        raise WireError(f"unknown frame type {ftype}")
+                except WireError as exc:
+                    send_frame(conn, T_ERROR, str(exc).encode())
+        except (ConnectionError, OSError):
+            pass
+        finally:
+            conn.close()
+
+
+def serve(host: str = "0.0.0.0", port: int = 5055, device_id: int = 0):
+    """The planner process: one GPU context, any number of client connections (``python -m emplanner_carla_amd.wire``)."""
+    from . import service
+    from .api import Planner
+    planner = Planner(device_id)
+    srv = PlannerServer(lambda arrays, dp: service.plan_arrays(planner, arrays, dp=dp), host, port)
+    print(f"emplanner wire server v{WIRE_VERSION} on {srv.address[0]}:{srv.address[1]}, device {device_id}", flush=True)
+    srv.serve_forever()
+
+
+class PlannerClient:
+    """Driver side.  ``plan(requests)`` takes the reference's request tuples and returns ``[(reply tuple or None, status)]``
+    in request order; global paths are sent once per distinct path object content."""
+
+    def __init__(self, host: str, port: int, dp=None, max_static: int = 8, max_dynamic: int = 4, timeout: float = 60.0):
+        from .api import dp_params
+        self.layout = Layout(dp or dp_params(), max_static, max_dynamic)
+        self.sock = socket.create_connection((host, port), timeout=timeout)
+        self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        send_frame(self.sock, T_HELLO, self.layout.hello())
+        ftype, _, payload = recv_frame(self.sock)
+        if ftype == T_ERROR:
+            raise WireError(payload.decode())
+        Layout.from_hello(payload)                                   # the server's strides equal ours, or this raises
+        self._paths = {}
+
+    def _path_id(self, path) -> int:
+        arr = np.ascontiguousarray(np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path], dtype="<f8"))
+        key = hash(arr.tobytes())
+        if key not in self._paths:
+            pid = len(self._paths) + 1
+            send_frame(self.sock, T_SET_PATH, struct.pack("<II", pid, len(arr)) + arr.tobytes())
+            self._paths[key] = pid
+        return self._paths[key]
+
+    def plan(self, requests):
+        ids = [self._path_id(r[6]) for r in requests]
+        send_frame(self.sock, T_PLAN, self.layout.encode_requests(requests, ids), len(requests))
+        ftype, count, payload = recv_frame(self.sock)
+        if ftype == T_ERROR:
+            raise WireError(payload.decode())
+        if ftype != T_REPLY or count != len(requests):
+            raise WireError(f"expected {len(requests)} replies, got frame type {ftype} with {count}")
+        return [(reply, status) for reply, status, _ in self.layout.decode_replies(payload, count)]
+
+    def close(self):
+        try:
+            send_frame(self.sock, T_BYE)
+        except OSError:
+            pass
+        self.sock.close()
+
+
+def motion_planning_remote(conn, host: str, port: int, dp=None):
+    """Drop-in body of the reference's planning process (test_9.py:92-220) that plans on a remote server: requests come in
+    over the driver's Pipe, go out over the socket, the reply tuple goes back over the Pipe.  Failure handling as in
+    ``service.motion_planning``."""
+    client = PlannerClient(host, port, dp=dp)
+    while 1:
+        request = conn.recv()
+        reply, status = client.plan([request])[0]
+        if reply is None:
+            if status & (2 | 4):
+                raise IndexError("list index out of range")
+            reply = (None, [int(request[7][0])], [], [])
+        conn.send(reply)
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="EM-Planner service on the GPU (wire format: emplanner_carla_amd/wire.py)")
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=5055)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args()
+    serve(a.host, a.port, a.device)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 5
+#define EMP_ABI_VERSION 6
 
 typedef struct emp_ctx emp_ctx;
 
@@ -141,6 +141,12 @@ void* emp_result_stream(emp_ctx* ctx);
 int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int32_t path_cap, const int32_t* status,
                      const int32_t* traj_len, const int32_t* path_len, const double* dp_rows, const double* path_s,
                      const double* path_l, const double* traj, double* rec, int on_result_stream, emp_mem where);
+/* The same for a consumer that only drives the controller (ref: controller/controller.py:66-71 takes the list of
+ * (x, y, theta, kappa) and nothing else): rec [B][2 + 4*(path_cap+1)] doubles = status, traj_len, traj [path_cap+1][4]
+ * - 94 instead of 179 doubles per scene on the 40x9 lattice (ABI version 6). */
+int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_t path_cap, const int32_t* status,
+                                const int32_t* traj_len, const double* traj, double* rec, int on_result_stream,
+                                emp_mem where);
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
 int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
 

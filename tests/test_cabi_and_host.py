@@ -118,6 +118,118 @@ def test_gather_records_world_size_2_gloo(total):
         assert np.array_equal(got[r], want)
 
 
+def _worker_dst(rank, world, port, total, width, q):
+    import torch
+    import torch.distributed as dist
+    from emplanner_carla_amd.dist import gather_records, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, count = shard_range(total, rank, world)
+    local = torch.arange(start, start + count, dtype=torch.float64).reshape(-1, 1).repeat(1, width)
+    local = local + torch.arange(width, dtype=torch.float64) * 1e-3
+    out = gather_records(local, total, dst=0)
+    q.put((rank, None if out is None else out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_gather_records_to_rank_0_world_size_2_gloo(total):
+    """The gather proper (BASELINE: 'RCCL gather only'): rank 0 receives every block in scene order, rank 1 nothing."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + total
+    width = 5
+    procs = [ctx.Process(target=_worker_dst, args=(r, 2, port, total, width, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(total, dtype=np.float64).reshape(-1, 1) * np.ones((1, width)) + np.arange(width) * 1e-3
+    assert got[1] is None and np.array_equal(got[0], want)
+
+
+class _StubPlanner:
+    """Stands in for emplanner_carla_amd.api.Planner in the CPU test of the multi-GPU step loop: `plan_cycle` returns a
+    CycleResult that encodes (scene index, step) in every field, so the gathered records can be checked exactly."""
+
+    def __init__(self, col, max_pts):
+        self.col, self.max_pts = col, max_pts
+
+    def plan_cycle(self, scene_ids, step):
+        import torch
+        from emplanner_carla_amd.api import CycleResult
+        B, M = len(scene_ids), self.max_pts
+        ids = torch.as_tensor(scene_ids, dtype=torch.float64)
+        f = lambda *shape: (ids.reshape(-1, *([1] * (len(shape)))) * 1000.0 + step + torch.arange(
+            int(np.prod(shape)), dtype=torch.float64).reshape(1, *shape) * 1e-3).contiguous()
+        return CycleResult(dp_rows=f(self.col), dp_s=None, dp_l=None, dp_len=None, path_s=f(M), path_l=-f(M),
+                           path_len=torch.full((B,), M // 2 + 1, dtype=torch.int32), traj=f(M + 1, 4),
+                           traj_len=torch.full((B,), M // 2 + 2, dtype=torch.int32),
+                           status=(torch.as_tensor(scene_ids) % 3).to(torch.int32))
+
+
+def _worker_steps(rank, world, port, total, fields, dst, q):
+    import torch.distributed as dist
+    from emplanner_carla_amd.dist import StepGather, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    col, M = 6, 9
+    start, count = shard_range(total, rank, world)
+    stub = _StubPlanner(col, M)
+    sg = StepGather(col, M, total, planner=None, fields=fields, dst=dst, depth=2)
+    last = None
+    for step in range(5):                                # more steps than the in-flight ring holds
+        last = sg.submit(stub.plan_cycle(list(range(start, start + count)), step))
+    sg.drain()
+    if last is None:
+        q.put((rank, None))
+    else:
+        u = sg.unpack(last)
+        q.put((rank, {k: v.numpy() for k, v in u.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,fields,dst", [(10, "full", 0), (9, "trajectory", 0), (9, "full", None)],
+                         ids=["equal_full_rank0", "ragged_trajectory_rank0", "ragged_full_all"])
+def test_step_loop_of_the_many_scene_mode_world_size_2_gloo(total, fields, dst):
+    """bench.py's per-step code for N > 1 (emplanner_carla_amd.dist.StepGather: pack -> gather -> in-flight ring -> unpack)
+    on two gloo ranks with a stub planner, equal and ragged shards, full and trajectory-only records, gather to rank 0 and
+    all_gather: what arrives is every scene's last-step record, in scene order."""
+    import torch.multiprocessing as mp
+    from emplanner_carla_amd.dist import path_capacity
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + total + (7 if fields == "trajectory" else 0) + (13 if dst is None else 0)
+    procs = [ctx.Process(target=_worker_steps, args=(r, 2, port, total, fields, dst, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    col, M = 6, 9
+    cap = path_capacity(M)
+    want = _StubPlanner(col, M).plan_cycle(list(range(total)), 4)
+    for r in range(2):
+        if dst is not None and r != dst:
+            assert got[r] is None
+            continue
+        u = got[r]
+        assert np.array_equal(u["status"], want.status.numpy()) and np.array_equal(u["traj_len"], want.traj_len.numpy())
+        assert np.array_equal(u["traj"], want.traj.numpy()[:, :cap + 1])
+        if fields == "full":
+            assert np.array_equal(u["dp_rows"], want.dp_rows.numpy()) and np.array_equal(u["path_l"], want.path_l.numpy()[:, :cap])
+        else:
+            assert set(u) == {"status", "traj_len", "traj"}
+
+
 def test_pack_unpack_records_roundtrip():
     import torch
     from emplanner_carla_amd.api import CycleResult
@@ -143,6 +255,11 @@ def test_pack_unpack_records_roundtrip():
     back = unpack_records(rec, col, M, path_cap=cap)
     assert np.array_equal(back["traj"].numpy(), res.traj[:, :cap + 1]) and np.array_equal(back["path_s"].numpy(), res.path_s[:, :cap])
     assert np.array_equal(back["status"].numpy(), res.status)
+    # trajectory-only records (what a controller-side consumer needs)
+    rec = pack_records(res, col, M, path_cap=cap, fields="trajectory")
+    assert tuple(rec.shape) == (B, 2 + 4 * (cap + 1)) == (B, record_width(col, M, cap, "trajectory"))
+    back = unpack_records(rec, col, M, path_cap=cap, fields="trajectory")
+    assert np.array_equal(back["traj"].numpy(), res.traj[:, :cap + 1]) and np.array_equal(back["traj_len"].numpy(), res.traj_len)
 
 
 def test_graft_entry_build_runs_on_cpu():

@@ -307,3 +307,23 @@ def test_stb_core_speed_qp_and_increase_points(hc):
         assert hc.hc_stb_increase_points(*[ptr(a) for a in prof], *[ptr(a) for a in outs]) == 0
         np.testing.assert_array_equal(outs[3], g["dense_out"][b, 3])
         assert_rel(np.stack(outs[:3]), g["dense_out"][b, :3], 1e-12, scale=1.0)
+
+
+def test_host_logic_under_address_and_undefined_behaviour_sanitizers():
+    """SURVEY.md section 5 (sanitizers): the scalar cores the kernels are built from, compiled with g++
+    -fsanitize=address,undefined and driven with sizes at and beside every capacity, infeasible QPs, NaN / Inf
+    coordinates, repeated points, empty and full obstacle slots (tests/host_check/sanitize_main.cpp).  Any report aborts
+    the program (-fno-sanitize-recover)."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_check")
+    exe = os.path.join(here, "_build", "sanitize_main")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", os.path.join(here, "host_check.cpp"),
+                    os.path.join(here, "sanitize_main.cpp"), "-o", exe], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
+    assert "sanitize_main:" in run.stdout

@@ -18,4 +18,4 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $P -f csv -d $OUT/p$i -o sq -- python $ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed (rc $?)" >> $OUT/failed.txt
 done
-python tools/summarize_sq.py $OUT
+python tools/summarize_sq.py $OUT ${RECORD:-}

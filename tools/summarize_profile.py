@@ -1,10 +1,10 @@
 """Turn gpurun_out/prof_<TAG>/ (written by tools/profile.sh on the GPU box) into the tracked evidence under
 profiles/: the rocprofv3 --kernel-trace --stats table, the per-kernel PMC means (FETCH_SIZE / WRITE_SIZE, each
-from its own pass) and profiles/traffic.json, which bench.py reads for roofline.traffic.
+from its own pass) and the dp_sweep_traffic entry of profiles/counters.json, which bench.py reads for roofline.traffic.
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on
 gfx950 counts 128-B requests as 64 B for wide coalesced streaming reads, so read bytes = 2 x FETCH_SIZE x 1024;
-WRITE_SIZE is taken as is.  Usage: python tools/summarize_profile.py TAG [scenes_per_gpu]"""
+WRITE_SIZE is taken as is.  Usage: python tools/summarize_profile.py TAG [scenes_per_gpu] [steps] [warmup] [config name]"""
 import collections
 import csv
 import json
@@ -16,6 +16,9 @@ tag = sys.argv[1]
 scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 warmup = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+config = sys.argv[5] if len(sys.argv) > 5 else "cfg2_40x9_8obs"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _counters  # noqa: E402
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -57,11 +60,11 @@ with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
         lines.append(f"| `{k}` | {fs:.0f} | {2 * fs * 1024 / 1e6:.1f} | {ws:.0f} | {ws * 1024 / 1e6:.1f} |")
 sweep = next((k for k in pmc if k.startswith("dp_sweep_kernel")), None)
 if sweep:
-    t = {"tag": tag, "kernel": "dp_sweep", "scenes_per_gpu": scenes,
+    t = {"config": config, "scenes_per_gpu": scenes,
          "hbm_bytes_per_launch": int(2 * pmc[sweep].get("FETCH_SIZE", 0) * 1024 + pmc[sweep].get("WRITE_SIZE", 0) * 1024),
-         "method": "2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (KiB counters; gfx950 FETCH_SIZE counts 128-B requests as 64 B)"}
-    json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-    lines += ["", f"dp_sweep HBM traffic per launch: {t['hbm_bytes_per_launch'] / 1e6:.1f} MB "
-                  f"(algorithmic {(8 * (9 + 39 * 81) + 4 * 9 * 40 + 4 * 40) * scenes / 1e6:.1f} MB)"]
+         "source": f"profiles/{tag}_pmc.csv: 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 of {sweep} (KiB counters, separate rocprofv3 "
+                   f"--pmc passes; gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md)"}
+    _counters.upsert("dp_sweep_traffic", t, ("config", "scenes_per_gpu"))
+    lines += ["", f"dp_sweep HBM traffic per launch: {t['hbm_bytes_per_launch'] / 1e6:.1f} MB"]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

@@ -11,6 +11,8 @@ import os
 import sys
 
 root = sys.argv[1]
+# optional: TAG CONFIG SCENES SCENE_DIST -> copy the summary to profiles/<TAG>_sq.csv and record the edge kernel's counters
+record = sys.argv[2:6] if len(sys.argv) >= 6 else None
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 dur = collections.defaultdict(list)
@@ -36,3 +38,20 @@ with open(os.path.join(root, "summary.csv"), "w") as f:
         d = sum(dur[k]) / len(dur[k]) if dur.get(k) else float("nan")
         f.write(",".join([k.replace(",", ";"), str(n), f"{d:.2f}", *meta[k]] + [f"{v.get(c, float('nan')):.6g}" for c in names] + [la, ipw]) + "\n")
 print(open(os.path.join(root, "summary.csv")).read())
+if record:
+    import shutil
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _counters
+    tag, config, scenes, scene_dist = record
+    dst = os.path.join(_counters.ROOT, "profiles", f"{tag}_sq.csv")
+    shutil.copy(os.path.join(root, "summary.csv"), dst)
+    for k in sorted(agg):
+        if k.startswith("dp_edge_kernel"):
+            v = {c: sum(x) / len(x) for c, x in agg[k].items()}
+            _counters.upsert("dp_edge_counters", {
+                "config": config, "scenes_per_gpu": int(scenes), "scene_dist": scene_dist,
+                "insts_valu": int(v["SQ_INSTS_VALU"]), "insts_salu": int(v["SQ_INSTS_SALU"]),
+                "valu_busy_quad_cycles": int(v["SQ_ACTIVE_INST_VALU"]),
+                "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
+                "source": f"profiles/{tag}_sq.csv (rocprofv3 --pmc SQ passes of bench.py --no-pipeline, tools/pmc_sq.sh)"},
+                ("config", "scenes_per_gpu", "scene_dist"))
