@@ -9,6 +9,7 @@ import numpy as np
 
 from ..api import mpc_params
 from ..planner._runtime import planner
+from ..planner.vehicle_state import planar_state
 
 
 class Lateral_MPC_controller(object):
@@ -25,21 +26,10 @@ class Lateral_MPC_controller(object):
         self.x_pre = self.y_pre = self.x_pro = self.y_pro = 0
 
     def cal_vehicle_info(self):
-        """:90-113 - state from the (duck-typed) vehicle; |Vx| is kept >= 0.005 as in the reference."""
-        loc = self._vehicle.get_location()
-        x, y = loc.x, loc.y
-        fi = self._vehicle.get_transform().rotation.yaw * (math.pi / 180)
-        V = self._vehicle.get_velocity()
-        V_length = math.sqrt(V.x * V.x + V.y * V.y + V.z * V.z)
-        beta = math.atan2(V.y, V.x) - fi
-        Vy = V_length * math.sin(beta)
-        if V_length * math.cos(beta) < 0:
-            Vx = -max(abs(V_length * math.cos(beta)), 0.005)
-        else:
-            Vx = max(V_length * math.cos(beta), 0.005)
-        fi_dao = self._vehicle.get_angular_velocity().z * (math.pi / 180)
-        self._vehicle_state = (x, y, fi, Vy, fi_dao)
-        self._vehicle_Vx = Vx
+        """:90-113 - the longitudinal speed keeps its sign but never drops below 0.005 in magnitude (the model divides by it)."""
+        st = planar_state(self._vehicle)
+        self._vehicle_state = (st.x, st.y, st.yaw, st.v_lat, st.yaw_rate)
+        self._vehicle_Vx = math.copysign(max(abs(st.v_long), 0.005), st.v_long) if st.v_long != 0 else 0.005
 
     def _control(self):
         """:313-337 - returns the first control of the horizon (the raw steering command)."""
@@ -76,18 +66,10 @@ class Lateral_LQR_controller(object):
         self.x_pre = self.y_pre = self.x_pro = self.y_pro = 0
 
     def cal_vehicle_info(self):
-        """:405-422 - no clamp on Vx here (cal_A_B_fun adds 0.0001 instead, :439)."""
-        loc = self._vehicle.get_location()
-        x, y = loc.x, loc.y
-        fi = self._vehicle.get_transform().rotation.yaw * (math.pi / 180)
-        V = self._vehicle.get_velocity()
-        V_length = math.sqrt(V.x * V.x + V.y * V.y + V.z * V.z)
-        beta = math.atan2(V.y, V.x) - fi
-        Vy = V_length * math.sin(beta)
-        Vx = V_length * math.cos(beta)
-        fi_dao = self._vehicle.get_angular_velocity().z * (math.pi / 180)
-        self._vehicle_state = (x, y, fi, Vy, fi_dao)
-        self._vehicle_Vx = Vx
+        """:405-422 - no clamp on the longitudinal speed here (cal_A_B_fun adds 0.0001 instead, :439)."""
+        st = planar_state(self._vehicle)
+        self._vehicle_state = (st.x, st.y, st.yaw, st.v_lat, st.yaw_rate)
+        self._vehicle_Vx = st.v_long
 
     def _control(self):
         """:585-611 - the raw steering command -K e_rr + delta_f."""

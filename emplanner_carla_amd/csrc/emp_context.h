@@ -63,9 +63,12 @@ inline int fail(emp_ctx* ctx, int code, const std::string& msg) {
 #define EMP_HIP(ctx, call)                                                                         \
     do {                                                                                           \
         hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return emp::fail((ctx), EMP_ERR_HIP,                                                   \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError(); /* the runtime keeps the error for the next hipGetLastError(): without this, \
+                                        the launch check of the NEXT call would report this call's failure */ \
+            return emp::fail((ctx), e_ == hipErrorOutOfMemory ? EMP_ERR_NOMEM : EMP_ERR_HIP,       \
                              std::string(#call) + ": " + hipGetErrorString(e_));                   \
+        }                                                                                          \
     } while (0)
 
 #define EMP_REQUIRE(ctx, cond, msg)                                                               \

@@ -13,6 +13,7 @@ import numpy as np
 from .. import _lib as L
 from ..api import smooth_params
 from ._runtime import f64, line_array, planner, xy_array
+from .vehicle_state import planar_state
 
 
 # ---- CARLA-bound helpers (host glue only: attribute access and list building) ------------------
@@ -31,19 +32,11 @@ def waypoint_list_2_target_path(pathway):
 
 
 def predict_block(ego_vehicle, ts=0.1):
-    """ref :591-614 - constant-velocity / yaw-rate prediction from a carla.Vehicle."""
-    loc = ego_vehicle.get_location()
-    x, y = loc.x, loc.y
-    fi = ego_vehicle.get_transform().rotation.yaw * (math.pi / 180)
-    V = ego_vehicle.get_velocity()
-    V_length = math.sqrt(V.x * V.x + V.y * V.y + V.z * V.z)
-    beta = math.atan2(V.y, V.x) - fi
-    V_y = V_length * math.sin(beta)
-    V_x = V_length * math.cos(beta)
-    x = x + V_x * ts * math.cos(fi) - V_y * ts * math.sin(fi)
-    y = y + V_y * ts * math.cos(fi) + V_x * ts * math.sin(fi)
-    fi = fi + ego_vehicle.get_angular_velocity().z * (math.pi / 180) * ts
-    return x, y, fi
+    """ref :591-614 - where the vehicle is ``ts`` seconds from now at constant body-frame velocity and yaw rate."""
+    st = planar_state(ego_vehicle)
+    c, s_ = math.cos(st.yaw), math.sin(st.yaw)
+    return (st.x + st.v_long * ts * c - st.v_lat * ts * s_, st.y + st.v_lat * ts * c + st.v_long * ts * s_,
+            st.yaw + st.yaw_rate * ts)
 
 
 def predict_block_based_on_frenet(vehicle_loc, vehicle_velocity, local_frenet_path_opt, cur_path_s, cur_path_l, ts=0.1):
