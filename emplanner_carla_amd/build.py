@@ -43,7 +43,7 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc()] + FLAGS + os.environ.get("EMP_EXTRA_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

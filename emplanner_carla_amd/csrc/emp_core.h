@@ -18,6 +18,17 @@
 #define EMP_HD inline
 #endif
 
+// Wavefront priorities (s_setprio, 0..3) of the kernels that share the SIMDs when two batches are in flight.
+#ifndef EMP_PRIO_BACK
+#define EMP_PRIO_BACK 3      // path QP, Cartesian tail
+#endif
+#ifndef EMP_PRIO_FRONT
+#define EMP_PRIO_FRONT 0     // projection, edge costs
+#endif
+#ifndef EMP_PRIO_SWEEP
+#define EMP_PRIO_SWEEP 3     // min-plus sweep
+#endif
+
 namespace emp {
 
 constexpr int kSamples = 10;          // ref: path_planning.py:486-493 (10 samples per lattice edge)

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __r
                                                       double* __restrict__ start_cost,
                                                       double* __restrict__ edge, int cols_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __builtin_amdgcn_s_setprio(EMP_PRIO_FRONT);
     const int row = P.row, rr = P.row * P.row;
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
     // One wavefront per tile, ~75 instructions per column between two waits for HBM: with two batches in flight it shares
     // its SIMD with the previous batch's path-QP / Cartesian wavefronts, which raise their priority to 3; at priority 0
     // every one of its short bursts queued behind them and the stream slowed from 20.5 to 22.5-25 us.
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(EMP_PRIO_SWEEP);
     const int row = ROW > 0 ? ROW : P.row;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* cost_lds = reinterpret_cast<double*>(pre_lds);

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     const double* __restrict__ start_a, const double* __restrict__ obs_xy, const int* __restrict__ n_obs,
     double* __restrict__ s_map, double* __restrict__ obs_s, double* __restrict__ obs_l, double* __restrict__ begin_sl,
     double* __restrict__ start, int obs_cap, const double* __restrict__ dyn, int* __restrict__ n_obs_out) {
+    __builtin_amdgcn_s_setprio(EMP_PRIO_FRONT);
     // obs_xy rows hold max_obs slots, obs_s / obs_l rows obs_cap >= max_obs (+3 when `dyn` is given: the virtual
     // obstacles of test_9.py:137-169 are appended behind the projected ones and n_obs_out gets the total)
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(64) EMP_QP_OCC void cycle_qp_wave_kernel(int B, int
                                                            double* __restrict__ path_s, double* __restrict__ path_l,
                                                            int* __restrict__ path_len, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
-    __builtin_amdgcn_s_setprio(3);     // a chain of dependent instructions: issue ahead of bulk work sharing the SIMD
+    __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);     // wavefront priority of the back stage, see emp_context.h
     constexpr int GPW = 64 / G;                                   // groups (scenes) per wavefront
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
     const int b = blockIdx.x * GPW + grp;
@@ -691,7 +692,7 @@ __device__ __forceinline__ void cycle_cartesian_body(
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
     double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __builtin_amdgcn_s_setprio(3);          // as in the path QP kernel
+    __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);          // as in the path QP kernel
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     double* sm = lds;                       // [max_ref]
     double* txy = sm + max_ref;             // [cap][2] interleaved x, y
