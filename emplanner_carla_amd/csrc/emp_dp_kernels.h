@@ -91,12 +91,12 @@ __device__ __forceinline__ double soft_cost_quotient(double d2) {
 // consecutive samples are `stride` doubles apart.  Against the nested form with the early break (one LDS read, one
 // wait and two exec-mask regions per sample, each nested in the previous one) this issues 3 % more vector
 // instructions and 45 % fewer scalar ones, and the kernel went from 175 to 157 us (profiles/r02_edge_variants.md).
-__device__ __forceinline__ double obstacle_scan_dense(const double (&sn)[kSamples], const double* l_n, int stride,
+__device__ __forceinline__ double obstacle_scan_dense(double s0, const double* t_smp, const double* l_n, int stride,
                                                       double os, double ol, double w_coll) {
     double d2[kSamples];
 #pragma unroll
     for (int n = 0; n < kSamples; ++n) {
-        const double d_lon = os - sn[n];
+        const double d_lon = os - (s0 + t_smp[n]);            // the sample abscissa, ref :493/:566 (rebuilt, not kept: registers)
         const double d_lat = ol - l_n[n * stride];
         d2[n] = d_lon * d_lon + d_lat * d_lat;
     }
@@ -135,14 +135,12 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
     const int row = P.row, rr = P.row * P.row;
     const int nmask = min(nob, 64);
     const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
-    double sn[kSamples];
-#pragma unroll
-    for (int n = 0; n < kSamples; ++n) sn[n] = s0 + t_smp[n];
+    const double s9 = s0 + t_smp[kSamples - 1];
     // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
     unsigned long long near_s = 0;
     for (int m = 0; m < nmask; ++m) {
         const double os = my_obs_s[m];
-        if (os > s0 - 6.5 && os < sn[kSamples - 1] + 6.5) near_s |= 1ull << m;
+        if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= 1ull << m;
     }
     for (int k = 0; k < row; ++k) {
         const int p = k * row + i;
@@ -154,7 +152,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         double S_d3 = 0.0;
 #pragma unroll
         for (int n = 0; n < kSamples; ++n) {
-            const double d3 = jerk_quirk_at(jq, sn[n]);
+            const double d3 = jerk_quirk_at(jq, s0 + t_smp[n]);
             S_d3 = S_d3 + d3 * d3;
         }
         const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
@@ -163,13 +161,13 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         for (unsigned long long rest = near_s; rest; rest &= rest - 1) {   // ascending m, as the reference
             const int m = __ffsll((long long)rest) - 1;
             const double os = my_obs_s[m], ol = my_obs_l[m];
-            if (!obstacle_box_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;   // contributes exactly 0
-            coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
+            if (!obstacle_box_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;   // contributes exactly 0
+            coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
         }
         for (int m = 64; m < nob; ++m) {                                  // beyond the mask: full test per edge
             const double os = my_obs_s[m], ol = my_obs_l[m];
-            if (!obstacle_in_reach(os, ol, s0, sn[kSamples - 1], l_lo, l_hi)) continue;
-            coll = coll + obstacle_scan_dense(sn, &tab[p], rr, os, ol, P.w_coll);
+            if (!obstacle_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;
+            coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
         }
         store(k, (smooth + coll) + tab[(kSamples + 4) * rr + p]);
     }
@@ -178,7 +176,10 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
 // grid = (tiles, column chunks), block = 256.  Dynamic LDS: the pair table (copied from `pair_tab`),
 // followed by the tile's obstacles [S][max_obs] x2 doubles and the sample offsets.
 template <bool TILED>
-__global__ __launch_bounds__(256) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
+// Five wavefronts per SIMD (at most 102 registers; 94 used, nothing spilled - the sample abscissae are rebuilt from
+// s0 + t_n where they are needed instead of living in twenty registers): alone the kernel takes the same 158 us as with
+// four, with a second batch's path-QP wavefronts on the SIMDs it gets a slot more (0.348 -> 0.340 ms per step).
+__global__ __launch_bounds__(256, 5) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
                                                       const double* __restrict__ obs_s,
                                                       const double* __restrict__ obs_l,
                                                       const int* __restrict__ n_obs,
