@@ -28,3 +28,35 @@ def test_bench_line(extra):
     assert d["value"] > 1e6 and 0.3 < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
     assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else 2)
+
+
+@pytest.mark.parametrize("extra,metric_part", [
+    (("--latency",), "latency"),
+    (("--config", "cfg5", "--scenes-per-gpu", "96"), "120x21"),
+    (("--scene-dist", "survey", "--scenes-per-gpu", "512"), "40x9"),
+    (("--scene-dist", "worst", "--scenes-per-gpu", "512"), "40x9"),
+    (("--dp-mode", "fused", "--scenes-per-gpu", "512"), "40x9"),
+    (("--force-gather-path", "--records", "trajectory", "--gather", "all", "--scenes-per-gpu", "512"), "40x9"),
+], ids=["latency", "cfg5", "survey", "worst", "fused", "gather_all_trajectory"])
+def test_other_bench_lines(extra, metric_part):
+    """The other lines bench.py can print (BASELINE configs[1] and [4], the survey's and the worst-case scene layouts, the
+    fused DP, the all-gather / trajectory-only exchange): each runs and carries the contract's keys."""
+    d = _run(*extra)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert metric_part in d["metric"] and d["value"] > 0 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    if "--latency" in extra:
+        assert d["higher_is_better"] is False and d["roofline"] is None and 0.05 < d["value"] < 5.0
+        return
+    assert d["higher_is_better"] is True and "fully_planned_cycles_per_s" in d
+    if "fused" in extra:
+        assert d["roofline"] is None and "dp_fused" in d["kernels_ms"]
+    else:
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0.01
+    if "cfg5" in extra:
+        assert "speed_dp" in d["kernels_ms"] and d["config"]["lattice"] == "col=120 x row=21"
+    if "worst" in extra:
+        assert d["scenes_fully_planned_frac"] > 0.9
+    if "--gather" in extra:
+        assert d["gather"]["mode"] == "all" and d["gather"]["doubles_per_scene"] == 94 and d["gather"]["records_complete_on_rank0"]
