@@ -1,0 +1,15 @@
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/r02
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err
+python bench.py --no-pipeline --no-cpu-baseline > gpurun_out/r02/bench_one_batch.json 2>/dev/null
+python bench.py --force-gather-path --no-cpu-baseline > gpurun_out/r02/bench_gather_path.json 2>/dev/null
+python bench.py --force-gather-path --records trajectory --no-cpu-baseline > gpurun_out/r02/bench_gather_path_trajectory.json 2>/dev/null
+python bench.py --scenes-per-gpu 32768 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/r02/bench_32768.json 2>/dev/null
+python bench.py --scene-dist survey --cpu-pool 0 --cpu-sample 24 > gpurun_out/r02/bench_survey.json 2>/dev/null
+python bench.py --scene-dist worst --cpu-pool 0 --cpu-sample 24 > gpurun_out/r02/bench_worst.json 2>/dev/null
+python bench.py --config cfg5 --steps 20 --warmup 3 > gpurun_out/r02/bench_cfg5.json 2> gpurun_out/r02/bench_cfg5.err
+rm -rf gpurun_out/prof_r02a gpurun_out/sq_r02a
+STEPS=100 WARMUP=10 bash tools/profile.sh r02a > gpurun_out/r02/profile_r02a.log 2>&1
+bash tools/pmc_sq.sh r02a > gpurun_out/r02/sq_r02a.log 2>&1
+for f in gpurun_out/r02/bench_*.json; do echo "$f: $(cut -c1-200 $f)"; done
