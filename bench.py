@@ -13,7 +13,7 @@ configs[2] on one GPU (4096 scenes, 40x9 lattice, 8 obstacles) and configs[3] ac
 
 Other lines (one JSON line per invocation, same keys):
     --config cfg5      BASELINE configs[4]: 120x21 lattice, 16 obstacles, full cycle + the S-T speed DP (40x16 grid, 16
-                       dynamic-obstacle slots; reference speed_planning_test.py:38-188) per scene, 1024 scenes per GPU
+                       dynamic-obstacle slots; reference speed_planning_test.py:38-188) per scene, 4096 scenes per GPU
     --latency          BASELINE configs[1]: ONE scene on the 40x9 lattice, synchronous calls (metric: ms per cycle)
     --scene-dist X     obstacle layout of the synthetic scenes: corridor (default, emplanner_carla_amd/scenes.py), survey
                        (s_k = 12 + 11 k +- 2, l_k = +-U(2.5, 5)), worst (all obstacles within reach
@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["cfg2", "cfg5"], default="cfg2", help="cfg2 = BASELINE configs[2]/[3] (default); cfg5 = configs[4]")
-    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="default 4096 (cfg2) / 1024 (cfg5)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0, help="default 4096")
     ap.add_argument("--scene-dist", choices=["corridor", "survey", "worst"], default="corridor")
     ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
@@ -242,7 +242,7 @@ def main():
 
     wide = args.config == "cfg5"
     cfg = S.CFG5 if wide else S.CFG2
-    B = args.scenes_per_gpu or (1024 if wide else 4096)
+    B = args.scenes_per_gpu or 4096
     total = B * world
     start, count = emp_dist.shard_range(total, rank, world)
     batch = S.make_batch(range(start, start + count), cfg, dist=args.scene_dist)
