@@ -341,6 +341,177 @@ struct RangeQp {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Dual active-set solver (Goldfarb & Idnani 1983) for the banded range QP - scalar form.
+// ---------------------------------------------------------------------------------------------
+// The interior-point solver above spends 6-19 factorisations on a path QP whose solution has two or three active
+// rows.  The Hessian P does not depend on the iterate, so ONE factorisation P = U'U serves the whole solve: start at
+// the unconstrained minimiser, and while some row is violated add the most violated one to the active set by a step
+// that keeps every active row active and the multipliers non-negative (dropping the row whose multiplier reaches zero
+// first).  In the coordinates y = U u the objective is |y|^2 / 2 + ..., the active normals n~ = U^-T n are kept
+// through an orthonormal basis Q1 and a triangular R (Q1 R = [n~_a]); a step needs one forward substitution (n~_p),
+// k dot products, one back substitution (the step in u) - against a banded factorisation and two full solves per
+// interior-point iteration - and the method ends after (rows added + rows dropped) steps with the exact minimiser,
+// or proves infeasibility when a violated row can be neither reached nor traded (returns 1).
+// Row id = (station * F + form) * 2 + side: side 0 is the upper bound c + g u <= hi, side 1 the lower bound.
+// `M` must hold the band factor of P (band_chol) and `u` the unconstrained minimiser.  work: gi_words(N) doubles.
+// Where it is used: as the second, independent solver the host tests hold the interior point against
+// (tests/test_host_logic.py, `solver="gi"`); the kernels keep the interior point.  The wave-parallel form of this
+// solver (tools/experiments/path_qp_dual_active_set_wave_r02.diff.txt) passed every GPU test but lost on the clock:
+// its dependent chain per step (substitution sweep, k reductions, k-step triangular solve, sweep back) is as long as an
+// interior-point iteration's, its slowest benchmark scene takes 20 steps, and Q1/R cost 31 KB of LDS per wavefront.
+constexpr double kGiTolViolation = 1e-10;     // a row counts as violated below -1e-10 (metres)
+constexpr double kGiTolRank = 1e-12;          // |z~|^2 <= 1e-12 |n~|^2: the row's normal lies in the span of the active ones
+EMP_HD constexpr int gi_words(int N) { return 2 * N * N + 8 * N; }
+
+template <int KD>
+EMP_HD void band_fwd(const double* uf, double* x, int n) {     // U' y = b
+    constexpr int W = KD + 1;
+    for (int i = 0; i < n; ++i) {
+        double sum = x[i];
+        const int k0 = (i - KD > 0) ? i - KD : 0;
+        for (int k = k0; k < i; ++k) sum -= uf[k * W + (i - k)] * x[k];
+        x[i] = sum / uf[i * W];
+    }
+}
+template <int KD>
+EMP_HD void band_bwd(const double* uf, double* x, int n) {     // U x = y
+    constexpr int W = KD + 1;
+    for (int i = n - 1; i >= 0; --i) {
+        double sum = x[i];
+        for (int d = 1; d <= KD && i + d < n; ++d) sum -= uf[i * W + d] * x[i + d];
+        x[i] = sum / uf[i * W];
+    }
+}
+
+template <int KD, int F, int W>
+EMP_HD int range_qp_gi_scalar(RangeQp<KD, F, W>& Q, double* work, int iter_cap = 0) {
+    const int N = Q.N, ns = Q.ns;
+    Q.iters = 0;
+    if (N <= 0) return 0;
+    double* Qm = work;                 // [N][N]  column a of Q1 at Qm[a*N ..]
+    double* R = Qm + N * N;            // [N][N]  R[i*N + j], upper triangular
+    double* lam = R + N * N;           // [N]
+    double* nt = lam + N;              // n~_p
+    double* zt = nt + N;               // (I - Q1 Q1') n~_p
+    double* dv = zt + N;               // Q1' n~_p
+    double* rv = dv + N;               // R^-1 d
+    double* zu = rv + N;               // step in u
+    double* idsd = zu + N;             // [N] active row ids (as doubles: one storage class)
+    double* spare = idsd + N;
+    (void)spare;
+    const int cap = iter_cap > 0 ? iter_cap : 4 * N + 2 * ns * F + 20;
+    int k = 0;
+    auto slack = [&](int id) {
+        const int side = id & 1, tf = id >> 1, t = tf / F, f = tf - t * F;
+        const double v = Q.c[tf] + Q.form_val(t, f, Q.u);
+        return side == 0 ? Q.hi[tf] - v : v - Q.lo[tf];
+    };
+    auto is_active = [&](int id) {
+        for (int a = 0; a < k; ++a)
+            if ((int)idsd[a] == id) return true;
+        return false;
+    };
+    for (;;) {
+        // ---- the most violated row that is not active
+        int p = -1;
+        double worst = -kGiTolViolation;
+        for (int id = 0; id < ns * F * 2; ++id) {
+            const double sl = slack(id);
+            if (sl < worst && !is_active(id)) {
+                worst = sl;
+                p = id;
+            }
+        }
+        if (p < 0) return 0;                                   // every row holds: u is the minimiser
+        // n~_p = U^-T n_p with n_p = +-g on the row's window (as inequality n'u >= b)
+        const int side = p & 1, tf = p >> 1, t = tf / F, f = tf - t * F;
+        const double sign = side == 0 ? -1.0 : 1.0;
+        for (int m = 0; m < N; ++m) nt[m] = 0.0;
+        for (int w = 0; w < W; ++w) {
+            const int m = t + Q.off0 + w;
+            if (m >= 0 && m < N) nt[m] = sign * Q.g[f][w];
+        }
+        band_fwd<KD>(Q.M, nt, N);
+        double nn = 0.0;
+        for (int m = 0; m < N; ++m) nn += nt[m] * nt[m];
+        double lam_p = 0.0;
+        for (;;) {                                             // partial steps until row p is active (or proves infeasible)
+            if (++Q.iters > cap) return 2;
+            for (int a = 0; a < k; ++a) {
+                double acc = 0.0;
+                for (int m = 0; m < N; ++m) acc += Qm[a * N + m] * nt[m];
+                dv[a] = acc;
+            }
+            double zz = 0.0;
+            for (int m = 0; m < N; ++m) {
+                double v = nt[m];
+                for (int a = 0; a < k; ++a) v -= dv[a] * Qm[a * N + m];
+                zt[m] = v;
+                zz += v * v;
+            }
+            for (int a = k - 1; a >= 0; --a) {                 // r = R^-1 d
+                double acc = dv[a];
+                for (int j = a + 1; j < k; ++j) acc -= R[a * N + j] * rv[j];
+                rv[a] = acc / R[a * N + a];
+            }
+            double t1 = INFINITY;
+            int kd = -1;
+            for (int a = 0; a < k; ++a)
+                if (rv[a] > kGiTolRank) {
+                    const double ta = lam[a] / rv[a];
+                    if (ta < t1) {
+                        t1 = ta;
+                        kd = a;
+                    }
+                }
+            const bool full = zz > kGiTolRank * nn;
+            const double t2 = full ? -slack(p) / zz : INFINITY;
+            if (!(t1 < INFINITY) && !full) return 1;           // the row can be neither reached nor traded: infeasible
+            const double tt = t1 < t2 ? t1 : t2;
+            if (full) {
+                for (int m = 0; m < N; ++m) zu[m] = zt[m];
+                band_bwd<KD>(Q.M, zu, N);
+                for (int m = 0; m < N; ++m) Q.u[m] += tt * zu[m];
+            }
+            for (int a = 0; a < k; ++a) lam[a] -= tt * rv[a];
+            lam_p += tt;
+            if (full && t2 <= t1) {                            // full step: row p joins the active set
+                const double nz = sqrt(zz);
+                for (int m = 0; m < N; ++m) Qm[k * N + m] = zt[m] / nz;
+                for (int a = 0; a < k; ++a) R[a * N + k] = dv[a];
+                R[k * N + k] = nz;
+                idsd[k] = (double)p;
+                lam[k] = lam_p;
+                ++k;
+                break;
+            }
+            // partial step: active row kd leaves; column kd of R goes, Givens rotations restore the triangle
+            for (int a = kd; a + 1 < k; ++a) {
+                idsd[a] = idsd[a + 1];
+                lam[a] = lam[a + 1];
+                for (int i = 0; i < k; ++i) R[i * N + a] = R[i * N + a + 1];
+            }
+            --k;
+            for (int j = kd; j < k; ++j) {
+                const double a0 = R[j * N + j], b0 = R[(j + 1) * N + j];
+                const double hh = sqrt(a0 * a0 + b0 * b0);
+                const double cg = a0 / hh, sg = b0 / hh;
+                for (int col = j; col < k; ++col) {
+                    const double x0 = R[j * N + col], x1 = R[(j + 1) * N + col];
+                    R[j * N + col] = cg * x0 + sg * x1;
+                    R[(j + 1) * N + col] = -sg * x0 + cg * x1;
+                }
+                for (int m = 0; m < N; ++m) {
+                    const double x0 = Qm[j * N + m], x1 = Qm[(j + 1) * N + m];
+                    Qm[j * N + m] = cg * x0 + sg * x1;
+                    Qm[(j + 1) * N + m] = -sg * x0 + cg * x1;
+                }
+            }
+        }
+    }
+}
+
 using PathRangeQp = RangeQp<3, 2, 3>;
 using BoxRangeQp = RangeQp<2, 1, 1>;
 
@@ -450,9 +621,10 @@ EMP_HD constexpr int path_qp_words_pair() { return 36 + PathRangeQp::words_fast(
 EMP_HD constexpr int path_qp_words(int n) { return PathRangeQp::words(n - 4 > 0 ? n - 4 : 0, n - 2 > 0 ? n - 2 : 0) + n + 2; }
 
 // complete scalar path QP on caller storage `mem` (path_qp_words(n) doubles)
+// gi_work != NULL: the dual active-set solver (gi_words(n - 4) doubles) instead of the interior point
 EMP_HD int path_qp_solve_scalar(double* mem, const double* l_min, const double* l_max, int n, double l0, double dl0,
                                 double ddl0, const PathQpParams& prm, double* out_l, double* out_dl, double* out_ddl,
-                                int* iters) {
+                                int* iters, double* gi_work = nullptr) {
     *iters = 0;
     if (n < 4) return 2;
     PathRangeQp Q;
@@ -466,7 +638,7 @@ EMP_HD int path_qp_solve_scalar(double* mem, const double* l_min, const double* 
         if (!band_chol<3>(Q.M, Q.N)) return 2;
         for (int m = 0; m < Q.N; ++m) Q.u[m] = -Q.q[m];
         band_solve<3>(Q.M, Q.u, Q.N);
-        rc = Q.solve_scalar();
+        rc = gi_work ? range_qp_gi_scalar(Q, gi_work) : Q.solve_scalar();
         *iters = Q.iters;
         if (rc) return rc;
         for (int m = 0; m < Q.N; ++m) cc[m + 3] = Q.u[m];

@@ -21,6 +21,8 @@ def load():
     lib.hc_segment_cost.argtypes = [d, d, d, d, d, d, p, p, i, d, d, d, d, d]
     lib.hc_path_qp.restype = i
     lib.hc_path_qp.argtypes = [i, p, p, d, d, d, p, p, p, p, p]
+    lib.hc_path_qp_gi.restype = i
+    lib.hc_path_qp_gi.argtypes = [i, p, p, d, d, d, p, p, p, p, p]
     lib.hc_box_qp.restype = i
     lib.hc_box_qp.argtypes = [i, p, i, d, d, d, d, p, p]
     lib.hc_heading_kappa.restype = None

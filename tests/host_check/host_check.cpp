@@ -26,6 +26,15 @@ int hc_path_qp(int n, const double* l_min, const double* l_max, double l0, doubl
     return path_qp_solve_scalar(mem, l_min, l_max, n, l0, dl0, ddl0, p, out_l, out_dl, out_ddl, iters);
 }
 
+int hc_path_qp_gi(int n, const double* l_min, const double* l_max, double l0, double dl0, double ddl0, const double* prm8,
+                  double* out_l, double* out_dl, double* out_ddl, int* iters) {
+    static double mem[path_qp_words(256)];
+    static double work[gi_words(256)];
+    if (n > 256) return 2;
+    PathQpParams p{prm8[0], prm8[1], prm8[2], prm8[3], prm8[4], prm8[5], prm8[6], prm8[7]};
+    return path_qp_solve_scalar(mem, l_min, l_max, n, l0, dl0, ddl0, p, out_l, out_dl, out_ddl, iters, work);
+}
+
 int hc_box_qp(int m, const double* ref, int stride, double w_smooth, double w_length, double w_ref, double thr,
               double* out, int* iters) {
     static double mem[BoxRangeQp::words(256, 256)];

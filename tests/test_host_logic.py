@@ -25,29 +25,31 @@ def hc():
     return host_check.load()
 
 
-def _path_qp(hc, l_min, l_max, start3, prm=QP_PRM):
+def _path_qp(hc, l_min, l_max, start3, prm=QP_PRM, solver="ipm"):
     n = len(l_min)
     l_min = np.ascontiguousarray(l_min, dtype=np.float64)
     l_max = np.ascontiguousarray(l_max, dtype=np.float64)
     prm = np.ascontiguousarray(prm, dtype=np.float64)
     out = [np.zeros(n) for _ in range(3)]
     it = C.c_int(0)
-    rc = hc.hc_path_qp(n, l_min.ctypes.data, l_max.ctypes.data, *[float(v) for v in start3], prm.ctypes.data,
+    fn = hc.hc_path_qp if solver == "ipm" else hc.hc_path_qp_gi      # interior point / dual active set
+    rc = fn(n, l_min.ctypes.data, l_max.ctypes.data, *[float(v) for v in start3], prm.ctypes.data,
                        out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, C.byref(it))
     return rc, out, it.value
 
 
 @pytest.mark.parametrize("fname", ["cycle_cfg2_40x9_8obs.npz", "cycle_default_6x12_3obs.npz",
                                    "cycle_cfg1_20x5_0obs.npz", "cycle_default_6x12_3obs_t7.npz"])
-def test_bspline_path_qp_matches_reference_formulation(hc, fname):
-    """Banded B-spline IPM == dense solve of the reference's own (H, f, G, h, Aeq, beq)."""
+@pytest.mark.parametrize("solver", ["ipm", "gi"])
+def test_bspline_path_qp_matches_reference_formulation(hc, fname, solver):
+    """Banded B-spline solvers (interior point, dual active set) == dense solve of the reference's own (H, f, G, h, Aeq, beq)."""
     g = load_golden(fname)
     n_ok = 0
     for i in range(len(g["seeds"])):
         if np.isnan(g["l_min"][i, 0]):
             continue
         nq = int(g["n_qp"][i])
-        rc, (l, dl, ddl), iters = _path_qp(hc, g["l_min"][i, :nq], g["l_max"][i, :nq], g["start"][i, 1:])
+        rc, (l, dl, ddl), iters = _path_qp(hc, g["l_min"][i, :nq], g["l_max"][i, :nq], g["start"][i, 1:], solver=solver)
         if g["status"][i] == 4:
             assert rc != 0, "oracle says infeasible, banded solver must not claim success"
             continue
@@ -59,7 +61,8 @@ def test_bspline_path_qp_matches_reference_formulation(hc, fname):
     assert n_ok >= 6
 
 
-def test_path_qp_kkt_certificate_on_random_corridors(hc):
+@pytest.mark.parametrize("solver", ["ipm", "gi"])
+def test_path_qp_kkt_certificate_on_random_corridors(hc, solver):
     """Certificate against the reference's dense formulation on corridors the goldens do not hold."""
     rng = np.random.default_rng(11)
     checked = 0
@@ -75,7 +78,7 @@ def test_path_qp_kkt_certificate_on_random_corridors(hc):
             else:
                 l_min[a:a + w] = rng.uniform(-4.0, -0.5)
         start3 = (rng.uniform(-0.4, 0.4), rng.uniform(-0.05, 0.05), rng.uniform(-0.01, 0.01))
-        rc, (l, dl, ddl), iters = _path_qp(hc, l_min, l_max, start3)
+        rc, (l, dl, ddl), iters = _path_qp(hc, l_min, l_max, start3, solver=solver)
         H, f, G, h, A, b = op.path_qp_matrices(l_min, l_max, *start3)
         ref = qp_dense.solve_qp(H, f, G, h, A, b)
         if ref.status != "optimal":
@@ -90,19 +93,22 @@ def test_path_qp_kkt_certificate_on_random_corridors(hc):
     assert checked >= 20
 
 
-def test_path_qp_rejects_infeasible_and_tiny(hc):
+@pytest.mark.parametrize("solver", ["ipm", "gi"])
+def test_path_qp_rejects_infeasible_and_tiny(hc, solver):
+    import functools
+    _path_qp_s = functools.partial(_path_qp, solver=solver)
     n = 12
-    rc, _, _ = _path_qp(hc, 2.0 * np.ones(n), -2.0 * np.ones(n), (0, 0, 0))       # empty corridor
+    rc, _, _ = _path_qp_s(hc, 2.0 * np.ones(n), -2.0 * np.ones(n), (0, 0, 0))       # empty corridor
     assert rc == 1
-    rc, _, _ = _path_qp(hc, -10 * np.ones(n), 10 * np.ones(n), (9.5, 0.0, 0.0))   # pinned start outside
+    rc, _, _ = _path_qp_s(hc, -10 * np.ones(n), 10 * np.ones(n), (9.5, 0.0, 0.0))   # pinned start outside
     assert rc == 1
     lmax = 10 * np.ones(n)
     lmax[n - 1] = -5.0                               # pinned end (l = 0) above the last stations' upper bound
-    rc, _, _ = _path_qp(hc, -10 * np.ones(n), lmax, (0, 0, 0))
+    rc, _, _ = _path_qp_s(hc, -10 * np.ones(n), lmax, (0, 0, 0))
     assert rc == 1
-    rc, _, _ = _path_qp(hc, -10 * np.ones(3), 10 * np.ones(3), (0, 0, 0))         # n < 4: start/end overlap
+    rc, _, _ = _path_qp_s(hc, -10 * np.ones(3), 10 * np.ones(3), (0, 0, 0))         # n < 4: start/end overlap
     assert rc == 2
-    rc, (l, dl, ddl), _ = _path_qp(hc, -10 * np.ones(4), 10 * np.ones(4), (0.3, 0.01, 0.0))   # n = 4: no freedom
+    rc, (l, dl, ddl), _ = _path_qp_s(hc, -10 * np.ones(4), 10 * np.ones(4), (0.3, 0.01, 0.0))   # n = 4: no freedom
     assert rc == 0 and abs(l[0] - 0.3) < 1e-15 and l[3] == 0.0
 
 
