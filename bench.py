@@ -205,7 +205,12 @@ def main():
     ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="one batch in flight instead of two (emp_set_pipeline off)")
+    ap.add_argument("--pipeline", default="staged", help="emp_set_pipeline mode: 'staged' (default: two batches, back stage of "
+                    "one over the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n "
+                    "lanes (highest throughput, every kernel slower)")
+    ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
+    ap.add_argument("--alt-pipeline", default="3", help="a second timed region in this pipeline mode, reported as "
+                    "'alt_pipeline' next to the headline ('none' to skip; N = 1 only)")
     ap.add_argument("--force-gather-path", action="store_true",
                     help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
     ap.add_argument("--gather", choices=["rank0", "all"], default="rank0",
@@ -262,11 +267,11 @@ def main():
     sdp = speed_dp_params()
     M = max_path_points(p)
     mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
-    # Two batches in flight: the back stage (path QP, Cartesian tail) of step k runs on the planner's second stream
-    # while the front stage (projection, DP) of step k+1 runs on its first (include/emplanner.h, emp_set_pipeline).
-    # Every step is a complete pass over the batch; the K timed steps are all finished at the closing fence.
-    pipelined = not args.no_pipeline
-    pl.set_pipeline(pipelined)
+    # Several batches in flight (include/emplanner.h, emp_set_pipeline).  Every step is a complete pass over the batch;
+    # the K timed steps are all finished at the closing fence.
+    pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
+    pl.set_pipeline(pmode)
+    pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()
 
     gather_path = world > 1 or args.force_gather_path
@@ -278,8 +283,8 @@ def main():
     def step():
         # torch work of a step runs on the planner's own streams, ordered with its kernels without any cross-stream
         # event: output allocation on the first; for N > 1 the records are packed on the stream on which the cycle's
-        # results become complete (the second one when pipelined) and gathered over RCCL on a third stream, so that
-        # the gather of step k overlaps the back stage of step k+1 as well as its front stage.
+        # results become complete (the step's lane when pipelined) and gathered over RCCL on a stream of its own, so that
+        # the gather of step k overlaps the steps behind it.
         with torch.cuda.stream(ts):
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
             if wide:
@@ -311,6 +316,28 @@ def main():
         elapsed = float(el.item())
 
     sweep_ms, sweep_launches = pl.kernel_ms("dp_sweep"), pl.kernel_launches("dp_sweep")
+    # The other pipeline form, as a second, separately reported measurement (same steps, same fences; N = 1 only): the
+    # headline is taken in the form that keeps the sweep's bandwidth, lane mode trades it for throughput.
+    alt = None
+    if world == 1 and not gather_path and args.alt_pipeline != "none" and args.alt_pipeline != args.pipeline:
+        fence()
+        pl.set_timing(False)
+        amode = 0 if args.alt_pipeline == "off" else (1 if args.alt_pipeline == "staged" else int(args.alt_pipeline))
+        pl.set_pipeline(amode)
+        for _ in range(max(args.warmup, 2 * pl.in_flight)):
+            out, res = step()
+        fence()
+        pl.set_timing(True, only="dp_sweep")
+        a0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, res = step()
+        fence()
+        a_el = time.perf_counter() - a0
+        a_sweep = pl.kernel_ms("dp_sweep")
+        alt = {"pipeline": "off" if amode == 0 else "staged" if amode == 1 else f"{amode} lanes", "batches_in_flight": pl.in_flight,
+               "value": round(total * args.steps / a_el, 1), "unit": "planning cycles/s",
+               "ms_per_step": round(a_el / args.steps * 1e3, 4), "sweep_mean_launch_us": round(a_sweep * 1e3, 2)}
+        pl.set_timing(False)
     # Per-kernel breakdown: a separate diagnostic pass AFTER the timed region, every kernel bracketed, one batch in
     # flight (the durations of overlapping kernels would not add up to anything)
     fence()
@@ -358,6 +385,8 @@ def main():
                     "traffic_source": prof["source"] if prof else None,
                     "algorithmic_bytes_per_launch": bytes_dp, "launches_timed": sweep_launches,
                     "mean_launch_us": round(sweep_ms * 1e3, 2)}
+        if alt and alt["sweep_mean_launch_us"] > 0:
+            alt["sweep_roofline_frac"] = round(bytes_dp / (alt["sweep_mean_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         # Secondary figures from the diagnostic pass (event-bracketed kernels; not part of the timed region):
         # the edge-cost kernel against the FP64 vector peak with SURVEY.md 8(d)'s ALGORITHMIC flop count next to what
         # the committed SQ counter profile says was executed (obstacles out of reach are skipped at run time and
@@ -405,11 +434,12 @@ def main():
                        "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
                        "scene_dist": args.scene_dist, "ref_line_points": int(P), "dp_mode": args.dp_mode,
-                       "batches_in_flight": 2 if pipelined else 1,
+                       "batches_in_flight": in_flight, "pipeline": "off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes",
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
             **extra,
             "kernels_ms": kernels,
+            "alt_pipeline": alt,
             "scenes_fully_planned_frac": round(ok_frac, 4),
             "fully_planned_cycles_per_s": round(value * ok_frac, 1),
         }

@@ -12,10 +12,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libemplanner.so")
+# Lane mode (emp_set_pipeline with n >= 2) needs one hardware queue per stream; the HIP runtime reads this variable when it
+# initialises (default 4: lanes would share queues and serialise).  The library sets it too when it is loaded, which is
+# too late if torch has touched the GPU before the first Planner is made - importing this module early is not.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 EMP_HOST, EMP_DEVICE = 0, 1
 EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1
 EMP_DP_FUSED, EMP_DP_TWO_KERNEL = 0, 1
+EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2
@@ -167,7 +172,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 6:
+    if lib.emp_abi_version() != 7:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

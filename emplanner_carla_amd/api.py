@@ -144,7 +144,7 @@ class _Args:
         self.torch = any(_is_torch(x) for x in inputs if x is not None)
         self.keep = []
         self.outs = []               # torch output tensors of this call
-        self.cycle = False           # set by Planner.plan_cycle: the call whose back stage may run on the second stream
+        self.cycle = False           # set by Planner.plan_cycle: the call that runs on a lane of its own when pipelined
         self.planner = planner
         self.same_stream = False
         if self.torch:
@@ -166,7 +166,7 @@ class _Args:
     def done(self):
         """After the library call: torch's current stream waits for the planner's stream, so that reading an output
         tensor from torch code (``.cpu()``, another kernel) sees the finished result.  In pipelined mode the results
-        of a cycle are produced on the planner's second stream: a caller on any OTHER stream waits for it; a caller
+        of a cycle are produced on the lane that ran it: a caller on any OTHER stream waits for it; a caller
         that works on the planner's own streams orders itself (``Planner.torch_result_stream``)."""
         if not (self.torch and self.planner is not None):
             return
@@ -245,8 +245,10 @@ class Planner:
         self._h = h
         self.device_id = int(device_id)
         self._torch_stream = None
-        self._torch_result_stream = None
+        self._torch_lane_streams = {}
         self.pipelined = False
+        self.pipe_mode = 0
+        self.in_flight = 1
         self._inflight = []
         self._cur = None
 
@@ -291,24 +293,30 @@ class Planner:
         """Raw hipStream_t of the context."""
         return self._lib.emp_stream(self._h)
 
-    def set_pipeline(self, enabled: bool):
-        """Two-stage pipelining of consecutive ``plan_cycle`` calls on device tensors (include/emplanner.h,
-        emp_set_pipeline): the path QP / Cartesian tail of one batch overlaps the projection / DP of the next.  The
-        outputs of a cycle are then complete on ``torch_result_stream()``; ``synchronize()`` waits for everything."""
-        self._check(self._lib.emp_set_pipeline(self._h, 1 if enabled else 0))
-        self.pipelined = bool(enabled)
-        self._torch_result_stream = None
-        self._inflight = []                      # emp_set_pipeline has drained both streams
+    def set_pipeline(self, mode=True):
+        """Several batches in flight for consecutive ``plan_cycle`` calls on device tensors (include/emplanner.h,
+        emp_set_pipeline).  ``mode``: False / 0 = off; True / "staged" / 1 = two batches, the back stage (path QP,
+        Cartesian tail) of one overlapping the front stage (projection, DP) of the next; an int n >= 2 = n batches on n
+        lanes (a stream and a pool of temporaries each), whole cycles overlapping freely - the highest throughput.  The
+        outputs of a cycle are then complete on ``torch_result_stream()`` (lane mode: the lane of the LATEST call) and
+        ``synchronize()`` waits for everything."""
+        m = L.EMP_PIPELINE_STAGED if (mode is True or mode == "staged") else max(int(mode), 0)
+        self._check(self._lib.emp_set_pipeline(self._h, m))
+        self.pipe_mode = m
+        self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)
+        self.pipelined = m != 0
+        self._inflight = []                      # emp_set_pipeline has drained every stream
 
     def torch_result_stream(self):
-        """The stream on which a cycle's outputs become complete (the planner's second stream in pipelined mode)."""
+        """The stream on which the latest cycle's outputs become complete (its lane in pipelined mode)."""
         if not self.pipelined:
             return self.torch_stream()
-        if self._torch_result_stream is None:
-            import torch
-            self._torch_result_stream = torch.cuda.ExternalStream(int(self._lib.emp_result_stream(self._h)),
-                                                                  device=torch.device("cuda", self.device_id))
-        return self._torch_result_stream
+        import torch
+        h = int(self._lib.emp_result_stream(self._h))
+        st = self._torch_lane_streams.get(h)
+        if st is None:
+            st = self._torch_lane_streams[h] = torch.cuda.ExternalStream(h, device=torch.device("cuda", self.device_id))
+        return st
 
     def torch_stream(self):
         """The context's stream as a torch stream: ``with torch.cuda.stream(pl.torch_stream()):`` orders torch
@@ -790,12 +798,12 @@ class Planner:
         self._check(self._lib.emp_plan_cycle(self._h, C.byref(p), C.byref(q), C.byref(sp), B, P, mo, M, int(mode),
                                              C.byref(io), a.where))
         if self.pipelined and a.torch:
-            # The outputs of the two calls in flight stay referenced here even if the caller drops them at once:
-            # their memory must not come back from torch's allocator into the next call's outputs while this call's
-            # back stage, or a consumer queued behind it on the result stream, still uses it.  (The call after the
-            # next one waits for this call's back stage before its first kernel.)
+            # The outputs of the calls in flight stay referenced here even if the caller drops them at once: their
+            # memory must not come back from torch's allocator into a later call's outputs while this call, or a
+            # consumer queued behind it on its result stream, still uses it.  (Call k + n runs on this call's lane,
+            # i.e. behind it.)
             self._inflight.append((list(res.values()), a.keep))
-            if len(self._inflight) > 2:
+            if len(self._inflight) > self.in_flight:
                 self._inflight.pop(0)
         return CycleResult(**res)
 

@@ -45,17 +45,18 @@ static size_t tiled_elems(const DpDev& d) { return (size_t)d.tiles * (size_t)(d.
 static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
     const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
     const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
-    emp_ctx::Buf& tb = ctx->named["dp_pair_table"];
+    emp_ctx::PairTable& pt = ctx->pair_tables[ctx->active_lane];
+    emp_ctx::Buf& tb = pt.buf;
     if (tb.bytes < tab_bytes) {
         const int grc = grow_buffer(ctx, tb, tab_bytes);
         if (grc) return grc;
-        ctx->pair_table_valid = false;
+        pt.valid = false;
     }
-    if (!ctx->pair_table_valid || memcmp(key, ctx->pair_table_key, sizeof(key)) != 0) {
+    if (!pt.valid || memcmp(key, pt.key, sizeof(key)) != 0) {
         hipLaunchKernelGGL(dp_pair_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d, (double*)tb.p);
         EMP_LAUNCH_CHECK(ctx);
-        memcpy(ctx->pair_table_key, key, sizeof(key));
-        ctx->pair_table_valid = true;
+        memcpy(pt.key, key, sizeof(key));
+        pt.valid = true;
     }
     *out = (const double*)tb.p;
     return EMP_OK;
@@ -152,11 +153,12 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
 }
 
 // DP_algorithm up to the backtrack.  `edge_scratch` may be NULL: taken from the named scratch.
-// The edge tensor (and the start costs behind it) of the current call.  One per pipeline parity: with two batches in
-// flight the sweep of call k may still read its tensor while the edge kernel of call k+1 writes the other one.
+// The edge tensor (and the start costs behind it) of the current call.  One per stream that runs DP kernels (the main
+// stream, and every lane in LANES mode): the sweep of one call may still read its tensor while the edge kernel of the
+// next call, on another lane, writes its own.
 static int dp_edge_tensor(emp_ctx* ctx, const DpDev& d, double** edge, double** start_cost) {
     const size_t need = (tiled_elems(d) + (size_t)d.B * d.row) * sizeof(double);
-    emp_ctx::Buf& sc = ctx->named[ctx->parity ? "dp_edge_tensor_1" : "dp_edge_tensor_0"];
+    emp_ctx::Buf& sc = ctx->named["dp_edge_tensor_" + std::to_string(ctx->active_lane)];
     const int grc = grow_buffer(ctx, sc, need);
     if (grc) return grc;
     *edge = (double*)sc.p;
@@ -214,6 +216,11 @@ static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
 }  // namespace emp
 
 using namespace emp;
+
+// Lane mode (emp_set_pipeline) needs a hardware queue per stream; the HIP runtime maps all streams of a process onto
+// GPU_MAX_HW_QUEUES queues (default 4) and reads the variable when it initialises.  Set it when the library is loaded
+// unless the process has chosen a value itself.
+__attribute__((constructor)) static void emp_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 
@@ -291,17 +298,20 @@ int emp_create(int device_id, emp_ctx** out) {
 void emp_destroy(emp_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    (void)sync_all(ctx);
     for (auto& b : ctx->pool)
         if (b.p) (void)hipFree(b.p);
-    for (auto& pool : ctx->cycle_pool)
-        for (auto& b : pool)
+    for (auto& ln : ctx->lanes) {
+        for (auto& b : ln.pool)
             if (b.p) (void)hipFree(b.p);
-    if (ctx->ev_front) (void)hipEventDestroy(ctx->ev_front);
-    for (auto& e : ctx->ev_back)
-        if (e) (void)hipEventDestroy(e);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
+        if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
+        if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
+    if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
+    for (auto& kv : ctx->pair_tables)
+        if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
     for (auto& kv : ctx->named)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->events)
@@ -317,8 +327,7 @@ const char* emp_last_error(const emp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int emp_synchronize(emp_ctx* ctx) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    EMP_HIP(ctx, (hipError_t)sync_all(ctx));
     return EMP_OK;
 }
 
@@ -326,7 +335,7 @@ void* emp_stream(emp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 void* emp_result_stream(emp_ctx* ctx) {
     if (!ctx) return nullptr;
-    return (void*)((ctx->pipeline && ctx->stream2) ? ctx->stream2 : ctx->stream);
+    return (void*)ctx->result_stream();
 }
 
 // one thread per record slot; consecutive threads write consecutive doubles
@@ -364,7 +373,7 @@ int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int3
     EMP_REQUIRE(ctx, B >= 0 && col >= 1 && max_pts >= 1 && path_cap >= 1 && path_cap <= max_pts, "bad sizes");
     EMP_REQUIRE(ctx, status && traj_len && path_len && dp_rows && path_s && path_l && traj && rec, "NULL array");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
-    const bool on_rs = on_result_stream && ctx->pipeline && ctx->stream2 && where == EMP_DEVICE;
+    const bool on_rs = on_result_stream && ctx->pipelined() && where == EMP_DEVICE;
     Stage st(ctx, where, on_rs);             // on the result stream the launch is ordered behind the cycle by the stream itself
     int rc;
     const int *d_st, *d_tl, *d_pl;
@@ -384,7 +393,7 @@ int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int3
     if (B) {
         const size_t total = (size_t)B * width;
         hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           on_rs ? ctx->stream2 : ctx->stream, B, col, max_pts, path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll,
+                           on_rs ? ctx->result_stream() : ctx->stream, B, col, max_pts, path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll,
                            d_traj, d_rec);
         EMP_LAUNCH_CHECK(ctx);
     }
@@ -411,7 +420,7 @@ int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_
     EMP_REQUIRE(ctx, B >= 0 && max_pts >= 1 && path_cap >= 1 && path_cap <= max_pts, "bad sizes");
     EMP_REQUIRE(ctx, status && traj_len && traj && rec, "NULL array");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
-    const bool on_rs = on_result_stream && ctx->pipeline && ctx->stream2 && where == EMP_DEVICE;
+    const bool on_rs = on_result_stream && ctx->pipelined() && where == EMP_DEVICE;
     Stage st(ctx, where, on_rs);
     int rc;
     const int *d_st, *d_tl;
@@ -425,29 +434,38 @@ int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_
     if (B) {
         const size_t total = (size_t)B * width;
         hipLaunchKernelGGL(pack_trajectory_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           on_rs ? ctx->stream2 : ctx->stream, B, max_pts, path_cap, d_st, d_tl, d_traj, d_rec);
+                           on_rs ? ctx->result_stream() : ctx->stream, B, max_pts, path_cap, d_st, d_tl, d_traj, d_rec);
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();
 }
 
-int emp_set_pipeline(emp_ctx* ctx, int enabled) {
+int emp_set_pipeline(emp_ctx* ctx, int mode) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, mode <= EMP_PIPELINE_MAX, "at most EMP_PIPELINE_MAX batches in flight");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
-    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
-    if (enabled && !ctx->stream2) {
+    EMP_HIP(ctx, (hipError_t)sync_all(ctx));
+    const int m = mode < 0 ? 0 : mode;
+    const int need = m == EMP_PIPELINE_STAGED ? 2 : m;
+    if ((int)ctx->lanes.size() < need) ctx->lanes.resize(need);
+    for (int i = 0; i < need; ++i) {
+        emp_ctx::Lane& ln = ctx->lanes[i];
+        if (m != EMP_PIPELINE_STAGED && !ln.stream) EMP_HIP(ctx, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        if (!ln.ev_in) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+        if (!ln.ev_front) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
+        if (!ln.ev_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+    }
+    if (m == EMP_PIPELINE_STAGED && !ctx->back_stream) {
         // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
         // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
         // stage's bulk work they overlap with
         int prio_low = 0, prio_high = 0;
         EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_high));
-        EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
-        for (auto& e : ctx->ev_back) EMP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->back_stream, hipStreamNonBlocking, prio_high));
     }
-    ctx->pipeline = enabled != 0;
-    ctx->ev_back_valid[0] = ctx->ev_back_valid[1] = false;
+    for (auto& ln : ctx->lanes) ln.done_valid = false;       // everything was drained above
+    ctx->pipe_mode = m;
+    ctx->lane = 0;
     return EMP_OK;
 }
 
@@ -459,8 +477,7 @@ int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
 }
 int emp_device_free(emp_ctx* ctx, void* ptr) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    EMP_HIP(ctx, (hipError_t)sync_all(ctx));
     EMP_HIP(ctx, hipFree(ptr));
     return EMP_OK;
 }
@@ -1008,23 +1025,39 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     EMP_REQUIRE(ctx, io->traj && io->traj_len && io->status, "traj, traj_len and status are required outputs");
     EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
-    // Pipelined mode (device pointers only): this call's temporaries come from the pool of its parity, which the back
-    // stage of the call before the previous one was the last to read.
-    const bool piped = ctx->pipeline && where == EMP_DEVICE && B > 0;
-    struct PoolSwap {                       // the parity's pool stands in for ctx->pool during this call
+    // Pipelined modes (device pointers only; emp_context.h).  LANES: the whole call runs on the next lane - its stream
+    // stands in for ctx->stream and its pool for ctx->pool - behind whatever the caller has ordered on the main stream so
+    // far.  STAGED: the call takes the pool of the next of two lanes once the back stage that used it last is done; its
+    // front stage runs on the main stream.
+    const int pmode = (where == EMP_DEVICE && B > 0) ? ctx->pipe_mode : 0;
+    const bool piped = pmode != 0, staged = pmode == EMP_PIPELINE_STAGED;
+    struct LaneSwap {
         emp_ctx* c;
-        int par;
-        bool on;
-        PoolSwap(emp_ctx* c_, bool on_) : c(c_), par(0), on(on_) {
-            if (!on) return;
-            par = (c->parity ^= 1);
-            std::swap(c->pool, c->cycle_pool[par]);
+        emp_ctx::Lane* ln = nullptr;
+        hipStream_t main_stream;
+        LaneSwap(emp_ctx* c_, int mode) : c(c_), main_stream(c_->stream) {
+            if (!mode) return;
+            c->lane = (c->lane + 1) % c->lanes_in_use();
+            ln = &c->lanes[c->lane];
+            std::swap(c->pool, ln->pool);
+            if (mode != EMP_PIPELINE_STAGED) {
+                c->active_lane = c->lane;
+                c->stream = ln->stream;
+            }
         }
-        ~PoolSwap() {
-            if (on) std::swap(c->pool, c->cycle_pool[par]);
+        ~LaneSwap() {
+            if (!ln) return;
+            c->stream = main_stream;
+            std::swap(c->pool, ln->pool);
+            c->active_lane = -1;
         }
-    } swap_pool(ctx, piped);
-    if (piped && ctx->ev_back_valid[swap_pool.par]) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_back[swap_pool.par], 0));
+    } lane(ctx, pmode);
+    if (staged) {
+        if (lane.ln->done_valid) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_done, 0));
+    } else if (piped) {
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
+    }
     Stage st(ctx, where, piped);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
     const int *d_nr, *d_no;
@@ -1081,34 +1114,22 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
     if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
     const QpDev Q = make_qp_dev(q);
-    // back stage (densified DP path, path QP, Cartesian tail: short kernels that last as long as their slowest scene):
-    // on the second stream when pipelined, ordered behind this call's front stage only
-    struct StreamSwap {
-        emp_ctx* c;
-        hipStream_t saved;
-        StreamSwap(emp_ctx* c_, bool on) : c(c_), saved(c_->stream) {
-            if (on) c->stream = c->stream2;
-        }
-        ~StreamSwap() { c->stream = saved; }
-    };
-    if (piped) {
-        EMP_HIP(ctx, hipEventRecord(ctx->ev_front, ctx->stream));
-        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_front, 0));
+    if (staged) {      // the back stage (short kernels that last as long as their slowest scene) goes to the back stream
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_front, ctx->stream));
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, lane.ln->ev_front, 0));
+        ctx->stream = ctx->back_stream;        // ~LaneSwap puts the main stream back
     }
-    {
-        StreamSwap back(ctx, piped);
-        if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
-        if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
-                               d_st)))
-            return rc;
-        const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
-        if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
-                                      d_traj, d_tlen, d_st)))
-            return rc;
-        if (piped) {
-            EMP_HIP(ctx, hipEventRecord(ctx->ev_back[swap_pool.par], ctx->stream));
-            ctx->ev_back_valid[swap_pool.par] = true;
-        }
+    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
+    if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
+                           d_st)))
+        return rc;
+    const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
+    if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
+                                  d_traj, d_tlen, d_st)))
+        return rc;
+    if (piped) {
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_done, ctx->stream));
+        lane.ln->done_valid = true;
     }
     return st.finish();
 }

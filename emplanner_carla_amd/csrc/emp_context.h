@@ -27,10 +27,15 @@ struct emp_ctx {
     size_t cursor = 0;
     // persistent named scratch (survives across the staged buffers of one call)
     std::map<std::string, Buf> named;
-    // lattice parameters the "dp_pair_table" scratch was built for (emp_api.hip: dev_dp_edge)
     std::string timing_filter;   // non-empty: only this kernel name is bracketed by events
-    double pair_table_key[8] = {0};
-    bool pair_table_valid = false;
+    // the pair table of the edge-cost kernel and the lattice parameters it was built for (emp_api.hip: dp_pair_table);
+    // one per stream that runs edge kernels (key: active_lane), so that a rebuild never races a reader on another stream
+    struct PairTable {
+        Buf buf;
+        double key[8] = {0};
+        bool valid = false;
+    };
+    std::map<int, PairTable> pair_tables;
     // per-kernel timing
     bool timing = false;
     struct Ev {
@@ -39,16 +44,33 @@ struct emp_ctx {
     };
     std::map<std::string, Ev> events;
     int cu_count = 0;
-    // Two-stage pipelining of consecutive emp_plan_cycle calls (emp_set_pipeline): the back stage (path QP, Cartesian
-    // tail) of call k runs on `stream2` while the front stage (projection, DP) of call k+1 already runs on `stream`.
-    // Each parity has its own pool of temporaries; ev_back[parity] marks the end of the back stage that read them.
-    bool pipeline = false;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_front = nullptr;
-    hipEvent_t ev_back[2] = {nullptr, nullptr};
-    bool ev_back_valid[2] = {false, false};
-    int parity = 0;
-    std::vector<Buf> cycle_pool[2];
+    // Several batches in flight (emp_set_pipeline), two forms.
+    // STAGED (mode 1, two batches): a cycle is a front stage (projection, edge costs, sweep) on `stream` and a back stage
+    // (densified DP path, path QP, Cartesian tail) on `back_stream`; the back stage of call k overlaps the front stage of
+    // call k+1.  The two calls in flight alternate between lanes[0] and lanes[1], of which only the pool of temporaries
+    // and the events are used.  The front stages are serial, so one edge tensor serves every call (it stays in the
+    // Infinity Cache) and the sweep overlaps nothing but the tail of the back stage before it.
+    // LANES (mode n >= 2, n batches): call k runs WHOLE on the stream of lanes[k mod n], with that lane's pool, edge
+    // tensor and pair table, behind everything queued on `stream` when it was issued; the dispatcher overlaps the kernels
+    // of n consecutive cycles wherever it finds room.
+    // ev_in: recorded on `stream` by a LANES call, its lane waits for it.  ev_front: end of a STAGED front stage.
+    // ev_done: end of the lane's latest cycle - what the next user of the lane's pool and every other entry point wait for.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr;
+        bool done_valid = false;
+        std::vector<Buf> pool;
+    };
+    std::vector<Lane> lanes;            // created on demand, kept until emp_destroy
+    hipStream_t back_stream = nullptr;  // STAGED: the back stages (highest queue priority)
+    int pipe_mode = 0;                  // 0 off, 1 STAGED, n >= 2 LANES with n lanes
+    int lane = 0;                       // lane of the latest pipelined cycle call
+    int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
+    bool pipelined() const { return pipe_mode != 0; }
+    int lanes_in_use() const { return pipe_mode == 1 ? 2 : pipe_mode; }
+    hipStream_t result_stream() const {
+        return pipe_mode == 0 ? stream : pipe_mode == 1 ? back_stream : lanes[lane].stream;
+    }
 };
 
 namespace emp {
@@ -76,14 +98,26 @@ inline int fail(emp_ctx* ctx, int code, const std::string& msg) {
         if (!(cond)) return emp::fail((ctx), EMP_ERR_INVALID, std::string(msg));                   \
     } while (0)
 
-// Grow-only device buffer with 25 % headroom.  A buffer is replaced only once nothing queued on either of the context's
-// streams can still touch it: with two batches in flight the back stage of an earlier call may be reading the very
-// temporaries a larger batch now outgrows, and hipFree's own implicit synchronisation is not relied upon.
+// Waits for everything queued on the context's streams (the main one and every lane).
+inline int sync_all(emp_ctx* ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (auto& ln : ctx->lanes) {
+        const hipError_t e2 = ln.stream ? hipStreamSynchronize(ln.stream) : hipSuccess;
+        if (e == hipSuccess) e = e2;
+    }
+    if (ctx->back_stream) {
+        const hipError_t e2 = hipStreamSynchronize(ctx->back_stream);
+        if (e == hipSuccess) e = e2;
+    }
+    return (int)e;
+}
+
+// Grow-only device buffer with 25 % headroom.  A buffer is replaced only once nothing queued on any of the context's
+// streams can still touch it (hipFree's own implicit synchronisation is not relied upon).
 inline int grow_buffer(emp_ctx* ctx, emp_ctx::Buf& b, size_t bytes) {
     if (b.bytes >= bytes) return EMP_OK;
     if (b.p) {
-        EMP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->stream2) EMP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        EMP_HIP(ctx, (hipError_t)sync_all(ctx));
         EMP_HIP(ctx, hipFree(b.p));
     }
     b.p = nullptr;
@@ -109,13 +143,14 @@ inline int pool_get(emp_ctx* ctx, size_t bytes, void** out) {
 // to pool buffers and outputs are copied back in finish().
 class Stage {
   public:
-    // in_cycle: the pipelined emp_plan_cycle orders itself; every OTHER call in pipelined mode first lets the main
-    // stream wait for the back stage still in flight, so that it may consume a cycle's outputs as before
+    // in_cycle: the pipelined emp_plan_cycle (and a launch placed on its lane) orders itself; every OTHER call in
+    // pipelined mode first lets the main stream wait for the cycles still in flight, so that it may consume a cycle's
+    // outputs as before
     Stage(emp_ctx* c, emp_mem where, bool in_cycle = false) : ctx_(c), dev_(where == EMP_DEVICE) {
         c->cursor = 0;
-        if (!in_cycle && c->pipeline)
-            for (int par = 0; par < 2; ++par)
-                if (c->ev_back_valid[par]) (void)hipStreamWaitEvent(c->stream, c->ev_back[par], 0);
+        if (!in_cycle && c->pipelined())
+            for (auto& ln : c->lanes)
+                if (ln.done_valid) (void)hipStreamWaitEvent(c->stream, ln.ev_done, 0);
     }
 
     template <typename T>

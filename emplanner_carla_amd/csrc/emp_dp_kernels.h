@@ -179,6 +179,9 @@ template <bool TILED>
 // Five wavefronts per SIMD (at most 102 registers; 94 used, nothing spilled - the sample abscissae are rebuilt from
 // s0 + t_n where they are needed instead of living in twenty registers): alone the kernel takes the same 158 us as with
 // four, with a second batch's path-QP wavefronts on the SIMDs it gets a slot more (0.348 -> 0.340 ms per step).
+// (Tried with several batches in flight: padding the allocation to 104 registers, so that four wavefronts leave room on
+// a SIMD for a wavefront of the sweep or the Cartesian tail that a fifth edge wavefront cannot take.  The overlapped sweep
+// got 15 % shorter, the edge kernel 3 % longer, and the step longer in every pipeline mode: not kept.)
 __global__ __launch_bounds__(256, 5) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
                                                       const double* __restrict__ obs_s,
                                                       const double* __restrict__ obs_l,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 6
+#define EMP_ABI_VERSION 7
 
 typedef struct emp_ctx emp_ctx;
 
@@ -121,15 +121,30 @@ int emp_set_timing(emp_ctx* ctx, int enabled);
  * pay for bracketing the others. */
 int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
 
-/* Two-stage pipelining of CONSECUTIVE emp_plan_cycle calls with device pointers (off by default).  The cycle is a
- * front stage (projection, S-L DP edge costs and sweep: FP64-issue and HBM bound) and a back stage (densified DP path,
- * path QP, Cartesian tail: bound by the latency of their slowest scene, the GPU mostly idle).  When enabled, the back stage of call k runs on a second
- * stream while the front stage of call k+1 already runs on emp_stream(): two batches are in flight.  Consequences for
- * the caller: the outputs of a call are complete on emp_result_stream() (emp_synchronize waits for both streams); each
- * call in flight needs its OWN output buffers (the next call's front stage writes dp_rows / status while
- * the previous call's back stage still reads its own); the inputs of a call must stay unchanged until its back stage
- * is done.  A third call waits for the first one's back stage.  Results are bit-identical to the unpipelined call. */
-int emp_set_pipeline(emp_ctx* ctx, int enabled);
+/* Several batches in flight: CONSECUTIVE emp_plan_cycle calls with device pointers overlap on the GPU (off by default).
+ * The kernels of a cycle are bound by different things - FP64 issue (edge costs), HBM (sweep), the latency of the slowest
+ * scene's chain of dependent instructions (projection, path QP, Cartesian tail, the chip mostly idle) - so one batch at a
+ * time leaves issue slots empty.  mode:
+ *   0                      off: one cycle at a time on emp_stream().
+ *   EMP_PIPELINE_STAGED    two batches: the back stage (densified DP path, path QP, Cartesian tail) of call k runs on a
+ *                          second stream while the front stage (projection, edge costs, sweep) of call k+1 runs on
+ *                          emp_stream().  The front stages stay serial, so the sweep runs next to nothing but the end
+ *                          of a back stage and keeps its share of the HBM roofline (0.33 ms per 4096-scene step, sweep
+ *                          22 us).
+ *   n = 2..EMP_PIPELINE_MAX  n batches on n lanes (a stream and a pool of temporaries each; ABI version 7): call k runs
+ *                          whole on lane k mod n, behind everything queued on emp_stream() when it is issued, and the
+ *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.285 ms
+ *                          per step) at the price of every kernel's own duration (the sweep: 35-45 us).  Needs as many
+ *                          hardware queues as streams: the library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless
+ *                          the variable is already set (the HIP runtime reads it when it initialises; its default of 4
+ *                          makes lanes share a queue and serialises them).
+ * Consequences for the caller: the outputs of a call are complete on emp_result_stream() - in lane mode the lane of the
+ * LATEST emp_plan_cycle call, so ask after every call - and emp_synchronize waits for every stream; each call in flight
+ * needs its OWN output buffers, and its inputs must stay unchanged until it is done.  Every other entry point first
+ * lets emp_stream() wait for the cycles in flight.  Results are bit-identical to the unpipelined call. */
+#define EMP_PIPELINE_STAGED 1
+#define EMP_PIPELINE_MAX 8
+int emp_set_pipeline(emp_ctx* ctx, int mode);
 void* emp_result_stream(emp_ctx* ctx);
 
 /* One fixed-stride record per scene for the multi-GPU gather (no reference counterpart: the reference plans one scene

@@ -144,6 +144,8 @@ expect(lib.emp_pack_trajectory_records(h, -1, M, M, args[0], args[1], args[6], p
 expect(lib.emp_dp_plan(None, C.byref(p), B, MO, ptr(obs_s), ptr(obs_l), ptr(n_obs), ptr(start), 1, ptr(rows), ptr(mc), ptr(st),
                        L.EMP_HOST), "emp_dp_plan ctx NULL") if False else None   # NULL ctx: message goes to the create slot
 assert lib.emp_synchronize(None) < 0 and lib.emp_set_pipeline(None, 1) < 0
+assert lib.emp_set_pipeline(h, L.EMP_PIPELINE_MAX + 1) < 0 and b"EMP_PIPELINE_MAX" in lib.emp_last_error(h), "too many lanes is an error"
+assert lib.emp_set_pipeline(h, -5) == 0 and lib.emp_set_pipeline(h, 3) == 0 and lib.emp_set_pipeline(h, 0) == 0    # negative = off
 nul = C.c_void_p()
 assert lib.emp_device_alloc(h, C.c_uint64(1 << 62), C.byref(nul)) < 0 and not nul.value, "an impossible allocation is an error"
 assert lib.emp_create(9999, C.byref(nul)) < 0 and lib.emp_last_error(None), "no such device"

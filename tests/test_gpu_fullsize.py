@@ -252,11 +252,15 @@ def test_rigid_motion_of_the_scene_moves_the_plan_with_it(planner):
             assert np.abs(moved_traj).max() < 0.4 * np.sqrt(2) + 1e-6
 
 
-def test_pipelined_cycles_equal_plain_cycles(planner):
-    """emp_set_pipeline: the back stage of one batch overlaps the front stage of the next.  Six DIFFERENT batches in
-    flight one after the other (every other call shares its pool of temporaries) give bit-identical results to the plain
-    calls, whether the caller works on the planner's own stream and reads after a synchronize, or on torch's default
-    stream and reads right away."""
+PIPE_MODES = ["staged", 2, 3, 4]         # emp_set_pipeline: two stages on two streams, or n whole cycles on n lanes
+
+
+@pytest.mark.parametrize("pipe", PIPE_MODES)
+def test_pipelined_cycles_equal_plain_cycles(planner, pipe):
+    """emp_set_pipeline, staged (the back stage of one batch overlaps the front stage of the next) and in lane mode (n
+    whole cycles on n streams).  Six DIFFERENT batches in flight one after the other (calls that share a lane share its
+    pool of temporaries) give bit-identical results to the plain calls, whether the caller works on the planner's own
+    stream and reads after a synchronize, or on torch's default stream and reads right away."""
     import torch
     cfg = S.CFG2
     p, q, sp = _params(cfg)
@@ -271,7 +275,8 @@ def test_pipelined_cycles_equal_plain_cycles(planner):
         r = planner.plan_cycle(p, q, sp, **ins)
         planner.synchronize()
         plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
-    planner.set_pipeline(True)
+    planner.set_pipeline(pipe)
+    assert planner.in_flight == (2 if pipe == "staged" else pipe)
     try:
         with torch.cuda.stream(planner.torch_stream()):                       # the bench's way: no cross-stream waits
             res = [planner.plan_cycle(p, q, sp, **ins) for ins in batches]
@@ -299,10 +304,11 @@ def test_pipelined_cycles_equal_plain_cycles(planner):
         planner.set_pipeline(False)
 
 
-def test_pipelined_records_packed_on_the_result_stream(planner):
-    """What a rank of the multi-GPU bench does per step when two batches are in flight: plan on the planner's first
-    stream, pack the result records on the stream on which the results become complete (the gather follows there).
-    The records of every step equal those of the plain call."""
+@pytest.mark.parametrize("pipe", PIPE_MODES)
+def test_pipelined_records_packed_on_the_result_stream(planner, pipe):
+    """What a rank of the multi-GPU bench does per step when several batches are in flight: plan on the planner's first
+    stream, pack the result records on the stream on which the results become complete (the gather follows there; in
+    lane mode it is a different stream from step to step).  The records of every step equal those of the plain call."""
     import torch
     from emplanner_carla_amd import dist as emp_dist
     from emplanner_carla_amd.api import max_path_points
@@ -320,7 +326,7 @@ def test_pipelined_records_packed_on_the_result_stream(planner):
         r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
         planner.synchronize()
         want.append(emp_dist.pack_records(r, p.col, M).cpu().numpy())
-    planner.set_pipeline(True)
+    planner.set_pipeline(pipe)
     try:
         recs = []
         for ins in batches:
@@ -340,7 +346,8 @@ def test_pipelined_records_packed_on_the_result_stream(planner):
         planner.set_pipeline(False)
 
 
-def test_native_record_packing_equals_the_torch_form(planner):
+@pytest.mark.parametrize("pipe", ["staged", 3])
+def test_native_record_packing_equals_the_torch_form(planner, pipe):
     """emp_pack_records (one launch) against the torch concatenation of emplanner_carla_amd.dist.pack_records, bit for
     bit, full and trimmed records: plain mode from torch's default stream, pipelined mode from the result stream (the
     bench's per-step pattern, the step's outputs dropped at once) and from the default stream."""
@@ -370,7 +377,7 @@ def test_native_record_packing_equals_the_torch_form(planner):
     host = CycleResult(**{k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
     got = emp_dist.pack_records(host, p.col, M, path_cap=emp_dist.path_capacity(M), planner=planner)
     assert isinstance(got, np.ndarray) and same(got, want[-1])
-    planner.set_pipeline(True)
+    planner.set_pipeline(pipe)
     try:
         recs = []
         for ins in batches:
