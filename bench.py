@@ -209,8 +209,9 @@ def main():
                     "one over the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n "
                     "lanes (highest throughput, every kernel slower)")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
-    ap.add_argument("--alt-pipeline", default="3", help="a second timed region in this pipeline mode, reported as "
-                    "'alt_pipeline' next to the headline ('none' to skip; N = 1 only)")
+    ap.add_argument("--alt-pipeline", default="none", help="a second timed region in this pipeline mode (e.g. 3), reported as "
+                    "'alt_pipeline' next to the headline (N = 1 only; off by default so that a profile of the default "
+                    "command holds one mode's launches only)")
     ap.add_argument("--force-gather-path", action="store_true",
                     help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
     ap.add_argument("--gather", choices=["rank0", "all"], default="rank0",

@@ -18,7 +18,8 @@ def _run(*extra):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("extra", [(), ("--no-pipeline",), ("--force-gather-path",), ("--force-gather-path", "--no-pipeline")])
+@pytest.mark.parametrize("extra", [(), ("--no-pipeline",), ("--force-gather-path",), ("--force-gather-path", "--no-pipeline"),
+                                   ("--pipeline", "3"), ("--pipeline", "2", "--force-gather-path"), ("--alt-pipeline", "3")])
 def test_bench_line(extra):
     d = _run(*extra)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -27,7 +28,14 @@ def test_bench_line(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["value"] > 1e6 and 0.3 < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
-    assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else 2)
+    lanes = int(extra[extra.index("--pipeline") + 1]) if "--pipeline" in extra else 0
+    assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else lanes or 2)
+    assert d["config"]["pipeline"] == ("off" if "--no-pipeline" in extra else f"{lanes} lanes" if lanes else "staged")
+    if "--alt-pipeline" in extra:      # the second timed region, in lane mode
+        alt = d["alt_pipeline"]
+        assert alt["pipeline"] == "3 lanes" and alt["value"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
+    else:
+        assert d["alt_pipeline"] is None
 
 
 @pytest.mark.parametrize("extra,metric_part", [

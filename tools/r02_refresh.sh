@@ -2,7 +2,11 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/r02
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err
+python bench.py --alt-pipeline 3 --no-cpu-baseline > gpurun_out/r02/bench_default_and_lanes3.json 2>/dev/null
 python bench.py --no-pipeline --no-cpu-baseline > gpurun_out/r02/bench_one_batch.json 2>/dev/null
+for n in 2 3 4; do python bench.py --pipeline $n --no-cpu-baseline > gpurun_out/r02/bench_lanes$n.json 2>/dev/null; done
+python bench.py --dp-mode fused --no-cpu-baseline > gpurun_out/r02/bench_fused.json 2>/dev/null
+python bench.py --latency > gpurun_out/r02/bench_latency.json 2>/dev/null
 python bench.py --force-gather-path --no-cpu-baseline > gpurun_out/r02/bench_gather_path.json 2>/dev/null
 python bench.py --force-gather-path --records trajectory --no-cpu-baseline > gpurun_out/r02/bench_gather_path_trajectory.json 2>/dev/null
 python bench.py --scenes-per-gpu 32768 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/r02/bench_32768.json 2>/dev/null
