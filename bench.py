@@ -205,9 +205,10 @@ def main():
     ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", default="staged", help="emp_set_pipeline mode: 'staged' (default: two batches, back stage of "
-                    "one over the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n "
-                    "lanes (highest throughput, every kernel slower)")
+    ap.add_argument("--pipeline", default="auto", help="emp_set_pipeline mode: 'staged' (two batches, back stage of one over "
+                    "the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n lanes "
+                    "(highest throughput, every kernel slower); 'auto' (default) = staged for cfg2, 2 lanes for cfg5 (whose "
+                    "S-T kernels run on the main stream beside the cycles on the lanes)")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
     ap.add_argument("--alt-pipeline", default="none", help="a second timed region in this pipeline mode (e.g. 3), reported as "
                     "'alt_pipeline' next to the headline (N = 1 only; off by default so that a profile of the default "
@@ -270,6 +271,8 @@ def main():
     mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
     # Several batches in flight (include/emplanner.h, emp_set_pipeline).  Every step is a complete pass over the batch;
     # the K timed steps are all finished at the closing fence.
+    if args.pipeline == "auto":
+        args.pipeline = "2" if wide else "staged"
     pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
     pl.set_pipeline(pmode)
     pipelined, in_flight = pl.pipelined, pl.in_flight
@@ -288,9 +291,11 @@ def main():
         # the gather of step k overlaps the steps behind it.
         with torch.cuda.stream(ts):
             res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
-            if wide:
+            if wide:      # the S-T half reads nothing of the cycle: it need not wait for the cycles in flight
+                pl.set_fence(False)
                 sets = pl.st_graph(*st_inputs[0])
                 pl.speed_dp(sdp, *sets, st_inputs[1], tables=False)
+                pl.set_fence(True)
         return sg.submit(res) if gather_path else res, res
 
     def fence():

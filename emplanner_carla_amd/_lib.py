@@ -99,6 +99,7 @@ PROTOTYPES = {
     "emp_set_timing_filter": (C.c_int, [_vp, C.c_char_p]),
     "emp_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "emp_result_stream": (_vp, [_vp]),
+    "emp_set_fence": (C.c_int, [_vp, C.c_int]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),

@@ -307,6 +307,11 @@ class Planner:
         self.pipelined = m != 0
         self._inflight = []                      # emp_set_pipeline has drained every stream
 
+    def set_fence(self, enabled: bool):
+        """emp_set_fence: whether calls other than a pipelined ``plan_cycle`` wait for the cycles in flight (default) or
+        overlap them (``False``: only for work that does not read a cycle's outputs)."""
+        self._check(self._lib.emp_set_fence(self._h, 1 if enabled else 0))
+
     def torch_result_stream(self):
         """The stream on which the latest cycle's outputs become complete (its lane in pipelined mode)."""
         if not self.pipelined:

@@ -469,6 +469,12 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     return EMP_OK;
 }
 
+int emp_set_fence(emp_ctx* ctx, int enabled) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    ctx->fence = enabled != 0;
+    return EMP_OK;
+}
+
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
     EMP_REQUIRE(ctx, ctx && out, "NULL argument");
     EMP_HIP(ctx, hipSetDevice(ctx->device));

@@ -66,6 +66,7 @@ struct emp_ctx {
     int pipe_mode = 0;                  // 0 off, 1 STAGED, n >= 2 LANES with n lanes
     int lane = 0;                       // lane of the latest pipelined cycle call
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
+    bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     bool pipelined() const { return pipe_mode != 0; }
     int lanes_in_use() const { return pipe_mode == 1 ? 2 : pipe_mode; }
     hipStream_t result_stream() const {
@@ -148,7 +149,7 @@ class Stage {
     // outputs as before
     Stage(emp_ctx* c, emp_mem where, bool in_cycle = false) : ctx_(c), dev_(where == EMP_DEVICE) {
         c->cursor = 0;
-        if (!in_cycle && c->pipelined())
+        if (!in_cycle && c->pipelined() && c->fence)
             for (auto& ln : c->lanes)
                 if (ln.done_valid) (void)hipStreamWaitEvent(c->stream, ln.ev_done, 0);
     }

@@ -146,6 +146,12 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
 #define EMP_PIPELINE_MAX 8
 int emp_set_pipeline(emp_ctx* ctx, int mode);
 void* emp_result_stream(emp_ctx* ctx);
+/* The fence of the pipelined modes (on by default): every entry point other than a pipelined emp_plan_cycle first lets
+ * emp_stream() wait for the cycles in flight, so that it may read their outputs.  Switched off, such calls are queued on
+ * emp_stream() at once and overlap the cycles in flight - for work that does not depend on them (the S-T speed planner of
+ * the same scenes: bench.py --config cfg5); what must be ordered, the caller orders with emp_result_stream().  Their
+ * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
+int emp_set_fence(emp_ctx* ctx, int enabled);
 
 /* One fixed-stride record per scene for the multi-GPU gather (no reference counterpart: the reference plans one scene
  * per process; this is the result exchange of the batched form, emplanner_carla_amd/dist.py):

@@ -145,6 +145,7 @@ expect(lib.emp_dp_plan(None, C.byref(p), B, MO, ptr(obs_s), ptr(obs_l), ptr(n_ob
                        L.EMP_HOST), "emp_dp_plan ctx NULL") if False else None   # NULL ctx: message goes to the create slot
 assert lib.emp_synchronize(None) < 0 and lib.emp_set_pipeline(None, 1) < 0
 assert lib.emp_set_pipeline(h, L.EMP_PIPELINE_MAX + 1) < 0 and b"EMP_PIPELINE_MAX" in lib.emp_last_error(h), "too many lanes is an error"
+assert lib.emp_set_fence(None, 1) < 0 and lib.emp_set_fence(h, 0) == 0 and lib.emp_set_fence(h, 1) == 0
 assert lib.emp_set_pipeline(h, -5) == 0 and lib.emp_set_pipeline(h, 3) == 0 and lib.emp_set_pipeline(h, 0) == 0    # negative = off
 nul = C.c_void_p()
 assert lib.emp_device_alloc(h, C.c_uint64(1 << 62), C.byref(nul)) < 0 and not nul.value, "an impossible allocation is an error"

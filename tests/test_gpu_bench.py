@@ -26,9 +26,10 @@ def test_bench_line(extra):
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert d["value"] > 1e6 and 0.3 < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
-    assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
     lanes = int(extra[extra.index("--pipeline") + 1]) if "--pipeline" in extra else 0
+    # (lane mode overlaps the sweep with other batches' edge kernels: it takes two to three times as long there)
+    assert d["value"] > 1e6 and (0.05 if lanes else 0.3) < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
+    assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
     assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else lanes or 2)
     assert d["config"]["pipeline"] == ("off" if "--no-pipeline" in extra else f"{lanes} lanes" if lanes else "staged")
     if "--alt-pipeline" in extra:      # the second timed region, in lane mode

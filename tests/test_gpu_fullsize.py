@@ -397,3 +397,52 @@ def test_native_record_packing_equals_the_torch_form(planner, pipe):
             assert np.array_equal(got[:, :3], want[k][:, :3]) and same(got[ok], want[k][ok]), f"default stream, step {k}"
     finally:
         planner.set_pipeline(False)
+
+
+@pytest.mark.parametrize("pipe", ["staged", 2])
+def test_unfenced_calls_overlap_the_cycles_in_flight(planner, pipe):
+    """emp_set_fence(0): the S-T speed planner of the same scenes, queued on the main stream while cycles are in flight,
+    neither waits for them nor disturbs them - what bench.py --config cfg5 does every step.  Both halves equal their
+    plain results bit for bit."""
+    import torch
+    from emplanner_carla_amd.api import speed_dp_params
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    sdp = speed_dp_params()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    batches, dyns = [], []
+    for k in range(4):
+        b = S.make_batch(range(300 * k, 300 * k + 1024), cfg)
+        batches.append({kk: t(v) for kk, v in _host_inputs(b).items()})
+        d = S.make_dynamic_batch(range(300 * k, 300 * k + 1024), 16)
+        dyns.append(([t(a) for a in d[:4]], t(d[4])))
+    torch.cuda.synchronize()
+    plain_cycle, plain_st = [], []
+    for ins, (obs, v0) in zip(batches, dyns):
+        r = planner.plan_cycle(p, q, sp, **ins)
+        sets = planner.st_graph(*obs)
+        st = planner.speed_dp(sdp, *sets, v0, tables=False)
+        planner.synchronize()
+        plain_cycle.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+        plain_st.append((st.speed_s.cpu().numpy(), st.speed_t.cpu().numpy(), st.end_node.cpu().numpy()))
+    planner.set_pipeline(pipe)
+    try:
+        res, sts = [], []
+        with torch.cuda.stream(planner.torch_stream()):
+            for ins, (obs, v0) in zip(batches, dyns):
+                res.append(planner.plan_cycle(p, q, sp, **ins))
+                planner.set_fence(False)
+                sets = planner.st_graph(*obs)
+                sts.append(planner.speed_dp(sdp, *sets, v0, tables=False))
+                planner.set_fence(True)
+        planner.synchronize()
+        torch.cuda.synchronize()
+        for k in range(4):
+            _assert_same(plain_cycle[k], {kk: getattr(res[k], kk).cpu().numpy() for kk in OUTPUTS}, f"cycle {k}")
+            got = (sts[k].speed_s.cpu().numpy(), sts[k].speed_t.cpu().numpy(), sts[k].end_node.cpu().numpy())
+            for a, b in zip(got, plain_st[k]):
+                assert np.array_equal(a, b, equal_nan=True), f"speed DP {k}"
+    finally:
+        planner.set_fence(True)
+        planner.set_pipeline(False)
