@@ -207,8 +207,10 @@ class PlannerServer:
     is what answers a batch (``serve`` below binds it to a GPU planner; tests bind a stub).  One thread per connection;
     the planner call itself is serialised (one device context)."""
 
-    def __init__(self, plan_arrays, host: str = "127.0.0.1", port: int = 0):
+    def __init__(self, plan_arrays, host: str = "127.0.0.1", port: int = 0, max_payload: int = 256 << 20,
+                 max_paths: int = 4096):
         self.plan_arrays = plan_arrays
+        self.max_payload, self.max_paths = int(max_payload), int(max_paths)     # per frame / per session
         self.sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self.sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         self.sock.bind((host, port))
@@ -237,7 +239,7 @@ class PlannerServer:
         layout, paths = None, {}
         try:
             while True:
-                ftype, count, payload = recv_frame(conn)
+                ftype, count, payload = recv_frame(conn, self.max_payload)
                 try:
                     if ftype == T_HELLO:
                         layout = Layout.from_hello(payload)
@@ -246,6 +248,8 @@ class PlannerServer:
                         pid, n = struct.unpack_from("<II", payload)
                         if len(payload) != 8 + n * 32:
                             raise WireError("SET_PATH length does not match its point count")
+                        if pid not in paths and len(paths) >= self.max_paths:
+                            raise WireError(f"more than {self.max_paths} paths in one session")
                         paths[pid] = np.frombuffer(payload, "<f8", n * 4, 8).reshape(n, 4).copy()
                     elif ftype == T_PLAN:
                         if layout is None:
@@ -258,8 +262,9 @@ class PlannerServer:
                         return
                     else:
                         raise WireError(f"unknown frame type {ftype}")
-                except WireError as exc:
-                    send_frame(conn, T_ERROR, str(exc).encode())
+                except (WireError, struct.error, ValueError, RuntimeError) as exc:
+                    # a malformed frame or a planner error is answered, not dropped: the session goes on
+                    send_frame(conn, T_ERROR, f"{type(exc).__name__}: {exc}".encode())
         except (ConnectionError, OSError):
             pass
         finally:
@@ -294,7 +299,7 @@ class PlannerClient:
 
     def _path_id(self, path) -> int:
         arr = np.ascontiguousarray(np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path], dtype="<f8"))
-        key = hash(arr.tobytes())
+        key = arr.tobytes()                       # the content itself: a hash of it could collide
         if key not in self._paths:
             pid = len(self._paths) + 1
             send_frame(self.sock, T_SET_PATH, struct.pack("<II", pid, len(arr)) + arr.tobytes())

@@ -67,7 +67,11 @@ def test_server_loop_with_a_stub_planner():
     reqs = [_driver_request(g, c) for c in range(6)]
     seen = []
 
+    boom = []
+
     def stub(arrays, dp):
+        if boom:
+            raise RuntimeError("planner on fire")
         B, M = len(arrays["pred"]), max_path_points(dp)
         seen.append(arrays)
         k = np.arange(B, dtype=np.float64)
@@ -101,6 +105,15 @@ def test_server_loop_with_a_stub_planner():
         wire.send_frame(cl.sock, wire.T_PLAN, b"x" * 10, 1)
         ftype, _, payload = wire.recv_frame(cl.sock)
         assert ftype == wire.T_ERROR and b"records" in payload
+        assert cl.plan(reqs[:1])[0][0] is not None
+        # so do a truncated SET_PATH (too short to hold its own header) and an error raised by the planner itself
+        wire.send_frame(cl.sock, wire.T_SET_PATH, b"\x01\x00")
+        ftype, _, payload = wire.recv_frame(cl.sock)
+        assert ftype == wire.T_ERROR and payload
+        boom.append(True)
+        with pytest.raises(wire.WireError, match="planner on fire"):
+            cl.plan(reqs[:1])
+        boom.clear()
         assert cl.plan(reqs[:1])[0][0] is not None
         cl.close()
         # a client built for another lattice cannot talk to a server that derives other strides: HELLO carries both
