@@ -44,7 +44,7 @@ static size_t tiled_elems(const DpDev& d) { return (size_t)d.tiles * (size_t)(d.
 // stream-ordered before its first use
 static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
     const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
-    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples) * sizeof(double);
+    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples + kSampleMoments) * sizeof(double);
     emp_ctx::PairTable& pt = ctx->pair_tables[ctx->active_lane];
     emp_ctx::Buf& tb = pt.buf;
     if (tb.bytes < tab_bytes) {
@@ -65,7 +65,7 @@ static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
 static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, double* start_cost, double* edge, bool tiled) {
     if (d.B == 0) return EMP_OK;
-    const size_t lds = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples) * sizeof(double);
+    const size_t lds = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples + kSampleMoments) * sizeof(double);
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
     int ncol = d.col - 1;
     int chunks = 1;

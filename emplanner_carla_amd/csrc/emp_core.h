@@ -118,7 +118,30 @@ EMP_HD JerkQuirk jerk_quirk(const Quintic& q, double s0) {
     j.k2x2 = (60.0 * c5) * 2.0;
     return j;
 }
-EMP_HD double jerk_quirk_at(const JerkQuirk& j, double s) { return (j.k0 + j.k1 * s) + j.k2x2 * s; }
+// The sum of the squared quirk term over the kSamples samples s_n = s0 + t_n, in closed form.  The term is LINEAR in s,
+//   6 c3 + 24 c4 s + 60 c5 (2 s) = A + K1 t_n   with  K1 = 24 c4 + 120 c5,  A = 6 c3 + K1 s0,
+// so  sum_n (A + K1 t_n)^2 = kSamples A^2 + 2 A K1 T1 + K1^2 T2  with the lattice constants T1 = sum t_n, T2 = sum t_n^2:
+// about twenty operations per edge where the sample loop (abscissa, two products, two sums, square, accumulate) took
+// eighty - a quarter of the edge-cost kernel's instructions.  Same mathematics as the reference's loop (:492-499,
+// :565-572), rounded differently in the last bits (the reference's own values carry ~1e-6 of noise from its 6x6 inverse).
+// Operation order as written; oracle/exact.py states the same.
+constexpr int kSampleMoments = 2;      // T1, T2 stored behind the kSamples sample offsets
+EMP_HD void sample_moments(double sample_s, double* T1, double* T2) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < kSamples; ++i) {
+        const double t = sample_t(i, sample_s);
+        a = a + t;
+        b = b + t * t;
+    }
+    *T1 = a;
+    *T2 = b;
+}
+EMP_HD double jerk_quirk_sum(const Quintic& q, double s0, double T1, double T2) {
+    const JerkQuirk j = jerk_quirk(q, s0);
+    const double K1 = j.k1 + j.k2x2;
+    const double A = j.k0 + K1 * s0;
+    return ((double)kSamples * (A * A) + (2.0 * A) * (K1 * T1)) + (K1 * K1) * T2;
+}
 
 // ref: cal_obs_cost (path_planning.py:588-609) driven by the caller's d^2 loop (:503-509 / :577-583):
 // ordered scan of the 10 samples of ONE obstacle with the early break on the first hard hit.
@@ -154,21 +177,20 @@ EMP_HD bool obstacle_in_reach(double obs_s, double obs_l, double s_first, double
 EMP_HD double segment_cost(const Quintic& q, double s0, double sample_s, const double* obs_s,
                            const double* obs_l, int n_obs, double w_collision, double w0, double w1, double w2,
                            double w_ref) {
-    const JerkQuirk jq = jerk_quirk(q, s0);
+    double T1, T2;
+    sample_moments(sample_s, &T1, &T2);
+    const double S_d3 = jerk_quirk_sum(q, s0, T1, T2);
     double l_s[kSamples];
-    double S_l = 0.0, S_dl = 0.0, S_ddl = 0.0, S_d3 = 0.0;
+    double S_l = 0.0, S_dl = 0.0, S_ddl = 0.0;
     for (int i = 0; i < kSamples; ++i) {
         const double t = sample_t(i, sample_s);
-        const double s = s0 + t;
         const double l = quintic_l(q, t);
         const double dl = quintic_dl(q, t);
         const double ddl = quintic_ddl(q, t);
-        const double d3 = jerk_quirk_at(jq, s);
         l_s[i] = l;
         S_l = S_l + l * l;
         S_dl = S_dl + dl * dl;
         S_ddl = S_ddl + ddl * ddl;
-        S_d3 = S_d3 + d3 * d3;
     }
     double coll = 0.0;
     for (int m = 0; m < n_obs; ++m) coll = coll + obstacle_cost(l_s, s0, sample_s, obs_s[m], obs_l[m], w_collision);

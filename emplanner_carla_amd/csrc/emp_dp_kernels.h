@@ -41,7 +41,8 @@ constexpr int kTableFields = kSamples + 7;  // l samples, a3, a4, a5, base smoot
 // (dl0 = ddl0 = 0, T = sample_s: the lateral samples, sum l^2, sum dl^2, sum ddl^2, a3..a5 are functions of the
 // row pair (k, i) only; the quirked jerk term and the obstacles are what see the absolute s).  It depends only
 // on the lattice parameters, so it is built once per parameter set by this one-block kernel and kept in device
-// memory: [kTableFields][row*row] doubles (pair index = k*row + i) followed by the kSamples sample offsets.
+// memory: [kTableFields][row*row] doubles (pair index = k*row + i) followed by the kSamples sample offsets t_n and
+// their two moments sum t_n, sum t_n^2 (emp_core.h sample_moments).
 __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __restrict__ tab) {
     const int row = P.row, rr = P.row * P.row;
     for (int p = threadIdx.x; p < rr; p += blockDim.x) {
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __r
         tab[(kSamples + 6) * rr + p] = fmax(l_pre, l_cur);
     }
     if (threadIdx.x < kSamples) tab[kTableFields * rr + threadIdx.x] = sample_t(threadIdx.x, P.sample_s);
+    if (threadIdx.x == 0) sample_moments(P.sample_s, &tab[kTableFields * rr + kSamples], &tab[kTableFields * rr + kSamples + 1]);
 }
 
 // kSoftGain / d2 for 16 < d2 < 36: the instruction sequence the compiler emits for an IEEE binary64 division
@@ -136,6 +138,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
     const int nmask = min(nob, 64);
     const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
     const double s9 = s0 + t_smp[kSamples - 1];
+    const double T1 = t_smp[kSamples], T2 = t_smp[kSamples + 1];    // sum t_n, sum t_n^2 (sample_moments)
     // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
     unsigned long long near_s = 0;
     for (int m = 0; m < nmask; ++m) {
@@ -148,13 +151,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         q.a3 = tab[(kSamples + 0) * rr + p];
         q.a4 = tab[(kSamples + 1) * rr + p];
         q.a5 = tab[(kSamples + 2) * rr + p];
-        const JerkQuirk jq = jerk_quirk(q, s0);
-        double S_d3 = 0.0;
-#pragma unroll
-        for (int n = 0; n < kSamples; ++n) {
-            const double d3 = jerk_quirk_at(jq, s0 + t_smp[n]);
-            S_d3 = S_d3 + d3 * d3;
-        }
+        const double S_d3 = jerk_quirk_sum(q, s0, T1, T2);
         const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
         const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
         double coll = 0.0;
@@ -195,12 +192,12 @@ __global__ __launch_bounds__(256, 5) void dp_edge_kernel(DpDev P, const double* 
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
     double* t_obs_l = t_obs_s + P.S * P.max_obs;
-    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples] sample offsets t_n
+    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples + 2] sample offsets t_n, then sum t_n and sum t_n^2
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
 
     for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
-    if (tid < kSamples) t_smp[tid] = pair_tab[kTableFields * rr + tid];
+    if (tid < kSamples + kSampleMoments) t_smp[tid] = pair_tab[kTableFields * rr + tid];
     for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
         const int s = x / P.max_obs, m = x - s * P.max_obs;
         const int b = tile * P.S + s;
@@ -444,7 +441,7 @@ struct FusedLds {
 __host__ __device__ inline FusedLds fused_lds(int row, int col, int S, int max_obs, int nc) {
     FusedLds L;
     int o = kTableFields * row * row * 8;
-    L.off_smp = o;   o += kSamples * 8;
+    L.off_smp = o;   o += (kSamples + kSampleMoments) * 8;
     L.off_obs_s = o; o += S * max_obs * 8;
     L.off_obs_l = o; o += S * max_obs * 8;
     L.off_buf = o;   o += 2 * nc * row * 64 * 8;
@@ -480,7 +477,7 @@ __global__ __launch_bounds__(256, 4) void dp_fused_kernel(DpDev P, const double*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
-    if (tid < kSamples) t_smp[tid] = pair_tab[kTableFields * rr + tid];
+    if (tid < kSamples + kSampleMoments) t_smp[tid] = pair_tab[kTableFields * rr + tid];
     for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
         const int sc = x / P.max_obs, m = x - sc * P.max_obs;
         const int bb = tile * P.S + sc;
