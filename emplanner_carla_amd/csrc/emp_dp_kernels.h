@@ -172,6 +172,9 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
 
 // grid = (tiles, column chunks), block = 256.  Dynamic LDS: the pair table (copied from `pair_tab`),
 // followed by the tile's obstacles [S][max_obs] x2 doubles and the sample offsets.
+#ifndef EMP_EDGE_WAVES
+#define EMP_EDGE_WAVES 5
+#endif
 template <bool TILED>
 // Five wavefronts per SIMD (at most 102 registers; 94 used, nothing spilled - the sample abscissae are rebuilt from
 // s0 + t_n where they are needed instead of living in twenty registers): alone the kernel takes the same 158 us as with
@@ -179,7 +182,7 @@ template <bool TILED>
 // (Tried with several batches in flight: padding the allocation to 104 registers, so that four wavefronts leave room on
 // a SIMD for a wavefront of the sweep or the Cartesian tail that a fifth edge wavefront cannot take.  The overlapped sweep
 // got 15 % shorter, the edge kernel 3 % longer, and the step longer in every pipeline mode: not kept.)
-__global__ __launch_bounds__(256, 5) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
+__global__ __launch_bounds__(256, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
                                                       const double* __restrict__ obs_s,
                                                       const double* __restrict__ obs_l,
                                                       const int* __restrict__ n_obs,
