@@ -17,8 +17,8 @@
  *     torch tensors' data_ptr()).  Parameter structs are always host memory.
  *   - functions return EMP_OK or a negative emp_error; emp_last_error() gives the text.
  *     Per-scene problems never fail a call: they are reported in `status[b]` (bit mask).
- *   - a context owns one device, one HIP stream and its scratch buffers; calls on one
- *     context are serialised by the caller.  HIP is initialised lazily in emp_create(), so a
+ *   - a context owns one device, its HIP stream (more streams once emp_set_pipeline is used) and its
+ *     scratch buffers; calls on one context are serialised by the caller.  HIP is initialised lazily in emp_create(), so a
  *     forked planning process (ref: test_9.py:225-227 runs the planner in a child process)
  *     must create its context after the fork.
  */
