@@ -404,7 +404,10 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
     // four quarter-length chains at once from its own row, then three hops pick the right ones and the scene's lanes share
     // the output columns - is bit-identical and was SLOWER: 21.7 against 20.6 us per launch at 4096 scenes, 40x9.  So was
     // leaving the rows as bytes in LDS and writing the tile's [S][col] block with 64 consecutive doubles per store: 21.5 us;
-    // the scattered stores below are asynchronous and hide behind the chain.  Without any backtrack the launch takes 19.0.)
+    // the scattered stores below are asynchronous and hide behind the chain.  A third form kept every lane's predecessor
+    // bytes in registers and followed the chains with v_readlane, row indices in scalar registers, seven scenes interleaved,
+    // fully unrolled: 26 us - every wave64 vector instruction of that chain costs four cycles, and there are 273 of them.
+    // Without any backtrack the launch takes 19.0.)
     if (live && i == 0) {
         const bool bypass = (n_obs != nullptr) && (n_obs[b] == 0);
         double* out = rows_out + (size_t)b * P.col;
