@@ -31,21 +31,32 @@ EMP_HD int match_scan(const double* line, int n_ref, double x, double y, int fir
     return match;
 }
 
+// numpy.dot of two 2-vectors, as the reference evaluates every projection (planning_utils.py:107, :173, :417, :443, :507,
+// :546-578, :799-800).  On an x86 host numpy hands it to OpenBLAS' ddot kernel, which accumulates with fused
+// multiply-adds: the result is fma(a1, b1, a0 * b0) - one rounding of the second product fewer than a0*b0 + a1*b1,
+// different in the last bit a quarter of the time (checked against numpy 2.2 / OpenBLAS 0.3.29 on 200 000 random
+// pairs: identical every time).  That bit decides ties the reference cannot see: a planning start that projects exactly
+// onto a node of the reference line (the synthetic scenes put it there) lands on one side or the other of
+// `s_map[idx + 1] < s` (path_planning.py:63) by the rounding of this sum.  Evaluating it the way the reference's host
+// does took the full-cycle mismatches of a 2048-scene sweep (tools/parity_sweep.py) from two scenes, first trajectory point
+// 0.45 mm off, to one - whose tie is decided by the last bit of cos / sin instead.
+EMP_HD double dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
+
 // ref: planning_utils.py:414-424 - projection on the tangent line of a matched node
 EMP_HD Node project_on(const Node& m, double x, double y) {
     const double c = cos(m.theta), s = sin(m.theta);
-    const double ds = (x - m.x) * c + (y - m.y) * s;
+    const double ds = dot2(x - m.x, y - m.y, c, s);
     return Node{m.x + ds * c, m.y + ds * s, m.theta + m.kappa * ds, m.kappa};
 }
 
 // ref: cal_projection_s_fun, planning_utils.py:439-443
 EMP_HD double projection_s(const Node& m, double s_at_m, double x, double y) {
-    return s_at_m + ((x - m.x) * cos(m.theta) + (y - m.y) * sin(m.theta));
+    return s_at_m + dot2(x - m.x, y - m.y, cos(m.theta), sin(m.theta));
 }
 
 // ref: cal_s_l_fun tail, planning_utils.py:499-507
 EMP_HD double lateral_offset(const Node& proj, double x, double y) {
-    return (x - proj.x) * (-sin(proj.theta)) + (y - proj.y) * cos(proj.theta);
+    return dot2(x - proj.x, y - proj.y, -sin(proj.theta), cos(proj.theta));
 }
 
 // ref: cal_s_map_fun, planning_utils.py:448-472.  s_map has n_ref entries.
@@ -71,12 +82,12 @@ EMP_HD FrenetState frenet_state(const Node& proj, double px, double py, double v
     FrenetState o;
     const double c = cos(proj.theta), s = sin(proj.theta);
     const double k = proj.kappa;
-    o.l = (px - proj.x) * (-s) + (py - proj.y) * c;
-    o.l_dot = vx * (-s) + vy * c;
-    o.s_dot = (vx * c + vy * s) / (1.0 - k * o.l);
-    o.l_ddot = (ax * (-s) + ay * c) - k * (1.0 - k * o.l) * (o.s_dot * o.s_dot);
+    o.l = dot2(px - proj.x, py - proj.y, -s, c);
+    o.l_dot = dot2(vx, vy, -s, c);
+    o.s_dot = dot2(vx, vy, c, s) / (1.0 - k * o.l);
+    o.l_ddot = dot2(ax, ay, -s, c) - k * (1.0 - k * o.l) * (o.s_dot * o.s_dot);
     o.dl_ds = (fabs(o.s_dot) < 1e-6) ? 0.0 : o.l_dot / o.s_dot;
-    o.s_ddot = ((ax * c + ay * s) + 2.0 * (o.s_dot * o.s_dot * k * o.dl_ds) + o.s_dot * o.s_dot * 0.0 * o.l) / (1.0 - k * o.l);
+    o.s_ddot = (dot2(ax, ay, c, s) + 2.0 * (o.s_dot * o.s_dot * k * o.dl_ds) + o.s_dot * o.s_dot * 0.0 * o.l) / (1.0 - k * o.l);
     o.ddl_ds = (fabs(o.s_dot) < 1e-6) ? 0.0 : (o.l_ddot - o.dl_ds * o.s_ddot) / (o.s_dot * o.s_dot);
     return o;
 }

@@ -249,7 +249,7 @@ __global__ void match_points_kernel(int B, int max_ref, int max_pts, const doubl
         } else {
             const int st = pre_match_index[b];                                     // ref :123-167
             const Node pm = node_at(line, st);
-            const double flag = (x - pm.x) * cos(pm.theta) + (y - pm.y) * sin(pm.theta);
+            const double flag = dot2(x - pm.x, y - pm.y, cos(pm.theta), sin(pm.theta));   // ref :139 np.dot
             m = match_scan(line, P, x, y, st, flag > 0.0 ? 1 : -1, 5);
         }
         if (j == 0) m_first = m;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void reference_line_wave_kernel(int B, int max_
             m = match_scan(line, P, x, y, 0, 1, 50);     // ref :72-92
         } else {
             const Node pm = node_at(line, st);           // ref :123-167
-            const double flag = (x - pm.x) * cos(pm.theta) + (y - pm.y) * sin(pm.theta);
+            const double flag = dot2(x - pm.x, y - pm.y, cos(pm.theta), sin(pm.theta));   // ref :139 np.dot
             m = match_scan(line, P, x, y, st, flag > 0.0 ? 1 : -1, 5);
         }
         // sampling (ref :244-259): the arguments are overwritten with 10 back / 40 forward
@@ -933,8 +933,8 @@ __global__ void dy_obs_deri_kernel(int n, const double* __restrict__ in, double*
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const double l = in[5 * t], vx = in[5 * t + 1], vy = in[5 * t + 2], hd = in[5 * t + 3], k = in[5 * t + 4];
-    const double l_dot = vx * (-sin(hd)) + vy * cos(hd);
-    const double s_dot = (vx * cos(hd) + vy * sin(hd)) / (1.0 - k * l);
+    const double l_dot = dot2(vx, vy, -sin(hd), cos(hd));                 // np.dot, :799-800
+    const double s_dot = dot2(vx, vy, cos(hd), sin(hd)) / (1.0 - k * l);
     out[3 * t] = s_dot;
     out[3 * t + 1] = l_dot;
     out[3 * t + 2] = (fabs(s_dot) < 1e-6) ? 0.0 : l_dot / s_dot;

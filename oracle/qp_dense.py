@@ -97,6 +97,7 @@ def _ipm(P, q, G, h, A, b, max_iter=200, tol=1e-11):
     s = s + shift
     z = np.ones(m)
     it = 0
+    best = None                      # (merit, x, s, y, z): the best iterate seen
     for it in range(max_iter):
         rx = P @ x + q + G.T @ z + A.T @ y
         rp = G @ x + s - h
@@ -104,6 +105,19 @@ def _ipm(P, q, G, h, A, b, max_iter=200, tol=1e-11):
         mu = float(s @ z) / max(m, 1)
         res = max(np.abs(rx).max(initial=0.0), np.abs(rp).max(initial=0.0),
                   np.abs(re).max(initial=0.0))
+        merit = max(res, mu)
+        if not np.isfinite(merit):
+            # The tolerance below sits under the rounding floor of some KKT systems (cond ~ 1e8 on paths squeezed between
+            # obstacles): the iteration then walks on with slacks at the boundary until a solve returns NaN.  The best
+            # iterate is within ~1e-9 of the minimiser and the active-set polish finishes from there.
+            if best is not None:
+                _, x, s, y, z = best
+            break
+        if best is None or merit < best[0]:
+            best = (merit, x.copy(), s.copy(), y.copy(), z.copy())
+        elif it > 40 and merit > 1e3 * best[0] and best[0] <= 1e-7 * scale:
+            _, x, s, y, z = best      # converged as far as the arithmetic allows, now drifting
+            break
         if res <= tol * scale and mu <= tol * 1e-2 * scale:
             break
         w = z / s
@@ -124,9 +138,10 @@ def _ipm(P, q, G, h, A, b, max_iter=200, tol=1e-11):
         ap = min(1.0, max_step(s, dsa))
         ad = min(1.0, max_step(z, dza))
         mu_aff = float((s + ap * dsa) @ (z + ad * dza)) / max(m, 1)
-        sigma = (mu_aff / mu) ** 3 if mu > 0 else 0.0
+        ratio = mu_aff / mu if mu > 0 else 0.0
+        sigma = ratio ** 3 if abs(ratio) < 1e100 else 1.0     # (a diverging, infeasible problem: float ** raises OverflowError)
         dx, dy, ds, dz = newton(s * z + dsa * dza - sigma * mu)
-        eta = max(0.99, 1.0 - mu) if mu < 1.0 else 0.99
+        eta = min(max(0.99, 1.0 - mu), 0.9995) if mu < 1.0 else 0.99     # never onto the boundary itself
         ap = min(1.0, eta * max_step(s, ds))
         ad = min(1.0, eta * max_step(z, dz))
         x = x + ap * dx
