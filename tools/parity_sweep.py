@@ -7,7 +7,10 @@
           reference's own result follows the rounding of its host's libm / BLAS ("Known sensitivity")
 
 The oracles run in a process pool on the host cores; prints one summary line per part and writes gpurun_out/parity_sweep.json.
-Usage: python tools/parity_sweep.py [N_DP] [N_CYCLE] [processes]"""
+  S-T     seeds 0..N_ST-1: generate_st_graph bit for bit, speed-DP cost tables within 1e-12, predecessor tables (a node may differ
+          only where two candidates tie to within pow()'s last bit), terminal node and chosen path where the tables agree
+
+Usage: python tools/parity_sweep.py [N_DP] [N_CYCLE] [processes] [N_ST]"""
 import json
 import multiprocessing as mp
 import os
@@ -21,6 +24,8 @@ N_DP = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 6553
 N_CY = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 NPROC = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, min(16, len(os.sched_getaffinity(0))))
 CHUNK = 256
+ST_CHUNK = 32
+N_ST = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 
 
 def _exact_chunk(lo):
@@ -56,6 +61,15 @@ def _port_scene(seed):
         return seed, ok, bool(out["dp_feasible"]), np.asarray(out["trajectory"], dtype=np.float64) if ok else None, extra
     except IndexError:
         return seed, False, None, None, dict(qp_status="IndexError")
+
+
+def _st_chunk(lo):
+    from emplanner_carla_amd import scenes as S
+    from oracle import st_speed
+    o = S.make_dynamic_batch(range(lo, lo + ST_CHUNK))
+    sets = st_speed.exact_generate_st_graph(*o[:4])
+    ex = st_speed.exact_speed_dp(*sets, o[4])
+    return lo, sets, ex["cost"], ex["node"], ex["end"], ex["speed_s"]
 
 
 def main():
@@ -143,9 +157,37 @@ def main():
         print("    tie:", json.dumps(d), flush=True)
     for d in report["cycle"]["details"]:
         print("   ", json.dumps(d), flush=True)
+    # ---- S-T speed DP (config 5's second half) against oracle/st_speed.py exact_*
+    t0 = time.time()
+    from emplanner_carla_amd.api import speed_dp_params
+    sdp = speed_dp_params()
+    g_bad = c_bad = e_bad = 0
+    node_mis = node_tot = 0
+    worst_c = 0.0
+    with ctx.Pool(NPROC) as pool:
+        for lo, xsets, xcost, xnode, xend, xss in pool.imap_unordered(_st_chunk, range(0, N_ST, ST_CHUNK)):
+            o = S.make_dynamic_batch(range(lo, lo + ST_CHUNK))
+            sets = pl.st_graph(*o[:4])
+            g_bad += int(sum(not np.array_equal(sets[i], xsets[i], equal_nan=True) for i in range(4)))
+            res = pl.speed_dp(sdp, *sets, o[4])
+            fin = np.isfinite(xcost)
+            c_bad += int((np.isfinite(res.cost) != fin).sum())
+            rel = np.abs(res.cost[fin] - xcost[fin]) / np.maximum(np.abs(xcost[fin]), 1.0)
+            worst_c = max(worst_c, float(rel.max(initial=0.0)))
+            node_mis += int((res.node != xnode).sum())
+            node_tot += int(xnode.size)
+            same = (res.node == xnode).all(axis=(1, 2))
+            e_bad += int((res.end_node[same] != xend[same]).any(axis=1).sum())
+            e_bad += int((~np.isclose(res.speed_s[same], xss[same], rtol=0, atol=0, equal_nan=True)).any(axis=1).sum())
+    report["speed_dp"] = {"scenes": N_ST, "st_graph_arrays_not_bit_equal": g_bad, "cost_finiteness_mismatch": c_bad,
+                          "worst_relative_cost_error": worst_c, "cost_tolerance": 1e-12, "node_mismatch": node_mis, "nodes": node_tot,
+                          "end_or_path_mismatch_where_tables_equal": e_bad, "seconds": round(time.time() - t0, 1)}
+    print("S-T ", json.dumps(report["speed_dp"]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/parity_sweep.json", "w"), indent=1)
-    ok = not any(bad.values()) and not (outcome or feas_bad or length) and worst <= 1e-6
+    st = report["speed_dp"]
+    ok_st = not (g_bad or c_bad or e_bad) and worst_c <= 1e-12 and st["node_mismatch"] <= 1e-4 * st["nodes"]
+    ok = not any(bad.values()) and not (outcome or feas_bad or length) and worst <= 1e-6 and ok_st
     print("PARITY-SWEEP", "OK" if ok else "MISMATCH")
     return 0 if ok else 1
 
