@@ -134,13 +134,25 @@ def _ipm(P, q, G, h, A, b, max_iter=200, tol=1e-11):
             neg = dv < 0
             return float((-v[neg] / dv[neg]).min()) if neg.any() else np.inf
 
-        dxa, dya, dsa, dza = newton(s * z)
+        try:
+            dxa, dya, dsa, dza = newton(s * z)
+        except np.linalg.LinAlgError:
+            # w = z / s has overflowed on a diverging (infeasible) problem and the KKT matrix is numerically singular: stop
+            # at the best iterate; the caller's residual test reports the problem as not solved
+            if best is not None:
+                _, x, s, y, z = best
+            break
         ap = min(1.0, max_step(s, dsa))
         ad = min(1.0, max_step(z, dza))
         mu_aff = float((s + ap * dsa) @ (z + ad * dza)) / max(m, 1)
         ratio = mu_aff / mu if mu > 0 else 0.0
         sigma = ratio ** 3 if abs(ratio) < 1e100 else 1.0     # (a diverging, infeasible problem: float ** raises OverflowError)
-        dx, dy, ds, dz = newton(s * z + dsa * dza - sigma * mu)
+        try:
+            dx, dy, ds, dz = newton(s * z + dsa * dza - sigma * mu)
+        except np.linalg.LinAlgError:
+            if best is not None:
+                _, x, s, y, z = best
+            break
         eta = min(max(0.99, 1.0 - mu), 0.9995) if mu < 1.0 else 0.99     # never onto the boundary itself
         ap = min(1.0, eta * max_step(s, ds))
         ad = min(1.0, eta * max_step(z, dz))

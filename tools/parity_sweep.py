@@ -38,10 +38,15 @@ def _exact_chunk(lo):
     return lo, rows, feas, [np.asarray(p[0]) for p in paths], [np.asarray(p[1]) for p in paths]
 
 
+def _cycle_cfg():
+    from emplanner_carla_amd import scenes as S
+    return {"cfg2": S.CFG2, "default": S.CFG_DEFAULT, "cfg1": S.CFG1}[os.environ.get("SWEEP_CYCLE_CFG", "cfg2")]
+
+
 def _port_scene(seed):
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
-    cfg = S.CFG2
+    cfg = _cycle_cfg()
     b = S.make_batch([seed], cfg)
     nk = int(b.n_obs[0])
     try:
@@ -100,8 +105,11 @@ def main():
                     bad["path"] += 1
     report["dp"] = {"scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
     print("DP  ", json.dumps(report["dp"]), flush=True)
-    # ---- whole cycle against the port
+    # ---- whole cycle against the port (SWEEP_CYCLE_CFG = cfg2 (default) | default | cfg1 picks the lattice)
     t0 = time.time()
+    cfg = _cycle_cfg()
+    p = dp_params_from_cfg(cfg)
+    M = max_path_points(p)
     b = S.make_batch(range(N_CY), cfg)
     P = b.ref.shape[1]
     r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
@@ -147,7 +155,7 @@ def main():
                                     err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
                                     worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
             compared += 1
-    report["cycle"] = {"scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
+    report["cycle"] = {"config": cfg.name, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
                        "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "worst_relative_error": worst,
                        "tolerance": 1e-6, "seconds": round(time.time() - t0, 1),
                        "tie_scenes_beyond_tolerance": sorted(ties, key=lambda d: d["seed"]),
