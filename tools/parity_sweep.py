@@ -10,7 +10,10 @@ The oracles run in a process pool on the host cores; prints one summary line per
   S-T     seeds 0..N_ST-1: generate_st_graph bit for bit, speed-DP cost tables within 1e-12, predecessor tables (a node may differ
           only where two candidates tie to within pow()'s last bit), terminal node and chosen path where the tables agree
 
-Usage: python tools/parity_sweep.py [N_DP] [N_CYCLE] [processes] [N_ST]"""
+  front   N_FE requests of the front end (find_match_points -> sampling -> smoothing of the 51-point reference line) on random
+          global paths against the port: match index exact, line within 1e-6
+
+Usage: python tools/parity_sweep.py [N_DP] [N_CYCLE] [processes] [N_ST] [N_FE]"""
 import json
 import multiprocessing as mp
 import os
@@ -26,6 +29,7 @@ NPROC = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, min(16, len(os.sched_g
 CHUNK = 256
 ST_CHUNK = 32
 N_ST = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+N_FE = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
 
 
 def _exact_chunk(lo):
@@ -75,6 +79,36 @@ def _st_chunk(lo):
     sets = st_speed.exact_generate_st_graph(*o[:4])
     ex = st_speed.exact_speed_dp(*sets, o[4])
     return lo, sets, ex["cost"], ex["node"], ex["end"], ex["speed_s"]
+
+
+FE_G = 240          # longest global path of the front-end part
+
+
+def _front_end_case(seed):
+    """One request of the cycle's front end (test_9.py:99-110): a noisy S-curve as the global path, the predicted
+    location near one of its nodes, the previous match a few nodes off (or a first run)."""
+    from oracle import ref_port as op
+    rng = np.random.default_rng(100000 + seed)
+    n = int(rng.integers(51, FE_G + 1))
+    t = np.arange(n) * 2.0
+    phase, amp = rng.uniform(0, 6.28), rng.uniform(5.0, 40.0)
+    xy = np.stack([t + rng.normal(0, 0.05, n), amp * np.sin(t / 60.0 + phase) + rng.normal(0, 0.05, n)], axis=1)
+    th, ka = op.cal_heading_kappa([tuple(q) for q in xy])
+    path = np.column_stack([xy, th, ka])
+    at = int(rng.integers(0, n))
+    first = int(rng.random() < 0.1)
+    pre = 0 if first else int(np.clip(at + rng.integers(-8, 9), 0, n - 1))
+    pred = path[at, :2] + rng.normal(0, 0.8, 2)
+    return path, pred, pre, first
+
+
+def _front_end_port(seed):
+    from oracle import ref_port as op
+    path, pred, pre, first = _front_end_case(seed)
+    nodes = [tuple(r) for r in path]
+    match, _ = op.find_match_points([tuple(pred)], nodes, bool(first), int(pre))
+    line = np.asarray(op.smooth_reference_line(op.sampling(int(match[0]), nodes)), dtype=np.float64)
+    return seed, int(match[0]), line
 
 
 def main():
@@ -191,11 +225,40 @@ def main():
                           "worst_relative_cost_error": worst_c, "cost_tolerance": 1e-12, "node_mismatch": node_mis, "nodes": node_tot,
                           "end_or_path_mismatch_where_tables_equal": e_bad, "seconds": round(time.time() - t0, 1)}
     print("S-T ", json.dumps(report["speed_dp"]), flush=True)
+    # ---- front end: find_match_points -> sampling -> smooth_reference_line (51 points) against the port
+    t0 = time.time()
+    gp = np.zeros((N_FE, FE_G, 4))
+    n_global = np.zeros(N_FE, np.int32)
+    pred = np.zeros((N_FE, 2))
+    pre = np.zeros(N_FE, np.int32)
+    first = np.zeros(N_FE, np.int32)
+    for k in range(N_FE):
+        path, pred[k], pre[k], first[k] = _front_end_case(k)
+        gp[k, :len(path)] = path
+        n_global[k] = len(path)
+    ref, n_ref, mi, it, stf = pl.reference_line(smooth_params(), gp, n_global, pred, pre, first)
+    m_bad = s_bad = 0
+    worst_fe = 0.0
+    with ctx.Pool(NPROC) as pool:
+        for k, match, line in pool.imap_unordered(_front_end_port, range(N_FE), chunksize=16):
+            if mi[k] != match:
+                m_bad += 1
+                continue
+            if stf[k] != 0 or n_ref[k] != 51:
+                s_bad += 1
+                continue
+            e = np.abs(ref[k, :, :3] - line[:, :3]) / np.maximum(np.abs(line[:, :3]), 1.0)
+            ek = np.abs(ref[k, :, 3] - line[:, 3]) / np.maximum(np.abs(line[:, 3]), 1e-2)
+            worst_fe = max(worst_fe, float(e.max()), float(ek.max()))
+    report["front_end"] = {"requests": N_FE, "match_index_mismatch": m_bad, "status_mismatch": s_bad,
+                           "worst_relative_error": worst_fe, "tolerance": 1e-6, "seconds": round(time.time() - t0, 1)}
+    print("front", json.dumps(report["front_end"]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(report, open("gpurun_out/parity_sweep.json", "w"), indent=1)
     st = report["speed_dp"]
     ok_st = not (g_bad or c_bad or e_bad) and worst_c <= 1e-12 and st["node_mismatch"] <= 1e-4 * st["nodes"]
-    ok = not any(bad.values()) and not (outcome or feas_bad or length) and worst <= 1e-6 and ok_st
+    ok_fe = not (m_bad or s_bad) and worst_fe <= 1e-6
+    ok = ok_fe and not any(bad.values()) and not (outcome or feas_bad or length) and worst <= 1e-6 and ok_st
     print("PARITY-SWEEP", "OK" if ok else "MISMATCH")
     return 0 if ok else 1
 
