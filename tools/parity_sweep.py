@@ -51,7 +51,7 @@ def _port_scene(seed):
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
     cfg = _cycle_cfg()
-    b = S.make_batch([seed], cfg)
+    b = S.make_batch([seed], cfg, dist=os.environ.get("SWEEP_SCENE_DIST", "corridor"))
     nk = int(b.n_obs[0])
     try:
         out = op.plan_cycle(b.ref[0], tuple(b.origin_xy[0]), tuple(b.start_xy[0]), tuple(b.start_v[0]), tuple(b.start_a[0]),
@@ -144,7 +144,8 @@ def main():
     cfg = _cycle_cfg()
     p = dp_params_from_cfg(cfg)
     M = max_path_points(p)
-    b = S.make_batch(range(N_CY), cfg)
+    dist_name = os.environ.get("SWEEP_SCENE_DIST", "corridor")      # corridor (default) | survey | worst: obstacle layout
+    b = S.make_batch(range(N_CY), cfg, dist=dist_name)
     P = b.ref.shape[1]
     r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
                       n_ref=np.full(N_CY, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
@@ -189,7 +190,7 @@ def main():
                                     err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
                                     worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
             compared += 1
-    report["cycle"] = {"config": cfg.name, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
+    report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
                        "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "worst_relative_error": worst,
                        "tolerance": 1e-6, "seconds": round(time.time() - t0, 1),
                        "tie_scenes_beyond_tolerance": sorted(ties, key=lambda d: d["seed"]),
