@@ -26,16 +26,22 @@ import numpy as np
 N_DP = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
 N_CY = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 NPROC = int(sys.argv[3]) if len(sys.argv) > 3 else max(1, min(16, len(os.sched_getaffinity(0))))
-CHUNK = 256
+CHUNK = 16 if os.environ.get("SWEEP_DP_CFG") == "cfg5" else 256     # scenes per oracle call (the wide lattice's temporaries are large)
 ST_CHUNK = 32
 N_ST = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 N_FE = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
 
 
+def _dp_cfg():
+    from emplanner_carla_amd import scenes as S
+    name = os.environ.get("SWEEP_DP_CFG", "cfg2")              # cfg2 (default) | cfg5 | default | cfg1
+    return {"cfg2": S.CFG2, "cfg5": S.CFG5, "default": S.CFG_DEFAULT, "cfg1": S.CFG1}[name]
+
+
 def _exact_chunk(lo):
     from emplanner_carla_amd import scenes as S
     from oracle import exact as ex
-    cfg = S.CFG2
+    cfg = _dp_cfg()
     b = S.make_batch(range(lo, lo + CHUNK), cfg)
     rows, feas, paths = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l,
                                    cfg.sampling_res)
@@ -114,7 +120,7 @@ def _front_end_port(seed):
 def main():
     from emplanner_carla_amd import scenes as S
     from emplanner_carla_amd.api import Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params
-    cfg = S.CFG2
+    cfg = _dp_cfg()
     p = dp_params_from_cfg(cfg)
     M = max_path_points(p)
     pl = Planner(0)
@@ -137,7 +143,7 @@ def main():
                     bad["length"] += 1
                 elif not (np.array_equal(ps[k, :ln[k]], xs[k]) and np.array_equal(pll[k, :ln[k]], xl[k])):
                     bad["path"] += 1
-    report["dp"] = {"scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
+    report["dp"] = {"config": cfg.name, "scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
     print("DP  ", json.dumps(report["dp"]), flush=True)
     # ---- whole cycle against the port (SWEEP_CYCLE_CFG = cfg2 (default) | default | cfg1 picks the lattice)
     t0 = time.time()
