@@ -1,5 +1,8 @@
+"""Why is a 20-step timed region slower per step than a 100-step one?  Per-round: ms per step, host issue time, first call -
+with and without the sweep's timing events.  (Answer: not the host and not event creation - the first rounds after a short
+warm-up run at lower clocks; bench.py therefore settles for ~50 ms before it times.)"""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from emplanner_carla_amd import _lib as L, scenes as S
 from emplanner_carla_amd.api import Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params
