@@ -244,11 +244,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (test hook: EMP_BENCH_BACKEND=gloo runs the N > 1 code with several ranks on ONE GPU - RCCL refuses two ranks on a
+    # device, gloo moves CUDA tensors through the host - so that the whole multi-rank step loop can be exercised on a
+    # one-GPU box; tests/test_gpu_bench.py.  The driver's runs never set it.)
+    backend = os.environ.get("EMP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     wide = args.config == "cfg5"
     cfg = S.CFG5 if wide else S.CFG2
@@ -267,7 +275,7 @@ def main():
         st_inputs = [t(a) for a in dyn[:4]], t(dyn[4])
     torch.cuda.synchronize()
 
-    pl = Planner(local_rank)
+    pl = Planner(dev_index)
     p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
     sdp = speed_dp_params()
     M = max_path_points(p)

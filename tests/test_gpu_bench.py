@@ -69,3 +69,27 @@ def test_other_bench_lines(extra, metric_part):
         assert d["scenes_fully_planned_frac"] > 0.9
     if "--gather" in extra:
         assert d["gather"]["mode"] == "all" and d["gather"]["doubles_per_scene"] == 94 and d["gather"]["records_complete_on_rank0"]
+
+
+@pytest.mark.parametrize("extra", [("--gather", "rank0"), ("--gather", "all", "--records", "trajectory"), ("--pipeline", "3")],
+                         ids=["gather_rank0", "all_gather_trajectory", "three_lanes"])
+def test_bench_two_ranks_on_one_gpu(extra):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks on the
+    one GPU and gloo instead of RCCL (EMP_BENCH_BACKEND: RCCL refuses two ranks on a device): shards, the per-step pack on
+    the result stream, the gather on its own stream with the in-flight ring, barriers and the max-over-ranks time are the
+    code the 2/4/8-GPU runs execute.  Rank 0 prints the one JSON line; the records it gathered are complete."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--settle-steps", "4", "--scenes-per-gpu", "1024", "--no-cpu-baseline", *extra]
+    env = dict(os.environ, EMP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["total_scenes"] == 2048 and d["config"]["scenes_per_gpu"] == 1024
+    assert d["value"] > 1e4 and d["gather"]["records_complete_on_rank0"] is True      # (gloo moves the records through the host)
+    assert d["gather"]["mode"] == ("all" if "all" in extra else "rank0")
+    assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
