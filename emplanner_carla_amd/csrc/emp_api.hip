@@ -709,8 +709,9 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     KernelTimer t(ctx, "path_qp");
     if (cap <= 34) {                                                  // N, ns <= 32: two scenes per wavefront
         const size_t per_pair = 2 * ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words_pair()) * sizeof(double);
-        if ((rc = set_lds(ctx, cycle_qp_wave_kernel<32>, per_pair))) return rc;
-        hipLaunchKernelGGL(cycle_qp_wave_kernel<32>, dim3((B + 1) / 2), dim3(64), per_pair, ctx->stream, B, max_pts,
+        auto kern = ctx->pipe_mode == EMP_PIPELINE_STAGED ? cycle_qp_wave_kernel_tight : cycle_qp_wave_kernel<32>;
+        if ((rc = set_lds(ctx, kern, per_pair))) return rc;
+        hipLaunchKernelGGL(kern, dim3((B + 1) / 2), dim3(64), per_pair, ctx->stream, B, max_pts,
                            max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     } else {
         if ((rc = set_lds(ctx, cycle_qp_wave_kernel<64>, per_group))) return rc;

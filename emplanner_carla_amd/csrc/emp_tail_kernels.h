@@ -533,13 +533,8 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 // One scene per GROUP of G lanes (G = 32: two scenes per wavefront when cap <= 34 stations, else G = 64).
 // dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)  (G = 32: + path_qp_words_pair() instead)
 // ---------------------------------------------------------------------------------------------
-#ifdef EMP_QP_WAVES      // development switch: force the register budget of N wavefronts per SIMD
-#define EMP_QP_OCC __attribute__((amdgpu_waves_per_eu(EMP_QP_WAVES, EMP_QP_WAVES)))
-#else
-#define EMP_QP_OCC
-#endif
 template <int G>
-__global__ __launch_bounds__(64) EMP_QP_OCC void cycle_qp_wave_kernel(int B, int max_pts, int max_obs, int cap, QpDev Q,
+__device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, int cap, const QpDev& Q,
                                                            const double* __restrict__ dp_s,
                                                            const double* __restrict__ dp_l,
                                                            const int* __restrict__ dp_len,
@@ -661,6 +656,27 @@ __global__ __launch_bounds__(64) EMP_QP_OCC void cycle_qp_wave_kernel(int B, int
         }
     }
 }
+
+#define EMP_CYCLE_QP_PARAMS                                                                                         \
+    int B, int max_pts, int max_obs, int cap, QpDev Q, const double *__restrict__ dp_s, const double *__restrict__ dp_l, \
+        const int *__restrict__ dp_len, const double *__restrict__ obs_s, const double *__restrict__ obs_l,           \
+        const int *__restrict__ n_obs, const double *__restrict__ start, double *__restrict__ path_s,                  \
+        double *__restrict__ path_l, int *__restrict__ path_len, int *__restrict__ status
+#define EMP_CYCLE_QP_ARGS B, max_pts, max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status
+template <int G>
+__global__ __launch_bounds__(64) void cycle_qp_wave_kernel(EMP_CYCLE_QP_PARAMS) {
+    cycle_qp_body<G>(EMP_CYCLE_QP_ARGS);
+}
+// The same kernel held to 128 registers (four wavefronts per SIMD instead of three; 104 B of scratch per lane).  Alone it
+// is 7 % slower (153 against 143 us).  In the staged pipeline its wavefronts sit on the SIMDs for as long as their slowest
+// scene while the next batch's edge kernel looks for registers beside them: there the step gains 2 % (0.314 against
+// 0.321 ms, same box).  With whole cycles on lanes the chip is issue-bound and the spill instructions cost 5 %: the
+// launcher takes this form in staged mode only.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cycle_qp_wave_kernel_tight(EMP_CYCLE_QP_PARAMS) {
+    cycle_qp_body<32>(EMP_CYCLE_QP_ARGS);
+}
+#undef EMP_CYCLE_QP_PARAMS
+#undef EMP_CYCLE_QP_ARGS
 
 // monotone index walk of cal_proj_point from index 0 (ref path_planning.py:62-64: `while s_map[idx + 1] < s: idx += 1`);
 // *off_end when it runs past the end.  s_map is a cumulative chord length, i.e. non-decreasing, so the walk's stopping
