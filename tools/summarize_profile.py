@@ -46,7 +46,7 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 
 stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
 lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps {steps} --warmup {warmup}` on one MI355X ({scenes} scenes/GPU)", "",
-         f"`rocprofv3 --kernel-trace --stats` (all launches: {warmup} warm-up + {steps} timed + the per-kernel diagnostic pass):", "",
+         f"`rocprofv3 --kernel-trace --stats` (all launches: {warmup} warm-up steps and the untimed settling steps, {steps} timed, the per-kernel diagnostic pass):", "",
          "| kernel | calls | mean us | % of GPU time |", "|---|---|---|---|"]
 for r in stats:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
