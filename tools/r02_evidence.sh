@@ -21,9 +21,5 @@ rm -rf gpurun_out/prof_r02* gpurun_out/sq_r02*
 STEPS=100 WARMUP=10 bash tools/profile.sh r02a > gpurun_out/r02/profile_r02a.log 2>&1
 STEPS=30 WARMUP=5 BENCH_ARGS="--scenes-per-gpu 32768" bash tools/profile.sh r02b_32768 > gpurun_out/r02/profile_r02b.log 2>&1
 STEPS=10 WARMUP=3 BENCH_ARGS="--config cfg5" bash tools/profile.sh r02c_cfg5 > gpurun_out/r02/profile_r02c.log 2>&1
-STEPS=100 WARMUP=10 BENCH_ARGS="--scene-dist survey" bash tools/profile.sh r02d_survey > gpurun_out/r02/profile_r02d.log 2>&1
-bash tools/pmc_sq.sh r02a > gpurun_out/r02/sq_r02a.log 2>&1
-bash tools/pmc_sq.sh r02d_survey --scene-dist survey > gpurun_out/r02/sq_r02d.log 2>&1
-bash tools/pmc_sq.sh r02e_worst --scene-dist worst > gpurun_out/r02/sq_r02e.log 2>&1
-STEPS=8 WARMUP=2 bash tools/pmc_sq.sh r02c_cfg5 --config cfg5 > gpurun_out/r02/sq_r02c.log 2>&1
+bash tools/r02_evidence_counters.sh      # the survey profile and the SQ passes, each under its own time limit
 for f in gpurun_out/r02/bench_*.json; do echo "$f: $(cut -c1-230 $f)"; done
