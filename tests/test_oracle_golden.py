@@ -539,3 +539,38 @@ def test_increase_points_and_merge_ports_match_reference():
         np.testing.assert_array_equal(np.stack(be.port_path_speed_merge(*args)), g["merge_out"][b])
         merged += 1
     assert dense >= 30 and merged >= 30
+
+
+def test_dense_qp_oracle_on_squeezed_corridors_and_infeasible_problems():
+    """The checker's own regression (found by tools/parity_sweep.py): path QPs of benchmark scenes whose corridor is squeezed
+    between obstacles have KKT systems conditioned ~3e8; the dense interior point used to aim below their rounding floor,
+    walk on to NaN and report 10 of 2048 FEASIBLE problems as unsolved.  It must solve them (certificate against the
+    reference-built matrices), and an infeasible problem must come back as not solved, without an exception."""
+    cfg = S.CFG2
+    solved = 0
+    for seed, feasible in ((520, True), (523, True), (885, True), (4, None), (9, None), (22, None)):
+        b = S.make_batch([seed], cfg)
+        nk = int(b.n_obs[0])
+        out = op.plan_cycle(b.ref[0], tuple(b.origin_xy[0]), tuple(b.start_xy[0]), tuple(b.start_v[0]), tuple(b.start_a[0]),
+                            [tuple(o) for o in b.obs_xy[0, :nk]],
+                            dp_kwargs=dict(row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l,
+                                           sampling_res=cfg.sampling_res), obs_length=cfg.obs_length, obs_width=cfg.obs_width,
+                            verbose=False)
+        assert out["qp_status"] in ("optimal", "unknown")
+        if feasible:
+            assert out["qp_status"] == "optimal", f"seed {seed}"
+        if out["qp_status"] == "optimal":
+            H, f, G, h, A, bb = op.path_qp_matrices(out["l_min"], out["l_max"], out["start_l"], out["start_dl"], out["start_ddl"])
+            x = np.empty(3 * len(out["qp_l"]))
+            x[0::3], x[1::3], x[2::3] = out["qp_l"], out["qp_dl"], out["qp_ddl"]
+            cert = qp_dense.kkt_certificate(H, f, G, h, A, bb, x)
+            assert cert["stationarity"] < 1e-7 and cert["ineq_violation"] < 1e-8 and cert["eq_violation"] < 1e-8, (seed, cert)
+            solved += 1
+        else:
+            pass                                   # returned as not solved, not raised
+    assert solved >= 3
+    # a plainly infeasible QP (lower bound above upper bound everywhere) diverges; the solver reports it, it does not raise
+    n = 21
+    H, f, G, h, A, bb = op.path_qp_matrices(np.full(n, 3.0), np.full(n, -3.0), 0.0, 0.0, 0.0)
+    r = qp_dense.solve_qp(H, f, G, h, A, bb)
+    assert r.status == "unknown"
