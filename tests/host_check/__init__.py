@@ -29,6 +29,8 @@ def load():
     lib.hc_heading_kappa.argtypes = [p, i, p, p]
     lib.hc_s_map.restype = None
     lib.hc_s_map.argtypes = [p, i, d, d, p]
+    lib.hc_dot2.restype = None
+    lib.hc_dot2.argtypes = [i, p, p, p]
     lib.hc_match.restype = i
     lib.hc_match.argtypes = [p, i, d, d, i, i, i]
     lib.hc_st_edge_cost.restype = d

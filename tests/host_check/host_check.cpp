@@ -55,6 +55,10 @@ void hc_heading_kappa(const double* xy, int m, double* theta, double* kappa) { h
 
 void hc_s_map(const double* line, int n_ref, double ox, double oy, double* s_map) { s_map_build(line, n_ref, ox, oy, s_map); }
 
+void hc_dot2(int n, const double* a, const double* b, double* out) {     // a, b: [n][2]
+    for (int i = 0; i < n; ++i) out[i] = dot2(a[2 * i], a[2 * i + 1], b[2 * i], b[2 * i + 1]);
+}
+
 int hc_match(const double* line, int n_ref, double x, double y, int first, int step, int limit) {
     return match_scan(line, n_ref, x, y, first, step, limit);
 }

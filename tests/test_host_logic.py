@@ -333,3 +333,29 @@ def test_host_logic_under_address_and_undefined_behaviour_sanitizers():
     assert run.returncode == 0, run.stderr[-3000:]
     assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr, run.stderr[-3000:]
     assert "sanitize_main:" in run.stdout
+
+
+def test_projection_dot_product_rounds_like_numpy(hc):
+    """emp_frenet_core.h dot2 = fma(a1, b1, a0 * b0): bit for bit what numpy.dot returns for two 2-vectors on an x86 host
+    whose OpenBLAS accumulates with fused multiply-adds (the reference evaluates every projection with np.dot,
+    planning_utils.py:107, :443, :507, :546-578).  The fused form itself is checked against libm's fma on any host; numpy
+    only where its dot is of that form (another BLAS may round the plain way - that is the reference's host dependence,
+    DESIGN.md section 4)."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    n = 20000
+    a = np.ascontiguousarray(rng.normal(0, 30, (n, 2)))
+    b = np.ascontiguousarray(rng.normal(0, 1, (n, 2)))
+    out = np.zeros(n)
+    hc.hc_dot2(n, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fma.restype = ctypes.c_double
+    libm.fma.argtypes = [ctypes.c_double] * 3
+    fused = np.array([libm.fma(a[k, 1], b[k, 1], a[k, 0] * b[k, 0]) for k in range(n)])
+    np.testing.assert_array_equal(out, fused)
+    plain = a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]
+    assert (fused != plain).mean() > 0.1                       # the two forms really differ in the last bit
+    dots = np.array([np.dot(a[k], b[k]) for k in range(n)])
+    if (dots == plain).all():
+        pytest.skip("this host's numpy rounds 2-vector dot products the plain way")
+    np.testing.assert_array_equal(out, dots)
