@@ -151,7 +151,8 @@ def main():
     p = dp_params_from_cfg(cfg)
     M = max_path_points(p)
     dist_name = os.environ.get("SWEEP_SCENE_DIST", "corridor")      # corridor (default) | survey | worst: obstacle layout
-    b = S.make_batch(range(N_CY), cfg, dist=dist_name)
+    seed0 = int(os.environ.get("SWEEP_SEED0", "0"))            # first seed of the cycle part
+    b = S.make_batch(range(seed0, seed0 + N_CY), cfg, dist=dist_name)
     P = b.ref.shape[1]
     r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
                       n_ref=np.full(N_CY, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
@@ -162,13 +163,14 @@ def main():
     compared = 0
     worst = 0.0
     with ctx.Pool(NPROC) as pool:
-        for seed, ok, feas, want, extra in pool.imap_unordered(_port_scene, range(N_CY), chunksize=8):
+        for seed_abs, ok, feas, want, extra in pool.imap_unordered(_port_scene, range(seed0, seed0 + N_CY), chunksize=8):
+            seed = seed_abs - seed0              # row of the batch
             dev_ok = (int(r.status[seed]) & ~1) == 0
             if feas is not None and bool(r.status[seed] & 1) == feas:
                 feas_bad += 1
             if ok != dev_ok:
                 outcome += 1
-                details.append(dict(seed=seed, kind="outcome", port_qp=str(extra.get("qp_status")), port_smooth=str(extra.get("smooth_status")),
+                details.append(dict(seed=seed_abs, kind="outcome", port_qp=str(extra.get("qp_status")), port_smooth=str(extra.get("smooth_status")),
                                     device_status=int(r.status[seed])))
                 continue
             if not ok:
@@ -183,20 +185,20 @@ def main():
             e = max(float(err.max()), float(errk.max()))
             if extra.get("tie") and e > 1e-6:
                 beyond = np.maximum(err.max(axis=1), errk) > 1e-6
-                ties.append(dict(seed=seed, err=e, err_xy=float(err[:, :2].max()), points_beyond_1e6=[int(v) for v in np.nonzero(beyond)[0]]))
+                ties.append(dict(seed=seed_abs, err=e, err_xy=float(err[:, :2].max()), points_beyond_1e6=[int(v) for v in np.nonzero(beyond)[0]]))
                 compared += 1
                 continue
             worst = max(worst, e)
             if e > 1e-6:
                 k = int(r.path_len[seed])
                 ps, pll = extra["path_s"], extra["path_l"]
-                details.append(dict(seed=seed, kind="trajectory", err=e, err_xy=float(err[:, :2].max()), err_theta=float(err[:, 2].max()),
+                details.append(dict(seed=seed_abs, kind="trajectory", err=e, err_xy=float(err[:, :2].max()), err_theta=float(err[:, 2].max()),
                                     err_kappa=float(errk.max()), n=m, path_len_equal=bool(k == len(ps)),
                                     err_path_l=float(np.abs(r.path_l[seed, :k] - pll[:k]).max()) if k == len(ps) else None,
                                     err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
                                     worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
             compared += 1
-    report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
+    report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "first_seed": seed0, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
                        "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "worst_relative_error": worst,
                        "tolerance": 1e-6, "seconds": round(time.time() - t0, 1),
                        "tie_scenes_beyond_tolerance": sorted(ties, key=lambda d: d["seed"]),
