@@ -4,6 +4,8 @@ sweep path and the compiled ones), short and long lattices, different station sp
 
 DP: rows, densified path and status bit-exact against oracle/exact.py.  Full cycle: per-scene outcome and trajectory
 against the faithful port (oracle/ref_port.py) at 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,7 @@ from oracle import ref_port as op
 from tests.conftest import assert_rel
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("EMP_FUZZ_SCALE", "1"))       # the same tests on SCALE times as many scenes per lattice shape
 
 # sample_s is kept off the integers: the reference sizes its output with int(end_s - start_s)
 # (path_planning.py:398), which for an integer sample_s sits on the edge of a truncation and follows the last bit of
@@ -44,7 +47,7 @@ def _cfg(i):
 def test_dp_bit_exact_on_random_lattices(planner, i):
     from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points
     cfg = _cfg(i)
-    b = S.make_batch(range(40 * i, 40 * i + 24), cfg)
+    b = S.make_batch(range(40 * i * SCALE, 40 * i * SCALE + 24 * SCALE), cfg)
     p = dp_params_from_cfg(cfg)
     rows, mc, st = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
     xrows, xfeas, xpaths = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l,
@@ -64,7 +67,7 @@ def test_dp_bit_exact_on_random_lattices(planner, i):
 def test_cycle_vs_port_on_random_lattices(planner, i):
     from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params, max_path_points
     cfg = _cfg(i)
-    seeds = list(range(1000 + 10 * i, 1000 + 10 * i + 5))
+    seeds = list(range(1000 + 10 * i * SCALE, 1000 + 10 * i * SCALE + 5 * SCALE))
     b = S.make_batch(seeds, cfg)
     P = b.ref.shape[1]
     p = dp_params_from_cfg(cfg)

@@ -6,6 +6,8 @@ exception the reference raises; increase_points 1e-12 relative (the reference sq
 the kernel with a multiplication - see emp_st_backend_core.h) and bit-exact against the same arithmetic in NumPy;
 speed_QP: parity unpinned (the reference's call cannot run) - the kernel's minimiser is compared with the dense
 oracle's certified one at 1e-6 and checked against the constraints the reference builds."""
+import os
+
 import numpy as np
 import pytest
 
@@ -198,7 +200,7 @@ def test_back_end_fuzz_vs_port(pl):
     reference on the golden set): convex space and merge bit-exact, statuses equal to the exceptions raised."""
     from oracle import st_backend as be
     rng = np.random.default_rng(99)
-    B, K, P = 300, 12, 70
+    B, K, P = 300 * int(os.environ.get("EMP_FUZZ_SCALE", "1")), 12, 70     # EMP_FUZZ_SCALE: the same test on more cases
     dp_s = np.full((B, 16), np.nan)
     dp_t = np.full((B, 16), np.nan)
     idx2s = np.zeros((B, P))
