@@ -129,12 +129,12 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  *   EMP_PIPELINE_STAGED    two batches: the back stage (densified DP path, path QP, Cartesian tail) of call k runs on a
  *                          second stream while the front stage (projection, edge costs, sweep) of call k+1 runs on
  *                          emp_stream().  The front stages stay serial, so the sweep runs next to nothing but the end
- *                          of a back stage and keeps its share of the HBM roofline (0.33 ms per 4096-scene step, sweep
- *                          22 us).
+ *                          of a back stage and keeps its share of the HBM roofline (0.32 ms per 4096-scene step, sweep
+ *                          21 us).
  *   n = 2..EMP_PIPELINE_MAX  n batches on n lanes (a stream and a pool of temporaries each; ABI version 7): call k runs
  *                          whole on lane k mod n, behind everything queued on emp_stream() when it is issued, and the
- *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.285 ms
- *                          per step) at the price of every kernel's own duration (the sweep: 35-45 us).  Needs as many
+ *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.27 ms
+ *                          per step) at the price of every kernel's own duration (the sweep: 45 us).  Needs as many
  *                          hardware queues as streams: the library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless
  *                          the variable is already set (the HIP runtime reads it when it initialises; its default of 4
  *                          makes lanes share a queue and serialises them).
