@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Safety net (pytest-timeout, when installed): no single test may hold the suite for more than 15 minutes - a rendezvous
+    # that never completes or a wedged child process fails its test instead of hanging the run.
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900
 
 
 def load_golden(name):

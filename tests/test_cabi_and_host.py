@@ -2,6 +2,7 @@
 (no compute calls - there is no GPU here); host-side logic (scene generator, sharding, record packing,
 the world_size-2 gather over gloo)."""
 import ctypes
+import datetime
 import os
 import re
 import subprocess
@@ -82,13 +83,40 @@ def test_shard_ranges_cover_everything():
             assert s1 == s0 + c0
 
 
+def _free_port():
+    """A port nobody listens on right now (bind to 0, read it back): a pid-derived port can collide with a stranger's, and a
+    rendezvous on a taken port waits out torch's 30-minute default with the workers blocking pytest's exit."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_ranks(ctx, target, args_of_rank, world=2):
+    """Start one daemon process per rank, collect one queue item from each, always reap the processes."""
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(*args_of_rank(r), q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = dict(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return got
+
+
 def _worker(rank, world, port, total, width, q):
     import torch
     import torch.distributed as dist
     from emplanner_carla_amd.dist import gather_records, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     start, count = shard_range(total, rank, world)
     local = (torch.arange(start, start + count, dtype=torch.float64).reshape(-1, 1)
              * torch.ones(1, width, dtype=torch.float64) + torch.arange(width, dtype=torch.float64) * 1e-3)
@@ -103,16 +131,8 @@ def test_gather_records_world_size_2_gloo(total):
     """The N>1 result collection (equal and ragged shards) on CPU with the gloo backend."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + total
-    width = 5
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, width, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    port, width = _free_port(), 5
+    got = _run_ranks(ctx, _worker, lambda r: (r, 2, port, total, width))
     want = np.arange(total, dtype=np.float64).reshape(-1, 1) * np.ones((1, width)) + np.arange(width) * 1e-3
     for r in range(2):
         assert np.array_equal(got[r], want)
@@ -124,7 +144,7 @@ def _worker_dst(rank, world, port, total, width, q):
     from emplanner_carla_amd.dist import gather_records, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     start, count = shard_range(total, rank, world)
     local = torch.arange(start, start + count, dtype=torch.float64).reshape(-1, 1).repeat(1, width)
     local = local + torch.arange(width, dtype=torch.float64) * 1e-3
@@ -139,16 +159,8 @@ def test_gather_records_to_rank_0_world_size_2_gloo(total):
     """The gather proper (BASELINE: 'RCCL gather only'): rank 0 receives every block in scene order, rank 1 nothing."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + total
-    width = 5
-    procs = [ctx.Process(target=_worker_dst, args=(r, 2, port, total, width, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    port, width = _free_port(), 5
+    got = _run_ranks(ctx, _worker_dst, lambda r: (r, 2, port, total, width))
     want = np.arange(total, dtype=np.float64).reshape(-1, 1) * np.ones((1, width)) + np.arange(width) * 1e-3
     assert got[1] is None and np.array_equal(got[0], want)
 
@@ -178,7 +190,7 @@ def _worker_steps(rank, world, port, total, fields, dst, q):
     from emplanner_carla_amd.dist import StepGather, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     col, M = 6, 9
     start, count = shard_range(total, rank, world)
     stub = _StubPlanner(col, M)
@@ -205,15 +217,8 @@ def test_step_loop_of_the_many_scene_mode_world_size_2_gloo(total, fields, dst):
     import torch.multiprocessing as mp
     from emplanner_carla_amd.dist import path_capacity
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + total + (7 if fields == "trajectory" else 0) + (13 if dst is None else 0)
-    procs = [ctx.Process(target=_worker_steps, args=(r, 2, port, total, fields, dst, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    port = _free_port()
+    got = _run_ranks(ctx, _worker_steps, lambda r: (r, 2, port, total, fields, dst))
     col, M = 6, 9
     cap = path_capacity(M)
     want = _StubPlanner(col, M).plan_cycle(list(range(total)), 4)

@@ -78,7 +78,10 @@ def test_bench_two_ranks_on_one_gpu(extra):
     one GPU and gloo instead of RCCL (EMP_BENCH_BACKEND: RCCL refuses two ranks on a device): shards, the per-step pack on
     the result stream, the gather on its own stream with the in-flight ring, barriers and the max-over-ranks time are the
     code the 2/4/8-GPU runs execute.  Rank 0 prints the one JSON line; the records it gathered are complete."""
-    port = 29500 + (os.getpid() % 400)
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--settle-steps", "4", "--scenes-per-gpu", "1024", "--no-cpu-baseline", *extra]
