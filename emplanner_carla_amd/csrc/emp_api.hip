@@ -1446,6 +1446,8 @@ int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t 
     EMP_REQUIRE(ctx, p != nullptr, "speed dp params are NULL");
     EMP_REQUIRE(ctx, B >= 0 && max_obs >= 1 && max_obs <= st::kMaxObs, "bad sizes (max_obs must be in [1, 64])");
     EMP_REQUIRE(ctx, s_in && s_out && t_in && t_out && plan_start_s_dot && end_node && speed_s && speed_t, "NULL argument");
+    // ref :281 w_cost_obs ** (1.5 - d): complex for a negative base, and the reference fails on its next comparison
+    EMP_REQUIRE(ctx, !(p->w_cost_obs < 0.0), "w_cost_obs must not be negative");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
     Stage stg(ctx, where);
     int rc;
@@ -1464,11 +1466,33 @@ int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t 
     if ((rc = stg.out(end_node, (size_t)B * 2, &d_e, false))) return rc;
     if ((rc = stg.out(speed_s, (size_t)B * st::kCols, &d_ss, false))) return rc;
     if ((rc = stg.out(speed_t, (size_t)B * st::kCols, &d_tt, false))) return rc;
+    // heaviest scenes first (emp_st_kernels.h: st_count_kernel); pointless when every block is resident at once
+    int* d_order = nullptr;
+    static const bool no_order = getenv("EMP_ST_NO_ORDER") != nullptr;   // development A/B switch
+    if (B > 512 && !no_order) {
+        unsigned char* d_key;
+        int* d_hist;
+        if ((rc = stg.tmp<int>((size_t)B, &d_order))) return rc;
+        if ((rc = stg.tmp<unsigned char>((size_t)B, &d_key))) return rc;
+        if ((rc = stg.tmp<int>(2 * (size_t)kStKeys, &d_hist, true))) return rc;
+        KernelTimer t(ctx, "speed_dp_order");
+        hipLaunchKernelGGL(st_count_kernel, grid1(B, 256), dim3(256), 0, ctx->stream, B, max_obs, d_si, d_key, d_hist);
+        hipLaunchKernelGGL(st_scatter_kernel, grid1(B, 256), dim3(256), 0, ctx->stream, B, d_key, d_hist, d_hist + kStKeys, d_order);
+        EMP_LAUNCH_CHECK(ctx);
+    }
     if (B) {
         const StDev d = make_st_dev(p, B, max_obs);
         KernelTimer t(ctx, "speed_dp");
-        hipLaunchKernelGGL(speed_dp_kernel, dim3(B), dim3(kStBlock), speed_dp_lds_bytes(max_obs), ctx->stream, d, d_si, d_so,
-                           d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt);
+        static const bool v1 = getenv("EMP_ST_DP_V1") != nullptr;   // development A/B switch
+        if (v1)
+            hipLaunchKernelGGL(speed_dp_kernel_v1, dim3(B), dim3(kStBlock), speed_dp_v1_lds_bytes(max_obs), ctx->stream, d, d_si,
+                               d_so, d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt);
+        else if (max_obs <= 32)
+            hipLaunchKernelGGL(speed_dp_kernel<uint32_t>, dim3(B), dim3(kStBlock), speed_dp_lds_bytes(max_obs), ctx->stream, d,
+                               d_si, d_so, d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt, d_order);
+        else
+            hipLaunchKernelGGL(speed_dp_kernel<uint64_t>, dim3(B), dim3(kStBlock), speed_dp_lds_bytes(max_obs), ctx->stream, d,
+                               d_si, d_so, d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt, d_order);
         EMP_LAUNCH_CHECK(ctx);
     }
     return stg.finish();

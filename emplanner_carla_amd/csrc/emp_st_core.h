@@ -73,6 +73,18 @@ EMP_HD double pow_base(const PowBase& b, double y) {
     return fma(r, 0.6931471805599453 * tail, r);
 }
 
+// pow_base for the compacted pair lists of the speed DP kernel: no call into the general pow() (whose expansion
+// alone needs ~140 vector registers).  The exponent is in (0, 1) wherever the result is used (0.5 < d < 1.5), and
+// there w ** y of a base that is 0, +inf or NaN is the base itself; a negative base (complex in the reference, which
+// then fails on its next comparison) is refused by emp_speed_dp.
+EMP_HD double pow_base_flat(const PowBase& b, double y) {
+    const double p = y * b.lg_hi;
+    const double tail = fma(y, b.lg_hi, -p) + y * b.lg_lo;
+    const double r = exp2(p);
+    const double v = fma(r, 0.6931471805599453 * tail, r);
+    return b.lg_hi == b.lg_hi ? v : b.w;
+}
+
 // ref :274-284 (CalcCollisionCost)
 EMP_HD double collision_cost(const PowBase& w, double d) {
     const double a = fabs(d);
@@ -123,6 +135,69 @@ EMP_HD bool point_is_far(double s, double t, double s_in, double t_in, double s_
     const double cross = v1x * v3y - v1y * v3x;
     const double d33 = v3x * v3x + v3y * v3y;
     return outside ? m >= 2.25 : cross * cross > 2.2500001 * d33;
+}
+
+// point_cost without branches (the speed DP kernel runs it on compacted lists of (sample, obstacle) pairs, where the
+// lanes of a wavefront take both sides of every test): one sqrt and one division for every pair, the selects pick
+// what point_cost computes on its side of the branch - the same operations on the same operands, bit for bit.
+EMP_HD double point_cost_flat(const PowBase& w, double s, double t, double s_in, double t_in, double s_out, double t_out) {
+    const double v1x = s_in - s, v1y = t_in - t;
+    const double v2x = s_out - s, v2y = t_out - t;
+    const double v3x = v2x - v1x, v3y = v2y - v1y;
+    const double p = v1x * v3x + v1y * v3y;
+    const double q = v2x * v3x + v2y * v3y;
+    const bool outside = (p > 0.0 && q > 0.0) || (p < 0.0 && q < 0.0);
+    const double d11 = v1x * v1x + v1y * v1y;
+    const double d22 = v2x * v2x + v2y * v2y;
+    const double d33 = v3x * v3x + v3y * v3y;
+    const double cross = v1x * v3y - v1y * v3x;
+    const double r = sqrt(outside ? (d22 < d11 ? d22 : d11) : d33);
+    const double quot = fabs(cross) / r;
+    const double d = outside ? r : quot;
+    const double a = fabs(d);
+    const double mid = pow_base_flat(w, (0.5 - d) + 1.0);
+    return a < 0.5 ? w.w : ((0.5 < a && a < 1.5) ? mid : 0.0);
+}
+
+// Reach of one obstacle segment at a fixed time t: an interval (lo, hi) of s outside which point_cost is exactly 0.
+// The points within kPruneGap of the segment lie in the rectangle |n| < G, -G < l < len + G of the segment's own
+// frame (n across, l along; G = kPruneGap = 1.6 > the 1.5 reach of CalcCollisionCost, ref :281-282); at a fixed t
+// both conditions are intervals of s.  The 0.1 margin is ten orders of magnitude above the rounding of these few
+// operations.  A degenerate segment (NaN frame) or a non-finite bound keeps everything: (-inf, +inf).
+// Returns false when the interval is empty.
+EMP_HD bool reach_interval(double t, double s_in, double t_in, double ux, double uy, double len, double* lo, double* hi) {
+    const double G = kPruneGap, inf = INFINITY;
+    const double a = (t - t_in) * ux, b = (t - t_in) * uy, top = len + G;
+    double l1 = -inf, h1 = inf, l2 = -inf, h2 = inf;
+    bool empty = false;
+    if (!(ux == ux) || !(uy == uy) || !(top == top)) {
+        *lo = -inf;
+        *hi = inf;
+        return true;
+    }
+    if (uy != 0.0) {                       // |a - x uy| < G,  x = s - s_in
+        const double x1 = (a - G) / uy, x2 = (a + G) / uy;
+        l1 = fmin(x1, x2);
+        h1 = fmax(x1, x2);
+    } else if (!(fabs(a) < G)) {
+        empty = true;
+    }
+    if (ux != 0.0) {                       // -G < x ux + b < top
+        const double x1 = (-G - b) / ux, x2 = (top - b) / ux;
+        l2 = fmin(x1, x2);
+        h2 = fmax(x1, x2);
+    } else if (!(-G < b && b < top)) {
+        empty = true;
+    }
+    const double l = s_in + fmax(l1, l2), h = s_in + fmin(h1, h2);
+    if (!(l == l) || !(h == h)) {          // inf - inf and the like: keep everything
+        *lo = -inf;
+        *hi = inf;
+        return true;
+    }
+    *lo = empty ? inf : l;
+    *hi = empty ? -inf : h;
+    return !empty && l < h;
 }
 
 // Obstacle segments of one scene plus, per segment, its unit direction (ux, uy) in the (s, t) plane and its

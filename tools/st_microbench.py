@@ -21,6 +21,10 @@ pl = Planner(0)
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 sets = pl.st_graph(*[t(a) for a in o[:4]])
+if os.environ.get("ST_SORT"):                         # heaviest scenes first (most S-T obstacles): what LPT scheduling would buy
+    order = torch.argsort((~torch.isnan(sets[0])).sum(1), descending=os.environ["ST_SORT"] != "asc", stable=True)
+    sets = tuple(a[order].contiguous() for a in sets)
+    o = o[:4] + (o[4][order.cpu().numpy()],)
 v0 = t(o[4])
 live = float((~torch.isnan(sets[0])).sum().item()) / B
 pl.set_timing(True)
