@@ -18,6 +18,7 @@ constexpr int kCols = 16;         // ref :116
 constexpr int kStSamples = 5;     // ref :244
 constexpr int kMaxObs = 64;       // obstacle slots per scene the kernels accept (prune mask is 64 bits)
 constexpr double kPruneGap = 1.6; // > the 1.5 m reach of CalcCollisionCost, with room for rounding
+constexpr double kReachGap = 1.51;  // the same for st::reach_interval: its few operations round at 1e-13 of the values
 
 // ref :114 - s_list[idx]; np.arange yields start + i*step, exact for these values
 EMP_HD double s_list_at(int idx) {
@@ -160,13 +161,13 @@ EMP_HD double point_cost_flat(const PowBase& w, double s, double t, double s_in,
 }
 
 // Reach of one obstacle segment at a fixed time t: an interval (lo, hi) of s outside which point_cost is exactly 0.
-// The points within kPruneGap of the segment lie in the rectangle |n| < G, -G < l < len + G of the segment's own
-// frame (n across, l along; G = kPruneGap = 1.6 > the 1.5 reach of CalcCollisionCost, ref :281-282); at a fixed t
-// both conditions are intervals of s.  The 0.1 margin is ten orders of magnitude above the rounding of these few
+// The points within kReachGap of the segment lie in the rectangle |n| < G, -G < l < len + G of the segment's own
+// frame (n across, l along; G = kReachGap = 1.51 > the 1.5 reach of CalcCollisionCost, ref :281-282); at a fixed t
+// both conditions are intervals of s.  The 0.01 margin is ten orders of magnitude above the rounding of these few
 // operations.  A degenerate segment (NaN frame) or a non-finite bound keeps everything: (-inf, +inf).
 // Returns false when the interval is empty.
 EMP_HD bool reach_interval(double t, double s_in, double t_in, double ux, double uy, double len, double* lo, double* hi) {
-    const double G = kPruneGap, inf = INFINITY;
+    const double G = kReachGap, inf = INFINITY;
     const double a = (t - t_in) * ux, b = (t - t_in) * uy, top = len + G;
     double l1 = -inf, h1 = inf, l2 = -inf, h2 = inf;
     bool empty = false;

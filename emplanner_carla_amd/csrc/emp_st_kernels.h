@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kStBlock) void speed_dp_kernel_v1(StDev d, const do
 // the first minimum of its five candidates; lanes 0-39 then take the minimum over the eight partial results, the
 // lowest k winning ties (= the reference's ordered strict-< scan, ref :138-152).
 #ifndef EMP_ST_WAVES
-#define EMP_ST_WAVES 5          // wavefronts per SIMD the register allocation aims for (96 VGPRs; measured 4: 3.9 ms, 5: 2.9 ms per 4096 scenes)
+#define EMP_ST_WAVES 6          // wavefronts per SIMD the register allocation aims for (80 VGPRs + scratch; 4: 3.8 ms, 5: 2.5, 6: 2.4, 7: 2.35 per 4096 scenes)
 #endif
 constexpr int kStListCap = 256;   // list entries per wavefront (a longer list is processed in windows)
 constexpr int kStWaves = kStBlock / 64;
@@ -201,21 +201,30 @@ __device__ __forceinline__ void st_wave_handover() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ unsigned long long st_uniform64(unsigned long long v) {   // a wave-uniform value into scalar registers
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 struct StLds {   // carve-up of the dynamic LDS of speed_dp_kernel
     double *o_s_in, *o_s_out, *o_t_in, *o_t_out, *o_ux, *o_uy, *o_len;   // [max_obs] each, squeezed
     double* iv;       // [10][max_obs][2]  reach intervals (lo, hi): class 0 = regular edges, 1 = edges from the origin
+    double* node_c;   // [40][max_obs]     cost of the source NODES of a column against every obstacle (sample m = 1)
     double* t_tab;    // [10]              sample times of the two classes
+    double* s_tab;    // [40]              s of the grid rows
     double* part_c;   // [8][40]           partial minima
     double* p_cost;   // [2][40]           previous / current column
     double* p_sdot;   // [2][40]
     double* row0;     // [16]              cost of row 0 in every column (terminal search)
+    unsigned long long* colmask;   // [2][2] obstacles with a non-empty interval in the column: [column parity][class]
     double* list_s;   // [waves][cap]      sample s of a pair, overwritten by the pair's cost
     uint32_t* list_c; // [waves][cap]      obstacle | sample slot << 8
     unsigned char* part_k;  // [8][40]
     unsigned char* t_node;  // [40][16]
 };
 inline size_t speed_dp_lds_bytes(int max_obs) {
-    return (27 * (size_t)max_obs + 10 + kStParts * st::kRows + 4 * st::kRows + st::kCols + kStWaves * kStListCap) * sizeof(double) +
+    return ((27 + st::kRows) * (size_t)max_obs + 10 + st::kRows + kStParts * st::kRows + 4 * st::kRows + st::kCols + 4 +
+            kStWaves * kStListCap) * sizeof(double) +
            kStWaves * kStListCap * sizeof(uint32_t) + kStParts * st::kRows + st::kRows * st::kCols;
 }
 __device__ __forceinline__ StLds st_carve(double* lds, int max_obs) {
@@ -228,12 +237,15 @@ __device__ __forceinline__ StLds st_carve(double* lds, int max_obs) {
     L.o_uy = L.o_ux + max_obs;
     L.o_len = L.o_uy + max_obs;
     L.iv = L.o_len + max_obs;
-    L.t_tab = L.iv + 20 * max_obs;
-    L.part_c = L.t_tab + 10;
+    L.node_c = L.iv + 20 * max_obs;
+    L.t_tab = L.node_c + st::kRows * max_obs;
+    L.s_tab = L.t_tab + 10;
+    L.part_c = L.s_tab + st::kRows;
     L.p_cost = L.part_c + kStParts * st::kRows;
     L.p_sdot = L.p_cost + 2 * st::kRows;
     L.row0 = L.p_sdot + 2 * st::kRows;
-    L.list_s = L.row0 + st::kCols;
+    L.colmask = reinterpret_cast<unsigned long long*>(L.row0 + st::kCols);
+    L.list_s = L.row0 + st::kCols + 4;
     L.list_c = reinterpret_cast<uint32_t*>(L.list_s + kStWaves * kStListCap);
     L.part_k = reinterpret_cast<unsigned char*>(L.list_c + kStWaves * kStListCap);
     L.t_node = L.part_k + kStParts * st::kRows;
@@ -241,10 +253,9 @@ __device__ __forceinline__ StLds st_carve(double* lds, int max_obs) {
 }
 
 // The pairs of one list window, 64 at a time: entry p = (sample s, obstacle | sample slot << 8) becomes the pair's cost.
-// Out of line: the long sqrt / division / exp2 expansions then do not compete for registers with the state the
-// calling loop keeps (sample abscissae, pair masks, running minima).  obs = the seven squeezed obstacle arrays.
-__device__ __forceinline__ void st_cost_window(st::PowBase w, double* list_s, const uint32_t* list_c, const double* t_tab,
-                                            const double* obs, int max_obs, int n, int lane) {
+// obs = the seven squeezed obstacle arrays.
+__device__ __forceinline__ void st_cost_window(const st::PowBase& w, double* list_s, const uint32_t* list_c, const double* t_tab,
+                                               const double* obs, int max_obs, int n, int lane) {
 #pragma unroll 1
     for (int p = lane; p < n; p += 64) {
         const uint32_t code = list_c[p];
@@ -254,9 +265,16 @@ __device__ __forceinline__ void st_cost_window(st::PowBase w, double* list_s, co
     }
 }
 
-// reach intervals and sample times of destination column c, by `nthreads` lanes numbered `x0`
-__device__ __forceinline__ void st_column_intervals(const StLds& L, int max_obs, int n_live, int c, int x0, int nthreads) {
+// What waves 1-4 prepare for destination column c while wavefront 0 takes the previous column's minima (nothing here
+// depends on the DP state), by `nthreads` lanes numbered `x0`:
+//   * reach intervals of every obstacle at the ten sample times of the column, and the column's obstacle mask;
+//   * the cost of the column's 40 source NODES against every obstacle.  Sample m = 1 of an edge is its source node
+//     itself (ref :251-252 with i - 1 = 0: s0 + (k 0) dt = s0, t0 + 0 dt = t0) whatever the destination row: computed
+//     here once per (node, obstacle) instead of once per edge, and added by the edges in the reference's place in the
+//     order of additions (after the pairs of sample 0, obstacle by obstacle; the exact zeros change nothing).
+__device__ __forceinline__ void st_column_setup(const StDev& d, const StLds& L, int n_live, int c, int x0, int nthreads) {
     using namespace st;
+    const int MO = d.max_obs;
     const double t1 = t_of_col(c);
     for (int x = x0; x < 10 * n_live; x += nthreads) {
         const int slot = x / n_live, j = x - slot * n_live;
@@ -265,19 +283,34 @@ __device__ __forceinline__ void st_column_intervals(const StLds& L, int max_obs,
         const double dt = (t1 - t0) * 0.25;
         const double t = t0 + (double)(m - 1) * dt;
         double lo, hi;
-        reach_interval(t, L.o_s_in[j], L.o_t_in[j], L.o_ux[j], L.o_uy[j], L.o_len[j], &lo, &hi);
-        if (c == 0 && cls == 0) {   // the first column has no regular edges
+        bool some = reach_interval(t, L.o_s_in[j], L.o_t_in[j], L.o_ux[j], L.o_uy[j], L.o_len[j], &lo, &hi);
+        if (c == 0 && cls == 0) some = false;   // the first column has no regular edges
+        if (!some || m == 1) {                  // sample 1 goes through node_c (its obstacle still counts for the mask)
             lo = INFINITY;
             hi = -INFINITY;
         }
-        L.iv[(slot * max_obs + j) * 2] = lo;
-        L.iv[(slot * max_obs + j) * 2 + 1] = hi;
+        L.iv[(slot * MO + j) * 2] = lo;
+        L.iv[(slot * MO + j) * 2 + 1] = hi;
+        if (some) atomicOr(&L.colmask[(c & 1) * 2 + cls], (unsigned long long)1 << j);
     }
     if (x0 < 10) {
         const int cls = x0 / kStSamples, m = x0 - cls * kStSamples;
         const double t0 = cls ? 0.0 : t_of_col(c > 0 ? c - 1 : 0);
         const double dt = (t1 - t0) * 0.25;
         L.t_tab[x0] = t0 + (double)(m - 1) * dt;      // the expression of st::obs_cost, ref :251
+    }
+    // nodes: x = obstacle * 40 + row, so that a wavefront covers one or two obstacles and skips those out of reach in time
+    const double t_prev = c > 0 ? t_of_col(c - 1) : 0.0;
+    for (int x = x0; x < kRows * n_live; x += nthreads) {
+        const int j = x / kRows, k = x - j * kRows;
+        const double s = k == 0 ? 0.0 : L.s_tab[k];     // ref :208-212: source row 0 means "the origin"
+        const double t = k == 0 ? 0.0 : t_prev;
+        const double ti = L.o_t_in[j], to = L.o_t_out[j];
+        double cost = 0.0;
+        // a point farther than the 1.5 reach from the segment's time span costs exactly 0 (NaN keeps the exact path)
+        if (!(t < fmin(ti, to) - kPruneGap || t > fmax(ti, to) + kPruneGap))
+            cost = point_cost_flat(d.w.w_obs, s, t, L.o_s_in[j], ti, L.o_s_out[j], to);
+        L.node_c[k * MO + j] = cost;
     }
 }
 
@@ -311,33 +344,36 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             L.o_t_out[at] = g_t_out[ob + tid];
             obs_frame(L.o_s_in[at], L.o_t_in[at], L.o_s_out[at], L.o_t_out[at], &L.o_ux[at], &L.o_uy[at], &L.o_len[at]);
         }
-        if (tid == 0) n_live_s = __popcll(m);
+        if (tid == 0) {
+            n_live_s = __popcll(m);
+            L.colmask[0] = L.colmask[1] = L.colmask[2] = L.colmask[3] = 0;
+        }
     }
     const double v_origin = v_start[b];
-    if (tid < kRows) L.p_cost[kRows + tid] = 0.0;   // "previous column" of column 0: the origin, cost 0 (x + 0.0 == x)
+    if (tid < kRows) {
+        L.p_cost[kRows + tid] = 0.0;   // "previous column" of column 0: the origin, cost 0 (x + 0.0 == x)
+        L.s_tab[tid] = s_of_row(tid);
+    }
     __syncthreads();
     const int n_live = n_live_s;
-    st_column_intervals(L, MO, n_live, 0, tid, kStBlock);
+    st_column_setup(d, L, n_live, 0, tid, kStBlock);
 
     const int j = tid % kRows, kb = tid / kRows;
-    const double s1 = s_of_row(j);
+    const double s1 = L.s_tab[j];
     double* my_s = L.list_s + wave * kStListCap;
     uint32_t* my_c = L.list_c + wave * kStListCap;
     const size_t tb = (size_t)b * kRows * kCols;
 
 #pragma unroll 1
     for (int c = 0; c < kCols; ++c) {
-        __syncthreads();   // [B] intervals of column c, and the previous column's cost / speed, are in place
+        __syncthreads();   // [B] intervals / node costs of column c, and the previous column's cost / speed, are in place
         const int cur = c & 1, prev = cur ^ 1;
         const double t1 = t_of_col(c);
-        // obstacles with any non-empty interval in this column (wave-uniform)
-        unsigned long long colmask;
-        {
-            bool any = false;
-            if (lane < n_live)
-                for (int slot = 0; slot < 10; ++slot) any = any || L.iv[(slot * MO + lane) * 2] < L.iv[(slot * MO + lane) * 2 + 1];
-            colmask = __ballot(any);
-        }
+        // obstacles within reach of the column's regular edges, and of its edges from the origin (whose samples span
+        // the whole time from 0: nearly every obstacle); only wavefront 0 has lanes of the second kind (k == 0)
+        const unsigned long long mask_reg = st_uniform64(L.colmask[cur * 2]);
+        const unsigned long long mask_all = mask_reg | st_uniform64(L.colmask[cur * 2 + 1]);
+        if (tid == 0) L.colmask[prev * 2] = L.colmask[prev * 2 + 1] = 0;   // the next column's setup ORs into them after [C]
         double best = INFINITY;
         int best_k = 0;
         const int n_src = c == 0 ? 1 : kStSamples;   // five source rows per lane; only the origin in column 0
@@ -346,37 +382,47 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             const int k = kb + kStParts * i;          // interleaved: every wavefront sees source rows from the whole s range
             const bool active = c > 0 || tid < kRows;
             const bool from_origin = k == 0;          // ref :208-212 (and every edge of column 0, ref :125-131)
-            const double s0 = from_origin ? 0.0 : s_of_row(k);
+            const unsigned long long colmask = (wave == 0 && i == 0) ? mask_all : mask_reg;
+            const double s0 = from_origin ? 0.0 : L.s_tab[k];
             const double t0 = from_origin ? 0.0 : t_of_col(c - 1);
             const double v0 = from_origin ? v_origin : L.p_sdot[prev * kRows + k];
             const double dt = (t1 - t0) * 0.25;
-            const double ks = div_dt(s1 - s0, t1 - t0);
+            // (s1 - s0) / (t1 - t0): edges between grid columns have t1 - t0 == 0.5 exactly, a multiplication by 2; only
+            // edges from the origin divide, and only wavefront 0 has any (one wave-level branch, not a select)
+            double ks = (s1 - s0) * 2.0;
+            if (wave == 0 && i == 0) ks = div_dt(s1 - s0, t1 - t0);
             const int slot0 = from_origin ? kStSamples : 0;
             double s_m[kStSamples];
 #pragma unroll
             for (int m = 0; m < kStSamples; ++m) s_m[m] = s0 + (ks * (double)(m - 1)) * dt;   // ref :252
-            // ---- candidate pairs: lo < s_m < hi ------------------------------------------------------------
+            // ---- candidate pairs of samples 0, 2, 3, 4: lo < s_m < hi --------------------------------------
             MaskT mask[kStSamples];
 #pragma unroll
             for (int m = 0; m < kStSamples; ++m) mask[m] = 0;
-            if (colmask) {
-                const double* ivl = L.iv + (size_t)slot0 * MO * 2;
-                for (unsigned long long rest = colmask; rest; rest &= rest - 1) {
-                    const int jj = __builtin_amdgcn_readfirstlane(ctz64(rest));
+            const double* ivl = L.iv + (size_t)slot0 * MO * 2;
+            for (unsigned long long rest = colmask; rest; rest &= rest - 1) {
+                const int jj = ctz64(rest);
 #pragma unroll
-                    for (int m = 0; m < kStSamples; ++m) {
-                        const double lo = ivl[(m * MO + jj) * 2], hi = ivl[(m * MO + jj) * 2 + 1];
-                        if (active && s_m[m] > lo && s_m[m] < hi) mask[m] |= (MaskT)1 << jj;
-                    }
+                for (int m = 0; m < kStSamples; ++m) {
+                    if (m == 1) continue;
+                    const double lo = ivl[(m * MO + jj) * 2], hi = ivl[(m * MO + jj) * 2 + 1];
+                    if (active && s_m[m] > lo && s_m[m] < hi) mask[m] |= (MaskT)1 << jj;
                 }
             }
-            int cnt = 0;
+            const int cnt0 = sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[0]) : __popc((unsigned)mask[0]);
+            int cnt = cnt0;
 #pragma unroll
-            for (int m = 0; m < kStSamples; ++m) cnt += sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[m]) : __popc((unsigned)mask[m]);
+            for (int m = 2; m < kStSamples; ++m) cnt += sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[m]) : __popc((unsigned)mask[m]);
             const int incl = st_wave_incl_sum(cnt);
             const int total = __builtin_amdgcn_readlane(incl, 63);
             const int off = incl - cnt;
             double obs = 0.0;
+            bool nodes_done = false;
+            const double* my_nodes = L.node_c + k * MO;
+            auto add_nodes = [&]() {                  // sample 1: the source node against the column's obstacles, in order
+                for (unsigned long long rest = colmask; rest; rest &= rest - 1) obs = obs + my_nodes[ctz64(rest)];
+                nodes_done = true;
+            };
 #pragma unroll 1
             for (int base = 0; base < total; base += kStListCap) {
                 // ---- emit this window's pairs, each lane its own in (sample, obstacle) order ----------------
@@ -397,10 +443,13 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                 st_cost_window(d.w.w_obs, my_s, my_c, L.t_tab, L.o_s_in, MO, min(kStListCap, total - base), lane);
                 st_wave_handover();
                 // ---- ordered sum of the lane's own pairs (ref :249-269: sample outer, obstacle inner) -------
-                const int q1 = min(off + cnt - base, kStListCap);
-                for (int q = max(off - base, 0); q < q1; ++q) obs = obs + my_s[q];
+                const int lo0 = off - base, mid = lo0 + cnt0, hi0 = lo0 + cnt;
+                for (int q = max(lo0, 0); q < min(mid, kStListCap); ++q) obs = obs + my_s[q];          // sample 0
+                if (!nodes_done && mid <= kStListCap) add_nodes();                                      // sample 1
+                for (int q = max(mid, 0); q < min(hi0, kStListCap); ++q) obs = obs + my_s[q];          // samples 2-4
                 st_wave_handover();
             }
+            if (!nodes_done) add_nodes();
             double acc, ref;
             kinematic_cost(d.w, s0, t0, v0, s1, t1, &acc, &ref);
             const double cand = ((obs + acc) + ref) + L.p_cost[prev * kRows + k];
@@ -420,7 +469,7 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                 best_v = s1 / t1;                     // ref :129
             } else {
                 v = INFINITY;
-                for (int part = 0; part < kStParts; ++part) {   // ascending source rows, strict <: the first minimum
+                for (int part = 0; part < kStParts; ++part) {
                     const double x = L.part_c[part * kRows + tid];
                     const int xk = L.part_k[part * kRows + tid];
                     if (x < v || (x == v && xk < kk)) {   // the partial minima interleave the source rows: lowest k wins a tie
@@ -429,7 +478,7 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                     }
                 }
                 // ref :148-150: the stored speed uses the real source node, even for k == 0
-                if (v < INFINITY) best_v = (s1 - s_of_row(kk)) * 2.0;   // / (t1 - t_prev), exactly 0.5
+                if (v < INFINITY) best_v = (s1 - L.s_tab[kk]) * 2.0;   // / (t1 - t_prev), exactly 0.5
                 else {
                     best_v = 0.0;
                     kk = 0;
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             if (g_s_dot) g_s_dot[tb + tid * kCols + c] = best_v;
             if (g_node) g_node[tb + tid * kCols + c] = kk;
         } else if (tid >= 64 && c + 1 < kCols) {
-            st_column_intervals(L, MO, n_live, c + 1, tid - 64, kStBlock - 64);
+            st_column_setup(d, L, n_live, c + 1, tid - 64, kStBlock - 64);
         }
     }
     __syncthreads();
