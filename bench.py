@@ -435,11 +435,27 @@ def main():
             extra["dp_only"] = {"value": round(count / (dp_ms * 1e-3), 1), "unit": "DP plans/s per GPU",
                                 "source": "sum of the three DP kernels' mean durations in the diagnostic pass"}
         if wide and "speed_dp" in kernels:
+            # The S-T speed DP is FP64-issue bound with no HBM traffic to speak of (0.8 KB per scene).  SURVEY.md 8(d)'s
+            # algorithmic count, E_st (30 + 5 n_obs 45) flops per scene, prices every (sample, obstacle) pair, of which the
+            # kernel costs only the 8 % within reach: like roofline_dp_edge's it says little.  The counter-backed figures are
+            # what the kernel executed (committed SQ pass of the same kernel alone at this batch size).
             e_st = 40 + 15 * 40 * 40
-            extra["speed_dp"] = {"value": round(count / (kernels["speed_dp"] * 1e-3), 1), "unit": "S-T speed DPs/s per GPU",
-                                 "edges_per_dp": e_st, "bound": "fp64_valu_issue",
-                                 "hbm_bytes_per_scene": 16 * 4 * 8 + 8 + 2 * 16 * 8 + 8,
-                                 "source": "diagnostic pass; tables stay in LDS (emp_st_kernels.h)"}
+            flops = e_st * (30 + 5 * 16 * 45) * count
+            tf = flops / (kernels["speed_dp"] * 1e-3) / 1e12
+            e = {"kernel": "speed_dp_kernel", "bound": "fp64_valu_issue", "achieved": round(tf, 2),
+                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s (ALGORITHMIC flops with all 16 slots present; far fewer are executed)",
+                 "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops,
+                 "mean_launch_us": round(kernels["speed_dp"] * 1e3, 1), "speed_dps_per_s": round(count / (kernels["speed_dp"] * 1e-3), 1),
+                 "edges_per_dp": e_st, "hbm_bytes_per_scene": 16 * 4 * 8 + 8 + 2 * 16 * 8 + 8,
+                 "source": "diagnostic pass after the timed region (one batch in flight); tables stay in LDS (emp_st_kernels.h)"}
+            cprof = committed_profile("speed_dp_counters", scenes_per_gpu=count, obstacle_slots=16)
+            if cprof:
+                e.update(executed_wave_instructions_valu=cprof["insts_valu"], active_lane_frac=cprof["lanes_active_frac"],
+                         executed_lane_ops=int(cprof["insts_valu"] * 64 * cprof["lanes_active_frac"]),
+                         valu_issue_busy_frac=cprof["valu_issue_busy_frac"],
+                         useful_issue_frac=round(cprof["valu_issue_busy_frac"] * cprof["lanes_active_frac"], 3),
+                         mean_waves_per_simd=cprof["mean_waves_per_simd"], counters_source=cprof["source"])
+            extra["roofline_speed_dp"] = e
         value = total * args.steps / elapsed
         gather_note = ""
         if world > 1:
@@ -447,6 +463,10 @@ def main():
         line = {
             "metric": ("planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)" if not wide else
                        "planning cycles/sec (DP+QP on the 120x21 S-L lattice, 16 obs, + S-T speed DP 40x16, 16 dynamic obstacles)"),
+            "metric_note": "value counts every scene of the batch: each one runs the whole cycle, and the scenes whose path QP "
+                           "turns out infeasible (walls and blocked corridors the generator puts there on purpose; "
+                           "scenes_fully_planned_frac) are refused with a status bit at the end of it.  "
+                           "fully_planned_cycles_per_s counts only the scenes planned to the end",
             "value": round(value, 1),
             "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "untimed_steps_before_the_timed_region": args.warmup + settle,

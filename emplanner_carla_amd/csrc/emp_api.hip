@@ -1483,11 +1483,7 @@ int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t 
     if (B) {
         const StDev d = make_st_dev(p, B, max_obs);
         KernelTimer t(ctx, "speed_dp");
-        static const bool v1 = getenv("EMP_ST_DP_V1") != nullptr;   // development A/B switch
-        if (v1)
-            hipLaunchKernelGGL(speed_dp_kernel_v1, dim3(B), dim3(kStBlock), speed_dp_v1_lds_bytes(max_obs), ctx->stream, d, d_si,
-                               d_so, d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt);
-        else if (max_obs <= 32)
+        if (max_obs <= 32)
             hipLaunchKernelGGL(speed_dp_kernel<uint32_t>, dim3(B), dim3(kStBlock), speed_dp_lds_bytes(max_obs), ctx->stream, d,
                                d_si, d_so, d_ti, d_to, d_v, d_c, d_sd, d_n, d_e, d_ss, d_tt, d_order);
         else

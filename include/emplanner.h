@@ -420,7 +420,9 @@ int emp_st_graph(emp_ctx* ctx, int32_t B, int32_t max_obs, const double* obs_s, 
  * The reference raises IndexError in its backtrack (float row index) and aliases its two output arrays (:156);
  * here the predecessor is an integer and speed_s / speed_t [B][16] are separate (NaN after the terminal column).
  * cost, s_dot [B][40][16] doubles and node [B][40][16] int32 are the reference's dp_st_cost / dp_st_s_dot /
- * dp_st_node; each may be NULL.  end_node [B][2] = (row, col) of the terminal node, (-1, -1) if every cost is NaN. */
+ * dp_st_node; each may be NULL.  end_node [B][2] = (row, col) of the terminal node, (-1, -1) if every cost is NaN.
+ * A negative w_cost_obs is refused (EMP_ERR_ARG): w ** (1.5 - d) (:281) is complex there and the reference fails on its
+ * next comparison.  Scenes are independent; the order in which the library runs them (heaviest first) shows in nothing. */
 int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t max_obs, const double* s_in,
                  const double* s_out, const double* t_in, const double* t_out, const double* plan_start_s_dot,
                  double* cost, double* s_dot, int32_t* node, int32_t* end_node, double* speed_s, double* speed_t,

@@ -35,6 +35,8 @@ def load():
     lib.hc_match.argtypes = [p, i, d, d, i, i, i]
     lib.hc_st_edge_cost.restype = d
     lib.hc_st_edge_cost.argtypes = [p, p, i, p, p, p, p, p]
+    lib.hc_st_reach.restype = None
+    lib.hc_st_reach.argtypes = [i, d, p, p, p, p, p, p]
     lib.hc_st_graph.restype = None
     lib.hc_st_graph.argtypes = [i] + [p] * 8
     lib.hc_st_grid.restype = None

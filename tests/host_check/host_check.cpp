@@ -73,6 +73,25 @@ double hc_st_edge_cost(const double* w4, const double* edge5, int n_obs, const d
     return st::edge_cost(w, edge5[0], edge5[1], edge5[2], edge5[3], edge5[4], set, obs);
 }
 
+// speed DP kernel, round 3: the branch-free pair cost against the reference-order one, and whether the sample lies inside
+// the segment's reach interval at its time (it must whenever the pair costs anything)
+void hc_st_reach(int n, double w_obs, const double* seg4, const double* pt2, double* cost, double* cost_flat, int* inside,
+                 double* lo_hi) {
+    const st::PowBase w = st::make_pow_base(w_obs);
+    for (int i = 0; i < n; ++i) {
+        const double s_in = seg4[4 * i], t_in = seg4[4 * i + 1], s_out = seg4[4 * i + 2], t_out = seg4[4 * i + 3];
+        const double s = pt2[2 * i], t = pt2[2 * i + 1];
+        cost[i] = st::point_cost(w, s, t, s_in, t_in, s_out, t_out);
+        cost_flat[i] = st::point_cost_flat(w, s, t, s_in, t_in, s_out, t_out);
+        double ux, uy, len, lo, hi;
+        st::obs_frame(s_in, t_in, s_out, t_out, &ux, &uy, &len);
+        st::reach_interval(t, s_in, t_in, ux, uy, len, &lo, &hi);
+        inside[i] = s > lo && s < hi;
+        lo_hi[2 * i] = lo;
+        lo_hi[2 * i + 1] = hi;
+    }
+}
+
 void hc_st_graph(int n, const double* s, const double* l, const double* sd, const double* ld, double* s_in, double* s_out,
                  double* t_in, double* t_out) {
     st::st_graph(n, s, l, sd, ld, s_in, s_out, t_in, t_out);

@@ -105,6 +105,43 @@ def test_speed_dp_batch_vs_exact_oracle(pl):
         np.testing.assert_array_equal(res.speed_t[b, :c + 1], st_speed.grid()[1][:c + 1])
 
 
+def test_speed_dp_large_batch_takes_the_heaviest_first_path(pl):
+    """Beyond 512 scenes the launcher sorts the scenes by obstacle count (heaviest blocks first) and block i takes scene
+    order[i]: every scene's result must equal what it gets in a small batch (no ordering), bit for bit, and the
+    exact oracle's on a sample."""
+    from emplanner_carla_amd import scenes as S
+    from oracle import st_speed
+    B = 1536
+    o = S.make_dynamic_batch(range(5000, 5000 + B))
+    sets = pl.st_graph(*o[:4])
+    big = pl.speed_dp(_params(), *sets, o[4])
+    for lo in range(0, B, 384):
+        sl = slice(lo, lo + 384)
+        small = pl.speed_dp(_params(), *[a[sl] for a in sets], o[4][sl])
+        for name in ("cost", "s_dot", "node", "end_node", "speed_s", "speed_t"):
+            np.testing.assert_array_equal(getattr(big, name)[sl], getattr(small, name), err_msg=f"{name}, scenes {lo}..")
+    pick = np.arange(0, B, 48)
+    ex = st_speed.exact_speed_dp(*[a[pick] for a in sets], o[4][pick])
+    assert_rel(big.cost[pick], ex["cost"], 1e-12, scale=1.0)
+    np.testing.assert_array_equal(big.node[pick], ex["node"])
+    np.testing.assert_array_equal(big.end_node[pick], ex["end"])
+
+
+def test_speed_dp_refuses_a_negative_obstacle_weight(pl):
+    """w_cost_obs ** (1.5 - d) is complex for a negative base and the reference fails on its next comparison
+    (speed_planning_test.py:281); the library refuses the call."""
+    nan16 = np.full((1, 16), np.nan)
+    with pytest.raises(Exception):
+        pl.speed_dp(_params(w_cost_obs=-1.0), nan16, nan16, nan16, nan16, np.zeros(1))
+    res = pl.speed_dp(_params(w_cost_obs=0.0), np.full((1, 16), 10.0), np.full((1, 16), 20.0), np.full((1, 16), 1.0),
+                      np.full((1, 16), 5.0), np.array([5.0]))        # 0 ** y = 0: a legal, obstacle-blind run
+    from oracle import st_speed
+    ex = st_speed.exact_speed_dp(np.full((1, 16), 10.0), np.full((1, 16), 20.0), np.full((1, 16), 1.0), np.full((1, 16), 5.0),
+                                 np.array([5.0]), w_cost_obs=0.0)
+    np.testing.assert_array_equal(res.cost, ex["cost"])
+    np.testing.assert_array_equal(res.node, ex["node"])
+
+
 def test_speed_dp_device_pointers_and_no_tables(pl):
     import torch
     from emplanner_carla_amd import scenes as S

@@ -252,6 +252,44 @@ def test_st_core_pruning_is_exact(hc):
     assert worst <= 1e-13
 
 
+def test_st_core_reach_interval_and_flat_pair_cost(hc):
+    """The two pieces the round-3 speed DP kernel adds (emp_st_core.h): the branch-free pair cost equals the reference-order
+    one bit for bit, and a pair that costs anything lies strictly inside the segment's reach interval at its sample time
+    (so skipping everything outside the interval never changes a result).  Points are drawn around the 1.5 m reach, at
+    the segment's ends, along it, and against steep, flat, short and degenerate segments."""
+    rng = np.random.default_rng(23)
+    n = 400000
+    s_in = rng.uniform(0, 55, n)
+    t_in = rng.uniform(0, 7, n)
+    kind = rng.integers(0, 6, n)
+    ds = np.where(kind == 0, 0.0, rng.uniform(-30, 30, n))               # stationary in s
+    dt = np.where(kind == 1, rng.uniform(1e-9, 1e-3, n), rng.uniform(0.2, 8, n))   # nearly instantaneous
+    ds = np.where(kind == 2, rng.uniform(-1e-6, 1e-6, n), ds)
+    both = kind == 3                                                      # degenerate: a point
+    ds = np.where(both, 0.0, ds)
+    dt = np.where(both, 0.0, dt)
+    s_out, t_out = s_in + ds, t_in + dt
+    # a point at parameter u along the segment, offset by r across it (or beyond an end)
+    u = rng.uniform(-0.3, 1.3, n)
+    r = np.where(rng.uniform(size=n) < 0.7, rng.uniform(1.3, 1.7, n), rng.uniform(0, 3, n)) * rng.choice([-1.0, 1.0], n)
+    L = np.hypot(ds, dt)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        nx, ny = np.where(L > 0, -dt / L, 1.0), np.where(L > 0, ds / L, 0.0)
+    pt = np.stack([s_in + u * ds + r * nx, t_in + u * dt + r * ny], axis=1)
+    seg = np.ascontiguousarray(np.stack([s_in, t_in, s_out, t_out], axis=1))
+    pt = np.ascontiguousarray(pt)
+    cost, flat, lohi = np.zeros(n), np.zeros(n), np.zeros((n, 2))
+    inside = np.zeros(n, np.int32)
+    ptr = lambda a: a.ctypes.data
+    hc.hc_st_reach(n, 10000000.0, ptr(seg), ptr(pt), ptr(cost), ptr(flat), ptr(inside), ptr(lohi))
+    assert np.array_equal(cost, flat, equal_nan=True), "point_cost_flat differs from point_cost"
+    costly = cost != 0.0
+    assert costly.sum() > 0.2 * n and (~costly).sum() > 0.2 * n          # both sides of the reach are sampled
+    assert inside[costly].all(), "a pair with a cost lies outside its reach interval"
+    # and the interval is not vacuous: most free pairs that lie across the segment's band are outside it
+    assert (inside[~costly] == 0).mean() > 0.5
+
+
 # --------------------------------------------------------------------------------------
 # S-T speed planning back end: the scalar core the kernels call (emp_st_backend_core.h) against the reference's
 # golden vectors and oracle/st_backend.py - no GPU involved

@@ -30,6 +30,7 @@ CHUNK = 16 if os.environ.get("SWEEP_DP_CFG") == "cfg5" else 256     # scenes per
 ST_CHUNK = 32
 N_ST = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 N_FE = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
+PARTS = set(os.environ.get("SWEEP_PARTS", "dp,cycle,st,fe").split(","))   # which parts run
 
 
 def _dp_cfg():
@@ -127,147 +128,157 @@ def main():
     report = {"config": cfg.name, "processes": NPROC}
     ctx = mp.get_context("spawn")
     # ---- DP, bit for bit
-    t0 = time.time()
-    bad = dict(rows=0, status=0, length=0, path=0)
-    infeasible = 0
-    with ctx.Pool(NPROC) as pool:
-        for lo, xrows, xfeas, xs, xl in pool.imap_unordered(_exact_chunk, range(0, N_DP, CHUNK)):
-            b = S.make_batch(range(lo, lo + CHUNK), cfg)
-            rows, mc, st = pl.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
-            ps, pll, ln, st2 = pl.dp_enrich(p, rows, b.sl_start, M)
-            bad["rows"] += int((rows != xrows).any(axis=1).sum())
-            bad["status"] += int((((st & 1) == 1) != ~xfeas).sum())
-            infeasible += int((~xfeas).sum())
-            for k in range(CHUNK):
-                if ln[k] != len(xs[k]):
-                    bad["length"] += 1
-                elif not (np.array_equal(ps[k, :ln[k]], xs[k]) and np.array_equal(pll[k, :ln[k]], xl[k])):
-                    bad["path"] += 1
-    report["dp"] = {"config": cfg.name, "scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
-    print("DP  ", json.dumps(report["dp"]), flush=True)
+    if "dp" in PARTS:
+        t0 = time.time()
+        bad = dict(rows=0, status=0, length=0, path=0)
+        infeasible = 0
+        with ctx.Pool(NPROC) as pool:
+            for lo, xrows, xfeas, xs, xl in pool.imap_unordered(_exact_chunk, range(0, N_DP, CHUNK)):
+                b = S.make_batch(range(lo, lo + CHUNK), cfg)
+                rows, mc, st = pl.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+                ps, pll, ln, st2 = pl.dp_enrich(p, rows, b.sl_start, M)
+                bad["rows"] += int((rows != xrows).any(axis=1).sum())
+                bad["status"] += int((((st & 1) == 1) != ~xfeas).sum())
+                infeasible += int((~xfeas).sum())
+                for k in range(CHUNK):
+                    if ln[k] != len(xs[k]):
+                        bad["length"] += 1
+                    elif not (np.array_equal(ps[k, :ln[k]], xs[k]) and np.array_equal(pll[k, :ln[k]], xl[k])):
+                        bad["path"] += 1
+        report["dp"] = {"config": cfg.name, "scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
+        print("DP  ", json.dumps(report["dp"]), flush=True)
     # ---- whole cycle against the port (SWEEP_CYCLE_CFG = cfg2 (default) | default | cfg1 picks the lattice)
-    t0 = time.time()
-    cfg = _cycle_cfg()
-    p = dp_params_from_cfg(cfg)
-    M = max_path_points(p)
-    dist_name = os.environ.get("SWEEP_SCENE_DIST", "corridor")      # corridor (default) | survey | worst: obstacle layout
-    seed0 = int(os.environ.get("SWEEP_SEED0", "0"))            # first seed of the cycle part
-    b = S.make_batch(range(seed0, seed0 + N_CY), cfg, dist=dist_name)
-    P = b.ref.shape[1]
-    r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
-                      n_ref=np.full(N_CY, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
-                      start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
-    outcome = feas_bad = length = 0
-    details = []
-    ties = []
-    compared = 0
-    worst = 0.0
-    with ctx.Pool(NPROC) as pool:
-        for seed_abs, ok, feas, want, extra in pool.imap_unordered(_port_scene, range(seed0, seed0 + N_CY), chunksize=8):
-            seed = seed_abs - seed0              # row of the batch
-            dev_ok = (int(r.status[seed]) & ~1) == 0
-            if feas is not None and bool(r.status[seed] & 1) == feas:
-                feas_bad += 1
-            if ok != dev_ok:
-                outcome += 1
-                details.append(dict(seed=seed_abs, kind="outcome", port_qp=str(extra.get("qp_status")), port_smooth=str(extra.get("smooth_status")),
-                                    device_status=int(r.status[seed])))
-                continue
-            if not ok:
-                continue
-            m = int(r.traj_len[seed])
-            if m != len(want):
-                length += 1
-                continue
-            got = r.traj[seed, :m]
-            err = np.abs(got[:, :3] - want[:, :3]) / np.maximum(np.abs(want[:, :3]), 1.0)
-            errk = np.abs(got[:, 3] - want[:, 3]) / np.maximum(np.abs(want[:, 3]), 1e-2)
-            e = max(float(err.max()), float(errk.max()))
-            if extra.get("tie") and e > 1e-6:
-                beyond = np.maximum(err.max(axis=1), errk) > 1e-6
-                ties.append(dict(seed=seed_abs, err=e, err_xy=float(err[:, :2].max()), points_beyond_1e6=[int(v) for v in np.nonzero(beyond)[0]]))
+    if "cycle" in PARTS:
+        t0 = time.time()
+        cfg = _cycle_cfg()
+        p = dp_params_from_cfg(cfg)
+        M = max_path_points(p)
+        dist_name = os.environ.get("SWEEP_SCENE_DIST", "corridor")      # corridor (default) | survey | worst: obstacle layout
+        seed0 = int(os.environ.get("SWEEP_SEED0", "0"))            # first seed of the cycle part
+        b = S.make_batch(range(seed0, seed0 + N_CY), cfg, dist=dist_name)
+        P = b.ref.shape[1]
+        r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
+                          n_ref=np.full(N_CY, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
+                          start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+        outcome = feas_bad = length = 0
+        details = []
+        ties = []
+        compared = 0
+        worst = 0.0
+        with ctx.Pool(NPROC) as pool:
+            for seed_abs, ok, feas, want, extra in pool.imap_unordered(_port_scene, range(seed0, seed0 + N_CY), chunksize=8):
+                seed = seed_abs - seed0              # row of the batch
+                dev_ok = (int(r.status[seed]) & ~1) == 0
+                if feas is not None and bool(r.status[seed] & 1) == feas:
+                    feas_bad += 1
+                if ok != dev_ok:
+                    outcome += 1
+                    details.append(dict(seed=seed_abs, kind="outcome", port_qp=str(extra.get("qp_status")), port_smooth=str(extra.get("smooth_status")),
+                                        device_status=int(r.status[seed])))
+                    continue
+                if not ok:
+                    continue
+                m = int(r.traj_len[seed])
+                if m != len(want):
+                    length += 1
+                    continue
+                got = r.traj[seed, :m]
+                err = np.abs(got[:, :3] - want[:, :3]) / np.maximum(np.abs(want[:, :3]), 1.0)
+                errk = np.abs(got[:, 3] - want[:, 3]) / np.maximum(np.abs(want[:, 3]), 1e-2)
+                e = max(float(err.max()), float(errk.max()))
+                if extra.get("tie") and e > 1e-6:
+                    beyond = np.maximum(err.max(axis=1), errk) > 1e-6
+                    ties.append(dict(seed=seed_abs, err=e, err_xy=float(err[:, :2].max()), points_beyond_1e6=[int(v) for v in np.nonzero(beyond)[0]]))
+                    compared += 1
+                    continue
+                worst = max(worst, e)
+                if e > 1e-6:
+                    k = int(r.path_len[seed])
+                    ps, pll = extra["path_s"], extra["path_l"]
+                    details.append(dict(seed=seed_abs, kind="trajectory", err=e, err_xy=float(err[:, :2].max()), err_theta=float(err[:, 2].max()),
+                                        err_kappa=float(errk.max()), n=m, path_len_equal=bool(k == len(ps)),
+                                        err_path_l=float(np.abs(r.path_l[seed, :k] - pll[:k]).max()) if k == len(ps) else None,
+                                        err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
+                                        worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
                 compared += 1
-                continue
-            worst = max(worst, e)
-            if e > 1e-6:
-                k = int(r.path_len[seed])
-                ps, pll = extra["path_s"], extra["path_l"]
-                details.append(dict(seed=seed_abs, kind="trajectory", err=e, err_xy=float(err[:, :2].max()), err_theta=float(err[:, 2].max()),
-                                    err_kappa=float(errk.max()), n=m, path_len_equal=bool(k == len(ps)),
-                                    err_path_l=float(np.abs(r.path_l[seed, :k] - pll[:k]).max()) if k == len(ps) else None,
-                                    err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
-                                    worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
-            compared += 1
-    report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "first_seed": seed0, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
-                       "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "worst_relative_error": worst,
-                       "tolerance": 1e-6, "seconds": round(time.time() - t0, 1),
-                       "tie_scenes_beyond_tolerance": sorted(ties, key=lambda d: d["seed"]),
-                       "details": sorted(details, key=lambda d: d["seed"])}
-    print("cycle", json.dumps({k: v for k, v in report["cycle"].items() if k not in ("details", "tie_scenes_beyond_tolerance")}), flush=True)
-    for d in report["cycle"]["tie_scenes_beyond_tolerance"]:
-        print("    tie:", json.dumps(d), flush=True)
-    for d in report["cycle"]["details"]:
-        print("   ", json.dumps(d), flush=True)
+        report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "first_seed": seed0, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
+                           "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "worst_relative_error": worst,
+                           "tolerance": 1e-6, "seconds": round(time.time() - t0, 1),
+                           "tie_scenes_beyond_tolerance": sorted(ties, key=lambda d: d["seed"]),
+                           "details": sorted(details, key=lambda d: d["seed"])}
+        print("cycle", json.dumps({k: v for k, v in report["cycle"].items() if k not in ("details", "tie_scenes_beyond_tolerance")}), flush=True)
+        for d in report["cycle"]["tie_scenes_beyond_tolerance"]:
+            print("    tie:", json.dumps(d), flush=True)
+        for d in report["cycle"]["details"]:
+            print("   ", json.dumps(d), flush=True)
     # ---- S-T speed DP (config 5's second half) against oracle/st_speed.py exact_*
-    t0 = time.time()
-    from emplanner_carla_amd.api import speed_dp_params
-    sdp = speed_dp_params()
-    g_bad = c_bad = e_bad = 0
-    node_mis = node_tot = 0
-    worst_c = 0.0
-    with ctx.Pool(NPROC) as pool:
-        for lo, xsets, xcost, xnode, xend, xss in pool.imap_unordered(_st_chunk, range(0, N_ST, ST_CHUNK)):
-            o = S.make_dynamic_batch(range(lo, lo + ST_CHUNK))
-            sets = pl.st_graph(*o[:4])
-            g_bad += int(sum(not np.array_equal(sets[i], xsets[i], equal_nan=True) for i in range(4)))
-            res = pl.speed_dp(sdp, *sets, o[4])
-            fin = np.isfinite(xcost)
-            c_bad += int((np.isfinite(res.cost) != fin).sum())
-            rel = np.abs(res.cost[fin] - xcost[fin]) / np.maximum(np.abs(xcost[fin]), 1.0)
-            worst_c = max(worst_c, float(rel.max(initial=0.0)))
-            node_mis += int((res.node != xnode).sum())
-            node_tot += int(xnode.size)
-            same = (res.node == xnode).all(axis=(1, 2))
-            e_bad += int((res.end_node[same] != xend[same]).any(axis=1).sum())
-            e_bad += int((~np.isclose(res.speed_s[same], xss[same], rtol=0, atol=0, equal_nan=True)).any(axis=1).sum())
-    report["speed_dp"] = {"scenes": N_ST, "st_graph_arrays_not_bit_equal": g_bad, "cost_finiteness_mismatch": c_bad,
-                          "worst_relative_cost_error": worst_c, "cost_tolerance": 1e-12, "node_mismatch": node_mis, "nodes": node_tot,
-                          "end_or_path_mismatch_where_tables_equal": e_bad, "seconds": round(time.time() - t0, 1)}
-    print("S-T ", json.dumps(report["speed_dp"]), flush=True)
+    if "st" in PARTS:
+        t0 = time.time()
+        from emplanner_carla_amd.api import speed_dp_params
+        sdp = speed_dp_params()
+        g_bad = c_bad = e_bad = 0
+        node_mis = node_tot = 0
+        worst_c = 0.0
+        with ctx.Pool(NPROC) as pool:
+            for lo, xsets, xcost, xnode, xend, xss in pool.imap_unordered(_st_chunk, range(0, N_ST, ST_CHUNK)):
+                o = S.make_dynamic_batch(range(lo, lo + ST_CHUNK))
+                sets = pl.st_graph(*o[:4])
+                g_bad += int(sum(not np.array_equal(sets[i], xsets[i], equal_nan=True) for i in range(4)))
+                res = pl.speed_dp(sdp, *sets, o[4])
+                fin = np.isfinite(xcost)
+                c_bad += int((np.isfinite(res.cost) != fin).sum())
+                rel = np.abs(res.cost[fin] - xcost[fin]) / np.maximum(np.abs(xcost[fin]), 1.0)
+                worst_c = max(worst_c, float(rel.max(initial=0.0)))
+                node_mis += int((res.node != xnode).sum())
+                node_tot += int(xnode.size)
+                same = (res.node == xnode).all(axis=(1, 2))
+                e_bad += int((res.end_node[same] != xend[same]).any(axis=1).sum())
+                e_bad += int((~np.isclose(res.speed_s[same], xss[same], rtol=0, atol=0, equal_nan=True)).any(axis=1).sum())
+        report["speed_dp"] = {"scenes": N_ST, "st_graph_arrays_not_bit_equal": g_bad, "cost_finiteness_mismatch": c_bad,
+                              "worst_relative_cost_error": worst_c, "cost_tolerance": 1e-12, "node_mismatch": node_mis, "nodes": node_tot,
+                              "end_or_path_mismatch_where_tables_equal": e_bad, "seconds": round(time.time() - t0, 1)}
+        print("S-T ", json.dumps(report["speed_dp"]), flush=True)
     # ---- front end: find_match_points -> sampling -> smooth_reference_line (51 points) against the port
-    t0 = time.time()
-    gp = np.zeros((N_FE, FE_G, 4))
-    n_global = np.zeros(N_FE, np.int32)
-    pred = np.zeros((N_FE, 2))
-    pre = np.zeros(N_FE, np.int32)
-    first = np.zeros(N_FE, np.int32)
-    for k in range(N_FE):
-        path, pred[k], pre[k], first[k] = _front_end_case(k)
-        gp[k, :len(path)] = path
-        n_global[k] = len(path)
-    ref, n_ref, mi, it, stf = pl.reference_line(smooth_params(), gp, n_global, pred, pre, first)
-    m_bad = s_bad = 0
-    worst_fe = 0.0
-    with ctx.Pool(NPROC) as pool:
-        for k, match, line in pool.imap_unordered(_front_end_port, range(N_FE), chunksize=16):
-            if mi[k] != match:
-                m_bad += 1
-                continue
-            if stf[k] != 0 or n_ref[k] != 51:
-                s_bad += 1
-                continue
-            e = np.abs(ref[k, :, :3] - line[:, :3]) / np.maximum(np.abs(line[:, :3]), 1.0)
-            ek = np.abs(ref[k, :, 3] - line[:, 3]) / np.maximum(np.abs(line[:, 3]), 1e-2)
-            worst_fe = max(worst_fe, float(e.max()), float(ek.max()))
-    report["front_end"] = {"requests": N_FE, "match_index_mismatch": m_bad, "status_mismatch": s_bad,
-                           "worst_relative_error": worst_fe, "tolerance": 1e-6, "seconds": round(time.time() - t0, 1)}
-    print("front", json.dumps(report["front_end"]), flush=True)
+    if "fe" in PARTS:
+        t0 = time.time()
+        gp = np.zeros((N_FE, FE_G, 4))
+        n_global = np.zeros(N_FE, np.int32)
+        pred = np.zeros((N_FE, 2))
+        pre = np.zeros(N_FE, np.int32)
+        first = np.zeros(N_FE, np.int32)
+        for k in range(N_FE):
+            path, pred[k], pre[k], first[k] = _front_end_case(k)
+            gp[k, :len(path)] = path
+            n_global[k] = len(path)
+        ref, n_ref, mi, it, stf = pl.reference_line(smooth_params(), gp, n_global, pred, pre, first)
+        m_bad = s_bad = 0
+        worst_fe = 0.0
+        with ctx.Pool(NPROC) as pool:
+            for k, match, line in pool.imap_unordered(_front_end_port, range(N_FE), chunksize=16):
+                if mi[k] != match:
+                    m_bad += 1
+                    continue
+                if stf[k] != 0 or n_ref[k] != 51:
+                    s_bad += 1
+                    continue
+                e = np.abs(ref[k, :, :3] - line[:, :3]) / np.maximum(np.abs(line[:, :3]), 1.0)
+                ek = np.abs(ref[k, :, 3] - line[:, 3]) / np.maximum(np.abs(line[:, 3]), 1e-2)
+                worst_fe = max(worst_fe, float(e.max()), float(ek.max()))
+        report["front_end"] = {"requests": N_FE, "match_index_mismatch": m_bad, "status_mismatch": s_bad,
+                               "worst_relative_error": worst_fe, "tolerance": 1e-6, "seconds": round(time.time() - t0, 1)}
+        print("front", json.dumps(report["front_end"]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(report, open("gpurun_out/parity_sweep.json", "w"), indent=1)
-    st = report["speed_dp"]
-    ok_st = not (g_bad or c_bad or e_bad) and worst_c <= 1e-12 and st["node_mismatch"] <= 1e-4 * st["nodes"]
-    ok_fe = not (m_bad or s_bad) and worst_fe <= 1e-6
-    ok = ok_fe and not any(bad.values()) and not (outcome or feas_bad or length) and worst <= 1e-6 and ok_st
+    json.dump(report, open(os.environ.get("SWEEP_OUT", "gpurun_out/parity_sweep.json"), "w"), indent=1)
+    ok = True
+    if "st" in PARTS:
+        st = report["speed_dp"]
+        ok = ok and not (g_bad or c_bad or e_bad) and worst_c <= 1e-12 and st["node_mismatch"] <= 1e-4 * st["nodes"]
+    if "fe" in PARTS:
+        ok = ok and not (m_bad or s_bad) and worst_fe <= 1e-6
+    if "dp" in PARTS:
+        ok = ok and not any(bad.values())
+    if "cycle" in PARTS:
+        ok = ok and not (outcome or feas_bad or length) and worst <= 1e-6
     print("PARITY-SWEEP", "OK" if ok else "MISMATCH")
     return 0 if ok else 1
 

@@ -1,5 +1,5 @@
 """Development check: the speed DP kernel of this build against another build of the library (EMP_AB_LIB, e.g. the
-previous round's kernel), bit for bit on B scenes.  Usage: EMP_AB_LIB=path/to/other.so python tools/st_ab.py [B]"""
+previous commit's), bit for bit on B scenes.  Usage: EMP_AB_LIB=path/to/other.so python tools/st_ab.py [B]"""
 import os
 import subprocess
 import sys
@@ -27,7 +27,7 @@ if __name__ == "__main__":
         np.savez(os.environ["EMP_AB_CHILD"], **run(B))
         sys.exit(0)
     out = []
-    for tag, env in (("a", {}), ("b", {"EMP_ST_DP_V1": "1"} if not os.environ.get("EMP_AB_LIB") else {"EMP_DBG_LIB": os.environ["EMP_AB_LIB"]})):
+    for tag, env in (("a", {}), ("b", {"EMP_DBG_LIB": os.environ["EMP_AB_LIB"]})):
         f = f"/tmp/st_ab_{tag}.npz"
         subprocess.run([sys.executable, __file__, str(B)], check=True, env={**os.environ, **env, "EMP_AB_CHILD": f})
         out.append(np.load(f))

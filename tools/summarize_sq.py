@@ -55,3 +55,17 @@ if record:
                 "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
                 "source": f"profiles/{tag}_sq.csv (rocprofv3 --pmc SQ passes of bench.py --no-pipeline, tools/pmc_sq.sh)"},
                 ("config", "scenes_per_gpu", "scene_dist"))
+        if k.startswith("speed_dp_kernel"):
+            v = {c: sum(x) / len(x) for c, x in agg[k].items()}
+            se_cycles = v["SQ_BUSY_CYCLES"] / 32.0            # SQ_BUSY_CYCLES sums over the 32 shader engines
+            _counters.upsert("speed_dp_counters", {
+                "scenes_per_gpu": int(scenes), "obstacle_slots": 16,
+                "insts_valu": int(v["SQ_INSTS_VALU"]), "insts_salu": int(v["SQ_INSTS_SALU"]),
+                "valu_busy_quad_cycles": int(v["SQ_ACTIVE_INST_VALU"]),
+                "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
+                "valu_issue_busy_frac": round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0 / se_cycles, 4),
+                "mean_waves_per_simd": round(v["SQ_WAVE_CYCLES"] * 4 / 1024.0 / se_cycles, 2),
+                "mean_us_under_pmc": round(sum(dur[k]) / len(dur[k]), 1) if dur.get(k) else None,
+                "source": f"profiles/{tag}_sq.csv (rocprofv3 --pmc SQ passes of tools/st_microbench.py, tools/pmc_sq_cmd.sh)"},
+                ("scenes_per_gpu", "obstacle_slots"))
+
