@@ -483,10 +483,17 @@ def cal_s_l_deri_fun(xy_list, V_xy_list, a_xy_list, local_path_xy_opt, origin_xy
     return L, DL, DS, DDL, LDS, DDS, LDDS
 
 
-def cal_proj_point(s, pre_match_index, frenet_path_opt, s_map):
-    """path_planning.py:52-75 (twin planning_utils.py:647-668) - monotone walk, IndexError past end."""
+def cal_proj_point(s, pre_match_index, frenet_path_opt, s_map, _flip_ties=None):
+    """path_planning.py:52-75 (twin planning_utils.py:647-668) - monotone walk, IndexError past end.
+
+    ``_flip_ties`` (checker only, not in the reference): the walk's comparison ``s_map[idx + 1] < s`` decides which
+    node a station is extrapolated from; when the two sides agree to within ``_flip_ties`` (a station that sits on
+    a node up to rounding) its outcome is the last bit of cos / sin / dot on the machine at hand, and either answer
+    is "the reference's".  With a tolerance given, such a comparison is answered the OTHER way - the reference run
+    on a machine that rounds the other way; tests use it to show that a device result beyond 1e-6 of the port is
+    the other branch of such a tie and nothing else."""
     idx = pre_match_index
-    while s_map[idx + 1] < s:
+    while (s_map[idx + 1] < s) != (_flip_ties is not None and abs(s_map[idx + 1] - s) <= _flip_ties):
         idx += 1
     mx, my, mth, mk = frenet_path_opt[idx]
     ds = s - s_map[idx]
@@ -497,17 +504,18 @@ def cal_proj_point(s, pre_match_index, frenet_path_opt, s_map):
 cal_proj_point_1 = cal_proj_point
 
 
-def frenet_path_to_xy(plan_start_s, plan_start_l, enriched_s_list, enriched_l_list, frenet_path_opt, s_map):
+def frenet_path_to_xy(plan_start_s, plan_start_l, enriched_s_list, enriched_l_list, frenet_path_opt, s_map,
+                      _flip_ties=None):
     """The un-smoothed target_xy of path_planning.py:29-46 (first tuple 2-long, rest 4-long)."""
     target = []
-    px, py, pth, _, idx = cal_proj_point(plan_start_s, 0, frenet_path_opt, s_map)
+    px, py, pth, _, idx = cal_proj_point(plan_start_s, 0, frenet_path_opt, s_map, _flip_ties)
     nor = np.array([-math.sin(pth), math.cos(pth)])
     cx, cy = np.array([px, py]) + plan_start_l * nor
     target.append((cx, cy))
     for i in range(len(enriched_l_list)):
         if enriched_s_list[i] > s_map[-1]:                                 # truncation :40
             break
-        px, py, pth, pk, idx = cal_proj_point(enriched_s_list[i], idx, frenet_path_opt, s_map)
+        px, py, pth, pk, idx = cal_proj_point(enriched_s_list[i], idx, frenet_path_opt, s_map, _flip_ties)
         nor = np.array([-math.sin(pth), math.cos(pth)])
         cx, cy = np.array([px, py]) + enriched_l_list[i] * nor
         target.append((cx, cy, pth, pk))
@@ -610,8 +618,10 @@ def virtual_obstacles(begin_s, start_v, dyn_dis_speed):
 
 
 def plan_cycle(ref_line, origin_xy, start_xy, start_v, start_a, static_obs_xy, dp_kwargs=None,
-               obs_length=5, obs_width=5, decimate=2, use_qp=True, midpoint=True, verbose=True, dyn_dis_speed=None):
-    """test_9.py:113-218 from the smoothed reference line onward; returns a dict of every stage."""
+               obs_length=5, obs_width=5, decimate=2, use_qp=True, midpoint=True, verbose=True, dyn_dis_speed=None,
+               _flip_ties=None):
+    """test_9.py:113-218 from the smoothed reference line onward; returns a dict of every stage.
+    ``_flip_ties``: see cal_proj_point (checker only)."""
     dp_kwargs = dict(dp_kwargs or {})
     ref_line = [tuple(p) for p in ref_line]
     s_map = cal_s_map_fun(ref_line, origin_xy=tuple(origin_xy))                                  # :113
@@ -642,7 +652,7 @@ def plan_cycle(ref_line, origin_xy, start_xy, start_v, start_a, static_obs_xy, d
         path_l = [ql[0]] + [(ql[i] + ql[i - 1]) / 2 for i in range(1, len(ql))] + [ql[-1]]
     else:
         path_s, path_l = list(dp_s), list(ql)
-    target_xy = frenet_path_to_xy(begin_s[0], begin_l[0], path_s, path_l, ref_line, s_map)       # :212
+    target_xy = frenet_path_to_xy(begin_s[0], begin_l[0], path_s, path_l, ref_line, s_map, _flip_ties)   # :212
     traj, smooth_status = smooth_reference_line(target_xy, _return_status=True)
     out.update(path_s=path_s, path_l=path_l, target_xy=target_xy, trajectory=traj,
                smooth_status=smooth_status)

@@ -23,21 +23,46 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def rel_close(a, b, rtol, scale=1.0):
-    """|a-b| <= rtol * max(|b|, scale): relative tolerance with an explicit magnitude floor."""
+ATOL_SURVEY = 1e-9     # "within 1e-6 relative (abs floor 1e-9)"
+
+
+def tolerance(b, rtol, scale=None):
+    """The suite's closeness rule.  For the 1e-6 bar it is SURVEY.md 8(d)'s, to the letter:
+    |a - b| <= max(rtol |b|, 1e-9 (rtol / 1e-6)) - no magnitude floor (until round 3 the floor was max(|b|, 1.0), i.e.
+    1e-6 m absolute near l = 0: a thousand times looser than what the whole GPU suite measures).
+    For the tight comparisons (rtol < 1e-7: S-T cost tables, MPC error model ...) `scale` is an explicit magnitude
+    floor, rtol max(|b|, scale), because there an absolute 1e-9 would be the LOOSER rule."""
+    b = np.abs(np.asarray(b, dtype=np.float64))
+    if rtol >= 1e-7 and scale is None:
+        return np.maximum(rtol * b, ATOL_SURVEY * (rtol / 1e-6))
+    return rtol * np.maximum(b, 1.0 if scale is None else scale)
+
+
+def rel_close(a, b, rtol, scale=None):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return np.abs(a - b) <= rtol * np.maximum(np.abs(b), scale)
+    return np.abs(a - b) <= tolerance(b, rtol, scale)
 
 
-def assert_rel(a, b, rtol, scale=1.0, what=""):
+def assert_rel(a, b, rtol, what="", scale=None):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
-    ok = rel_close(a, b, rtol, scale)
+    tol = tolerance(b, rtol, scale)
+    if os.environ.get("EMP_TOL_LOG") and a.size:      # development: what every comparison of the suite actually measures
+        import json
+        d = np.abs(a - b)
+        fin = np.isfinite(d)
+        rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "rtol": rtol, "scale": scale,
+               "n": int(a.size), "max_abs": float(d[fin].max(initial=0.0)),
+               "max_over_tolerance": float((d[fin] / tol[fin]).max(initial=0.0)),
+               "median_abs_b": float(np.median(np.abs(b[fin]))) if fin.any() else None}
+        with open(os.environ["EMP_TOL_LOG"], "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    ok = np.abs(a - b) <= tol
     if not ok.all():
-        err = np.abs(a - b) / np.maximum(np.abs(b), scale)
-        raise AssertionError(f"{what}: max scaled error {np.nanmax(err):.3e} > {rtol:.1e} "
+        err = np.abs(a - b) / tol
+        raise AssertionError(f"{what}: worst error is {np.nanmax(err):.3g} x the tolerance (rtol {rtol:.1e}) "
                              f"at {np.unravel_index(np.nanargmax(err), err.shape)}")
 
 

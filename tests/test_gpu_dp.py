@@ -51,13 +51,13 @@ def test_edge_costs_vs_reference_golden(planner):
         obs_s, obs_l, n_obs, start = _golden_inputs(load_golden(fname))
         c0, e = planner.dp_edge_costs(_params(cfg), obs_s, obs_l, n_obs, start)
         for sd in seeds:
-            assert_rel(c0[sd], ed[f"{cfg.name}__{sd}__c0"], RTOL, 1.0, "start edges")
+            assert_rel(c0[sd], ed[f"{cfg.name}__{sd}__c0"], RTOL, "start edges")
             s0 = start[sd, 0] + np.arange(1, cfg.col) * cfg.sample_s
             near = s0 <= 90.0      # beyond, the reference's own noise exceeds 1e-6 (tests/test_oracle_golden.py)
             red = ed[f"{cfg.name}__{sd}__e"]
-            assert_rel(e[sd][near], red[near], RTOL, 1.0, "neighbour edges")
+            assert_rel(e[sd][near], red[near], RTOL, "neighbour edges")
             if (~near).any():
-                assert_rel(e[sd][~near], red[~near], 4 * RTOL, 1.0, "neighbour edges beyond 90 m")
+                assert_rel(e[sd][~near], red[~near], 4 * RTOL, "neighbour edges beyond 90 m")
 
 
 def test_tiled_layout_matches_canonical(planner):
@@ -101,7 +101,7 @@ def test_dp_rows_index_exact_vs_reference(planner, cfg, fname, mode):
         n = int(g["dp_len"][b])
         assert ln[b] == n, "point count (int() truncation rule)"
         assert np.array_equal(ps[b, :n], g["dp_s"][b, :n]), "station s must be bit-exact with the reference"
-        assert_rel(pl[b, :n], g["dp_l"][b, :n], RTOL, 1.0, "dp_l vs reference")
+        assert_rel(pl[b, :n], g["dp_l"][b, :n], RTOL, "dp_l vs reference")
         xs, xl = xpaths[b]
         assert np.array_equal(pl[b, :n], np.asarray(xl)), "dp_l must be bit-exact with the exact oracle"
 
@@ -139,7 +139,7 @@ def test_enrich_truncation_rule_and_capacity(planner):
         s, l, ln, st = planner.dp_enrich(p, rows, start, 200)
         assert ln[0] == n and st[0] == 0
         assert np.array_equal(s[0, :n], rec[3:3 + n])
-        assert_rel(l[0, :n], rec[203:203 + n], RTOL, 1.0, "enrich l")
+        assert_rel(l[0, :n], rec[203:203 + n], RTOL, "enrich l")
         s, l, ln, st = planner.dp_enrich(p, rows, start, 10)      # too small: flagged, no overflow
         assert ln[0] == 10 and st[0] == 32
 

@@ -91,15 +91,15 @@ def _check_golden_subset(out):
     for b in range(n):
         k = int(g["dp_len"][b])
         assert out["dp_len"][b] == k
-        assert_rel(out["dp_l"][b, :k], g["dp_l"][b, :k], RTOL, 1.0, f"scene {b}: DP path")
+        assert_rel(out["dp_l"][b, :k], g["dp_l"][b, :k], RTOL, f"scene {b}: DP path")
         assert bool(out["status"][b] & 1) == bool(g["dp_infeasible_banner"][b])
         if g["status"][b] != 0:
             assert out["status"][b] & ~1
             continue
         m = int(g["traj_len"][b])
         assert out["traj_len"][b] == m
-        assert_rel(out["traj"][b, :m, :3], g["traj"][b, :m, :3], RTOL, 1.0, f"scene {b} trajectory")
-        assert_rel(out["traj"][b, :m, 3], g["traj"][b, :m, 3], RTOL, 1e-2, f"scene {b} curvature")
+        assert_rel(out["traj"][b, :m, :3], g["traj"][b, :m, :3], RTOL, f"scene {b} trajectory")
+        assert_rel(out["traj"][b, :m, 3], g["traj"][b, :m, 3], RTOL, f"scene {b} curvature")
         checked += 1
     assert checked >= 20
 
@@ -142,6 +142,82 @@ def test_configs2_4096_scenes(planner):
     outp = _plan_resident(planner, cfg, host, perm)
     _assert_same({k: v[perm] for k, v in out.items()}, outp, "permuted batch")
     _check_properties(planner, cfg, host, out)
+
+
+def _port_cycle(cfg, batch, i, **kw):
+    from oracle import ref_port as op
+    nk = int(batch.n_obs[i])
+    return op.plan_cycle(batch.ref[i], tuple(batch.origin_xy[i]), tuple(batch.start_xy[i]), tuple(batch.start_v[i]),
+                         tuple(batch.start_a[i]), [tuple(o) for o in batch.obs_xy[i, :nk]],
+                         dp_kwargs=dict(row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l,
+                                        sampling_res=cfg.sampling_res), obs_length=cfg.obs_length, obs_width=cfg.obs_width,
+                         verbose=False, **kw)
+
+
+def test_knot_tie_scenes_of_the_benchmark_batch_are_the_other_branch_and_nothing_else(planner):
+    """Seeds 177 and 3204 of the 4096-scene benchmark batch (and a few of their neighbours as controls).  The scene
+    generator puts the planning start on the normal through reference-line node 6, so `while s_map[idx + 1] < s`
+    (path_planning.py:62-63) compares two numbers that agree to an ulp and the segment the first trajectory points are
+    extrapolated from is decided by the last bit of cos / sin / dot on the machine at hand (0.45 mm apart: kappa ds^2).
+    On those two scenes the device lands on the other side than the port on this round's host.  What must hold, whatever
+    the host's libm does: each scene is within SURVEY 8(d)'s rule of the port - or, where the start IS tied, of the
+    port with that one comparison answered the other way (oracle/ref_port.py `_flip_ties`); a scene that is beyond
+    tolerance of both is a failure."""
+    cfg = S.CFG2
+    seeds = [176, 177, 178, 3203, 3204, 3205, 5, 1024]
+    batch = S.make_batch(seeds, cfg)
+    out = _plan_resident(planner, cfg, _host_inputs(batch))
+    tie_tol = 8e-15
+    flipped_needed = 0
+    compared = 0
+    for i, seed in enumerate(seeds):
+        port = _port_cycle(cfg, batch, i)
+        ok = port.get("qp_status", "optimal") == "optimal" and port["smooth_status"] == "optimal"
+        assert ok == ((int(out["status"][i]) & ~1) == 0), f"seed {seed}: outcome"
+        if not ok:
+            continue
+        want = np.asarray(port["trajectory"], dtype=np.float64)
+        m = len(want)
+        assert out["traj_len"][i] == m
+        got = out["traj"][i, :m]
+        gap = float(np.abs(np.asarray(port["s_map"]) - port["begin_s"]).min())
+        assert gap <= tie_tol, f"seed {seed}: the generator no longer puts the start on a node (gap {gap:.2e}); this test needs one"
+        near = np.abs(got - want) <= np.maximum(1e-6 * np.abs(want), 1e-9)
+        if not near.all():
+            other = np.asarray(_port_cycle(cfg, batch, i, _flip_ties=tie_tol)["trajectory"], dtype=np.float64)
+            assert len(other) == m
+            assert_rel(got, other, RTOL, f"seed {seed}: beyond tolerance of the port AND of its flipped tie branch")
+            # and the two branches really are what separates them: sub-millimetre, at the first points (the smoothing QP
+            # carries a decaying trace of it along the first dozen)
+            assert np.abs(want - other)[:, :2].max() < 2e-3 and not near[:2].all() and near[m // 2:].all()
+            flipped_needed += 1
+        compared += 1
+    assert compared >= 6
+    print(f"tie scenes: {compared} compared, {flipped_needed} on the other branch of the start tie")
+
+
+def test_start_off_the_reference_line_nodes_has_no_tie(planner):
+    """The same generator with the planning start 2.7 m ahead of the origin instead of 2.0 (not on a node): no scene
+    may need the flipped branch - every planned trajectory is within SURVEY 8(d)'s rule of the port, first points
+    included."""
+    cfg = S.CFG2
+    seeds = list(range(170, 186)) + list(range(3200, 3208))
+    batch = S.make_batch(seeds, cfg, start_ahead=2.7)
+    out = _plan_resident(planner, cfg, _host_inputs(batch))
+    compared = 0
+    for i, seed in enumerate(seeds):
+        port = _port_cycle(cfg, batch, i)
+        ok = port.get("qp_status", "optimal") == "optimal" and port["smooth_status"] == "optimal"
+        assert ok == ((int(out["status"][i]) & ~1) == 0), f"seed {seed}: outcome"
+        if not ok:
+            continue
+        gap = float(np.abs(np.asarray(port["s_map"]) - port["begin_s"]).min())
+        assert gap > 1e-3, f"seed {seed}: start on a node after all ({gap:.2e})"
+        want = np.asarray(port["trajectory"], dtype=np.float64)
+        assert out["traj_len"][i] == len(want)
+        assert_rel(out["traj"][i, :len(want)], want, RTOL, f"seed {seed} (start off the nodes)")
+        compared += 1
+    assert compared >= 16
 
 
 def test_configs3_32768_scenes_and_rank_shards(planner):

@@ -63,9 +63,9 @@ def test_speed_qp_vs_certified_oracle(pl):
         assert st[k] == 0 and it[k] > 0, f"case {b}: status {st[k]}"
         np.testing.assert_array_equal(qt[k, :n], np.arange(n) * dt)
         assert np.isnan(qs[k, n:]).all()
-        assert_rel(qs[k, :n], os_[:n], 1e-6, scale=1.0)
-        assert_rel(qv[k, :n], ov[:n], 1e-6, scale=1.0)
-        assert_rel(qa[k, :n], oa[:n], 1e-6, scale=1.0)
+        assert_rel(qs[k, :n], os_[:n], 1e-6)
+        assert_rel(qv[k, :n], ov[:n], 1e-6)
+        assert_rel(qa[k, :n], oa[:n], 1e-6)
         # the reference's own matrices: continuity equations and monotone s
         X = np.stack([qs[k, :n], qv[k, :n], qa[k, :n]], axis=1).reshape(-1)
         assert np.abs(F["Aeq"].T @ X).max() < 1e-8 * max(1.0, np.abs(X).max())
@@ -172,7 +172,7 @@ def test_dropin_back_end_functions(pl):
     q = sp.speed_QP(float(g["v0"][b]), float(g["qp_a0"][b]), g["dp_s"][b], g["dp_t"][b], *cs)
     assert len(q) == 4 and q[0].shape == (17,)
     k = int(g["qp_size"][b])
-    assert_rel(np.stack(q)[:, :k], g["prof"][b][:, :k], 1e-6, scale=1.0)
+    assert_rel(np.stack(q)[:, :k], g["prof"][b][:, :k], 1e-6)
     d = sp.increase_points(*g["prof"][b])
     assert len(d) == 4 and d[0].shape == (401,)
     assert_rel(np.stack(d), g["dense_out"][b], 1e-12, scale=1.0)

@@ -54,9 +54,9 @@ def test_bspline_path_qp_matches_reference_formulation(hc, fname, solver):
             assert rc != 0, "oracle says infeasible, banded solver must not claim success"
             continue
         assert rc == 0 and iters <= 40
-        assert_rel(l, g["qp_l"][i, :nq], 1e-8, 1.0, "qp_l")
-        assert_rel(dl, g["qp_dl"][i, :nq], 1e-8, 1.0, "qp_dl")
-        assert_rel(ddl, g["qp_ddl"][i, :nq], 1e-8, 1.0, "qp_ddl")
+        assert_rel(l, g["qp_l"][i, :nq], 1e-8, "qp_l", scale=1.0)
+        assert_rel(dl, g["qp_dl"][i, :nq], 1e-8, "qp_dl", scale=1.0)
+        assert_rel(ddl, g["qp_ddl"][i, :nq], 1e-8, "qp_ddl", scale=1.0)
         n_ok += 1
     assert n_ok >= 6
 
@@ -88,7 +88,7 @@ def test_path_qp_kkt_certificate_on_random_corridors(hc, solver):
         x = np.stack([l, dl, ddl], axis=1).reshape(-1)
         cert = qp_dense.kkt_certificate(H, f, G, h, A, b, x)
         assert cert["stationarity"] < 1e-7 and cert["ineq_violation"] < 1e-9 and cert["eq_violation"] < 1e-9
-        assert_rel(x, ref.x, 1e-7, 1.0, "x vs dense oracle")
+        assert_rel(x, ref.x, 1e-7, "x vs dense oracle", scale=1.0)
         checked += 1
     assert checked >= 20
 
@@ -131,7 +131,7 @@ def test_box_qp_matches_reference_smoothing(hc):
         for c in range(2):
             rc, x, iters = _box_qp(hc, pts[:, c])
             assert rc == 0 and iters <= 40
-            assert_rel(x, ref.x[c::2], 1e-9, 1.0, f"coordinate {c}, m={m}")
+            assert_rel(x, ref.x[c::2], 1e-9, f"coordinate {c}, m={m}", scale=1.0)
     # golden: the smoothed trajectory of the reference cycle (x, y columns)
     g = load_golden("cycle_cfg2_40x9_8obs.npz")
     f0 = load_golden("qp_formulation.npz")
@@ -140,7 +140,7 @@ def test_box_qp_matches_reference_smoothing(hc):
         rc, x, _ = _box_qp(hc, tgt[c::2])
         m = int(g["traj_len"][0])
         assert rc == 0
-        assert_rel(x, g["traj"][0, :m, c], 1e-9, 1.0, "golden trajectory")
+        assert_rel(x, g["traj"][0, :m, c], 1e-9, "golden trajectory", scale=1.0)
 
 
 def test_heading_kappa_and_s_map(hc):
@@ -149,12 +149,12 @@ def test_heading_kappa_and_s_map(hc):
     th = np.zeros(len(xy))
     kp = np.zeros(len(xy))
     hc.hc_heading_kappa(xy.ctypes.data, len(xy), th.ctypes.data, kp.ctypes.data)
-    assert_rel(th, g["hk_theta"], 1e-12, 1.0, "theta")
-    assert_rel(kp, g["hk_kappa"], 1e-9, 1.0, "kappa")
+    assert_rel(th, g["hk_theta"], 1e-12, "theta", scale=1.0)
+    assert_rel(kp, g["hk_kappa"], 1e-9, "kappa", scale=1.0)
     line = np.ascontiguousarray(g["mp_path"][:80])
     sm = np.zeros(80)
     hc.hc_s_map(line.ctypes.data, 80, 7.3, 2.0, sm.ctypes.data)
-    assert_rel(sm, g["sm_out"], 1e-12, 1.0, "s_map")
+    assert_rel(sm, g["sm_out"], 1e-12, "s_map", scale=1.0)
     # matching with both early exits (50 on a first run, 5 in windowed mode)
     full = np.ascontiguousarray(g["mp_path"])
     for (x, y), want in zip(g["mp_pts"], g["mp_index"]):
@@ -341,7 +341,7 @@ def test_stb_core_speed_qp_and_increase_points(hc):
             continue
         assert st == 0 and 0 < iters.value < 60
         k = int(g["qp_size"][b])
-        assert_rel(np.stack(outs)[:, :k], g["prof"][b][:, :k], 1e-6, scale=1.0)
+        assert_rel(np.stack(outs)[:, :k], g["prof"][b][:, :k], 1e-6)
         assert np.isnan(np.stack(outs)[:, k:]).all()
         solved += 1
     assert solved >= 25

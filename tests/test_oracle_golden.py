@@ -60,14 +60,14 @@ def test_faithful_port_full_cycle(cfg, fname, mode):
         except IndexError:
             assert g["status"][i] == 3
             continue
-        assert_rel(o["s_map"], g["s_map"][i], RTOL, 1.0, "s_map")
-        assert_rel(o["obs_s"], g["obs_s"][i, :k], RTOL, 1.0, "obs_s")
-        assert_rel(o["obs_l"], g["obs_l"][i, :k], RTOL, 1.0, "obs_l")
-        assert_rel([o["begin_s"], o["start_l"], o["start_dl"], o["start_ddl"]], g["start"][i], RTOL, 1.0, "start")
+        assert_rel(o["s_map"], g["s_map"][i], RTOL, "s_map")
+        assert_rel(o["obs_s"], g["obs_s"][i, :k], RTOL, "obs_s")
+        assert_rel(o["obs_l"], g["obs_l"][i, :k], RTOL, "obs_l")
+        assert_rel([o["begin_s"], o["start_l"], o["start_dl"], o["start_ddl"]], g["start"][i], RTOL, "start")
         n = int(g["dp_len"][i])
         assert len(o["dp_s"]) == n
-        assert_rel(o["dp_s"], g["dp_s"][i, :n], RTOL, 1.0, "dp_s")
-        assert_rel(o["dp_l"], g["dp_l"][i, :n], RTOL, 1.0, "dp_l")
+        assert_rel(o["dp_s"], g["dp_s"][i, :n], RTOL, "dp_s")
+        assert_rel(o["dp_l"], g["dp_l"][i, :n], RTOL, "dp_l")
         assert bool(g["dp_infeasible_banner"][i]) == (not o["dp_feasible"])
         if g["status"][i] == 4:
             assert o["qp_status"] != "optimal"
@@ -75,16 +75,16 @@ def test_faithful_port_full_cycle(cfg, fname, mode):
         assert g["status"][i] == 0
         if mode.get("use_qp", True):
             nq = int(g["n_qp"][i])
-            assert_rel(o["l_min"], g["l_min"][i, :nq], 0, 1.0, "l_min")
-            assert_rel(o["l_max"], g["l_max"][i, :nq], 0, 1.0, "l_max")
-            assert_rel(o["qp_l"], g["qp_l"][i, :nq], RTOL, 1.0, "qp_l")
-            assert_rel(o["qp_dl"], g["qp_dl"][i, :nq], RTOL, 1.0, "qp_dl")
-            assert_rel(o["qp_ddl"], g["qp_ddl"][i, :nq], RTOL, 1.0, "qp_ddl")
+            assert_rel(o["l_min"], g["l_min"][i, :nq], 0, "l_min", scale=1.0)
+            assert_rel(o["l_max"], g["l_max"][i, :nq], 0, "l_max", scale=1.0)
+            assert_rel(o["qp_l"], g["qp_l"][i, :nq], RTOL, "qp_l")
+            assert_rel(o["qp_dl"], g["qp_dl"][i, :nq], RTOL, "qp_dl")
+            assert_rel(o["qp_ddl"], g["qp_ddl"][i, :nq], RTOL, "qp_ddl")
         m = int(g["traj_len"][i])
         assert len(o["trajectory"]) == m
         t = np.asarray(o["trajectory"], dtype=np.float64)
-        assert_rel(t[:, :3], g["traj"][i, :m, :3], RTOL, 1.0, "traj xy theta")
-        assert_rel(t[:, 3], g["traj"][i, :m, 3], RTOL, 1e-2, "traj kappa")   # kappa ~ 1e-3..1e-1 1/m
+        assert_rel(t[:, :3], g["traj"][i, :m, :3], RTOL, "traj xy theta")
+        assert_rel(t[:, 3], g["traj"][i, :m, 3], RTOL, "traj kappa")   # kappa ~ 1e-3..1e-1 1/m
 
 
 @pytest.mark.parametrize("cfg,fname", [(S.CFG1, "cycle_cfg1_20x5_0obs.npz"),
@@ -108,7 +108,7 @@ def test_exact_oracle_dp_index_exact(cfg, fname):
         s, l = paths[i]
         assert len(s) == n
         assert np.array_equal(np.asarray(s), g["dp_s"][i, :n]), "station s must be bit-exact"
-        assert_rel(l, g["dp_l"][i, :n], RTOL, 1.0, "dp_l")
+        assert_rel(l, g["dp_l"][i, :n], RTOL, "dp_l")
         assert bool(g["dp_infeasible_banner"][i]) == (not feasible[i])
 
 
@@ -125,7 +125,7 @@ def test_edge_costs_vs_reference():
                                    cfg.sample_s, cfg.sample_l)
             rc0, red = e[f"{cfg.name}__{sd}__c0"], e[f"{cfg.name}__{sd}__e"]
             # costs span 1e1..1e15; floor 1.0 only matters for the handful of ~0 edges
-            assert_rel(c0[0], rc0, RTOL, 1.0, "start edge costs")
+            assert_rel(c0[0], rc0, RTOL, "start edge costs")
             # The reference's OWN edge costs are noise-limited beyond s ~ 90 m: its 6x6 boundary
             # matrix in absolute s has cond ~ s^10/T^5, and the measured deviation from the exact
             # quintic grows ~ s^6 (1e-11 at 10 m, 1e-7 at 70 m, 1.4e-6 at 100 m on the generating
@@ -133,9 +133,9 @@ def test_edge_costs_vs_reference():
             # get 4e-6 (documented in DESIGN.md "Reference noise floor").
             s0 = g["start"][sd, 0] + np.arange(1, cfg.col) * cfg.sample_s
             near = s0 <= 90.0
-            assert_rel(ed[0][near], red[near], RTOL, 1.0, "neighbour edge costs (s0 <= 90 m)")
+            assert_rel(ed[0][near], red[near], RTOL, "neighbour edge costs (s0 <= 90 m)")
             if (~near).any():
-                assert_rel(ed[0][~near], red[~near], 4 * RTOL, 1.0, "neighbour edge costs (s0 > 90 m)")
+                assert_rel(ed[0][~near], red[~near], 4 * RTOL, "neighbour edge costs (s0 > 90 m)")
             worst = max(worst, float((np.abs(ed[0][near] - red[near]) / np.maximum(np.abs(red[near]), 1.0)).max()))
             # faithful port on a sample of edges
             k = int(g["in_n_obs"][sd])
@@ -146,7 +146,7 @@ def test_edge_costs_vs_reference():
                 pre_l = ((cfg.row + 1) / 2 - 1 - kk) * cfg.sample_l
                 v = op.cal_neighbor_cost(os_, ol_, ps + j * cfg.sample_s, pre_l, ps + (j + 1) * cfg.sample_s, cur_l,
                                          cfg.sample_s, 1e12, [300, 1000, 5000], 20)
-                assert_rel(float(np.asarray(v).reshape(-1)[0]), red[j - 1, i, kk], RTOL, 1.0, "port edge")
+                assert_rel(float(np.asarray(v).reshape(-1)[0]), red[j - 1, i, kk], RTOL, "port edge")
     assert worst < RTOL
 
 
@@ -157,42 +157,42 @@ def test_function_level_vectors():
     for b, v in zip(g["quintic_bc"], g["quintic_vals"]):
         ts = np.linspace(b[6], b[7], 11)
         c = op.cal_quintic_coefficient(*b)
-        assert_rel(np.polyval(np.asarray(c)[::-1], ts), v, RTOL, 1.0, "quintic port")
+        assert_rel(np.polyval(np.asarray(c)[::-1], ts), v, RTOL, "quintic port")
     # a4
     for r, c, c3 in zip(g["obs_sq"], g["obs_cost"], g["obs_cost_w3"]):
         assert op.cal_obs_cost(1e12, r.reshape(10, 1)) == c
         assert op.cal_obs_cost(7.5, r.reshape(10, 1), danger_dis=3, safe_dis=5) == c3
     # a13
     th, kp = op.cal_heading_kappa(_tl(g["hk_xy"]))
-    assert_rel(th, g["hk_theta"], 1e-12, 1.0, "theta")
-    assert_rel(kp, g["hk_kappa"], 1e-9, 1.0, "kappa")
+    assert_rel(th, g["hk_theta"], 1e-12, "theta", scale=1.0)
+    assert_rel(kp, g["hk_kappa"], 1e-9, "kappa", scale=1.0)
     # a14, a19, sampling
     path = _tl(g["mp_path"])
     mi, pr = op.match_projection_points(_tl(g["mp_pts"]), path)
     assert np.array_equal(np.asarray(mi), g["mp_index"])
-    assert_rel(np.asarray(pr, dtype=np.float64), g["mp_proj"], 1e-12, 1.0, "projection")
+    assert_rel(np.asarray(pr, dtype=np.float64), g["mp_proj"], 1e-12, "projection", scale=1.0)
     for mode, out in zip(g["fm_modes"], g["fm_out"]):
         m, p = op.find_match_points(_tl(g["mp_pts"][:3]), path, bool(mode[0]), int(mode[1]))
         assert np.array_equal(np.asarray(m, dtype=np.float64), out[:3])
-        assert_rel(np.asarray(p, dtype=np.float64).reshape(-1), out[3:], 1e-12, 1.0, "find_match proj")
+        assert_rel(np.asarray(p, dtype=np.float64).reshape(-1), out[3:], 1e-12, "find_match proj", scale=1.0)
     for m, n, x0, x1 in g["sampling"]:
         loc = op.sampling(int(m), path)
         assert (len(loc), loc[0][0], loc[-1][0]) == (int(n), x0, x1)
     # a15-a17, a11, a18
     s_map = op.cal_s_map_fun(path[:80], (7.3, 2.0))
-    assert_rel(s_map, g["sm_out"], 1e-12, 1.0, "s_map")
+    assert_rel(s_map, g["sm_out"], 1e-12, "s_map", scale=1.0)
     sl = op.cal_s_l_fun(_tl(g["sl_pts"]), path[:80], s_map)
-    assert_rel(np.asarray(sl, dtype=np.float64), g["sl_out"], 1e-12, 1.0, "s_l")
+    assert_rel(np.asarray(sl, dtype=np.float64), g["sl_out"], 1e-12, "s_l", scale=1.0)
     idx = 0
     for rec in g["projpt"]:
         r = op.cal_proj_point(rec[0], idx, path[:80], s_map)
         idx = r[4]
-        assert_rel(np.asarray(r, dtype=np.float64), rec[1:], 1e-12, 1.0, "cal_proj_point")
+        assert_rel(np.asarray(r, dtype=np.float64), rec[1:], 1e-12, "cal_proj_point", scale=1.0)
     d1 = op.cal_s_l_deri_fun([(30.0, 12.0)], [(0.0, 0.0)], [(0.3, -0.2)], path[:80], (30.0, 12.0))
-    assert_rel([v[0] for v in d1], g["deri_zero"], 1e-12, 1.0, "deri zero-speed branch")
+    assert_rel([v[0] for v in d1], g["deri_zero"], 1e-12, "deri zero-speed branch", scale=1.0)
     d2 = op.cal_s_l_deri_fun([(30.0, 12.0), (50.0, 20.0)], [(6.0, 2.0), (5.0, 1.0)], [(0.3, -0.2), (0.1, 0.4)],
                              path[:80], (31.0, 12.5))
-    assert_rel(np.asarray(d2, dtype=np.float64), g["deri_two"], 1e-12, 1.0, "deri")
+    assert_rel(np.asarray(d2, dtype=np.float64), g["deri_two"], 1e-12, "deri", scale=1.0)
     # a5: sample counts (int() truncation) exact, s exact, l within 1e-6
     for rec in g["enrich"]:
         ps, res, n = rec[0], rec[1], int(rec[2])
@@ -202,26 +202,26 @@ def test_function_level_vectors():
         es, el = op.enrich_DP_s_l(DP_s, DP_l, ps, 0.2, 0.01, -0.003, resolution=res)
         assert len(es) == n
         assert np.array_equal(np.asarray(es, dtype=np.float64), rec[3:3 + n])
-        assert_rel(el, rec[203:203 + n], RTOL, 1.0, "enrich l")
+        assert_rel(el, rec[203:203 + n], RTOL, "enrich l")
         rows = (12 + 1) / 2 - 1 - np.asarray(DP_l) / 1.5
         xs, xl = ex.enrich(rows, (ps, 0.2, 0.01, -0.003), 12, 6, 15, 1.5, res)
         assert len(xs) == n and np.array_equal(np.asarray(xs), rec[3:3 + n])
-        assert_rel(xl, rec[203:203 + n], RTOL, 1.0, "exact enrich l")
+        assert_rel(xl, rec[203:203 + n], RTOL, "exact enrich l")
     # helpers beside the path
     fx, fy, fh, fk = (g["mp_path"][:80, k] for k in range(4))
     idx2s = op.trajectory_index2s(np.append(fx, np.nan), np.append(fy, np.nan))
-    assert_rel(idx2s, g["idx2s"], 1e-12, 1.0, "index2s")
+    assert_rel(idx2s, g["idx2s"], 1e-12, "index2s", scale=1.0)
     f2c = op.Frenet2Cartesian(*g["f2c_in"], fx, fy, fh, fk, idx2s[:80])
     got = np.stack([a[:5, 0] for a in f2c])
     assert np.array_equal(np.isnan(got), np.isnan(g["f2c_out"]))
-    assert_rel(np.nan_to_num(got), np.nan_to_num(g["f2c_out"]), 1e-12, 1.0, "Frenet2Cartesian")
+    assert_rel(np.nan_to_num(got), np.nan_to_num(g["f2c_out"]), 1e-12, "Frenet2Cartesian", scale=1.0)
     cp = op.CalcProjPoint(21.7, fx, fy, fh, fk, idx2s[:80])
-    assert_rel(cp, g["calcproj"][1:], 1e-12, 1.0, "CalcProjPoint")
+    assert_rel(cp, g["calcproj"][1:], 1e-12, "CalcProjPoint", scale=1.0)
     dy = op.cal_dy_obs_deri(np.array([1.0, -2.0, np.nan]), np.array([5.0, 0.0, 1.0]), np.array([1.0, 0.0, 1.0]),
                             np.array([0.1, 0.2, 0.3]), np.array([0.01, -0.02, 0.0]))
     got = np.stack([a[:4] for a in dy])
     assert np.array_equal(np.isnan(got), np.isnan(g["dyobs"]))
-    assert_rel(np.nan_to_num(got), np.nan_to_num(g["dyobs"]), 1e-12, 1.0, "cal_dy_obs_deri")
+    assert_rel(np.nan_to_num(got), np.nan_to_num(g["dyobs"]), 1e-12, "cal_dy_obs_deri", scale=1.0)
 
 
 def test_qp_formulation_pinned():
@@ -240,8 +240,8 @@ def test_qp_formulation_pinned():
                                   list(g["path_l"][0, :m_ - 1]), ref, list(g["s_map"][0]))
     H, q, G, h = op.smooth_qp_matrices(target)
     assert np.array_equal(H, f["smooth_P"]) and np.array_equal(G, f["smooth_G"])
-    assert_rel(q, f["smooth_q"], 1e-9, 1.0, "smooth q")
-    assert_rel(h, f["smooth_h"], 1e-9, 1.0, "smooth h")
+    assert_rel(q, f["smooth_q"], 1e-9, "smooth q", scale=1.0)
+    assert_rel(h, f["smooth_h"], 1e-9, "smooth h", scale=1.0)
     # certificates of the stored solutions (solver-independent)
     for name in ("path", "smooth"):
         cert = qp_dense.kkt_certificate(f[name + "_P"], f[name + "_q"], f[name + "_G"], f[name + "_h"],
@@ -254,7 +254,7 @@ def test_qp_dense_known_answers():
     (reference test.py:13-24: P=[[2,1],[1,2]], q=[2,1], x >= -1, x1+x2=1 -> x=(0,1), objective 2)."""
     r = qp_dense.solve_qp([[2.0, 1.0], [1.0, 2.0]], [2.0, 1.0], -np.eye(2), [1.0, 1.0], [[1.0, 1.0]], [1.0])
     assert r.status == "optimal"
-    assert_rel(r.x, [0.0, 1.0], 1e-9, 1.0)
+    assert_rel(r.x, [0.0, 1.0], 1e-9, scale=1.0)
     assert abs(0.5 * r.x @ np.array([[2.0, 1.0], [1.0, 2.0]]) @ r.x + np.array([2.0, 1.0]) @ r.x - 2.0) < 1e-9
     # box QP against scipy's bounded least squares (independent algorithm, BVLS)
     from scipy.optimize import lsq_linear
@@ -267,7 +267,7 @@ def test_qp_dense_known_answers():
     lo = -h.reshape(-1)[len(pts) * 2:]
     hi = h.reshape(-1)[:len(pts) * 2]
     ls = lsq_linear(L.T, c, bounds=(lo, hi), method="bvls", tol=1e-14)
-    assert_rel(r.x, ls.x, 1e-9, 1.0, "smoothing QP vs BVLS")
+    assert_rel(r.x, ls.x, 1e-9, "smoothing QP vs BVLS", scale=1.0)
     # an infeasible problem must not be reported optimal
     with np.errstate(all="ignore"):
         r = qp_dense.solve_qp(np.eye(1), [0.0], [[1.0], [-1.0]], [-1.0, -1.0])
