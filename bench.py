@@ -231,9 +231,10 @@ def main():
     if args.latency:
         return latency_main(args)
 
+    from emplanner_carla_amd import _lib as L
+    L.configure_hw_queues(8)          # lane mode: a hardware queue per stream; must precede HIP's initialisation (_lib.py)
     import torch
     import torch.distributed as dist
-    from emplanner_carla_amd import _lib as L
     from emplanner_carla_amd import dist as emp_dist
     from emplanner_carla_amd import scenes as S
     from emplanner_carla_amd.api import (Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params,

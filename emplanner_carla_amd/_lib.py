@@ -12,10 +12,27 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libemplanner.so")
-# Lane mode (emp_set_pipeline with n >= 2) needs one hardware queue per stream; the HIP runtime reads this variable when it
-# initialises (default 4: lanes would share queues and serialise).  The library sets it too when it is loaded, which is
-# too late if torch has touched the GPU before the first Planner is made - importing this module early is not.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def configure_hw_queues(n: int = 8) -> bool:
+    """Lane mode (emp_set_pipeline with n >= 2) wants one hardware queue per stream; the HIP runtime maps all streams of a
+    process onto GPU_MAX_HW_QUEUES queues (default 4) and reads the variable ONCE, when it initialises.  Neither the
+    library nor this package touches the process environment on its own: a program that owns its process (bench.py does)
+    calls this before anything initialises HIP - before the first torch.cuda call and the first Planner.  Returns False,
+    and changes nothing, if the variable is already set."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
+def hw_queues() -> int:
+    """The queue count the HIP runtime will use / has used, as far as the environment tells."""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
+
 
 EMP_HOST, EMP_DEVICE = 0, 1
 EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1

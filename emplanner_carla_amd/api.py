@@ -301,6 +301,11 @@ class Planner:
         outputs of a cycle are then complete on ``torch_result_stream()`` (lane mode: the lane of the LATEST call) and
         ``synchronize()`` waits for everything."""
         m = L.EMP_PIPELINE_STAGED if (mode is True or mode == "staged") else max(int(mode), 0)
+        if m >= 2 and m + 1 > L.hw_queues():
+            import warnings
+            warnings.warn(f"{m} lanes + the main stream on GPU_MAX_HW_QUEUES={L.hw_queues()} hardware queues: lanes will share "
+                          "queues and serialise (emplanner_carla_amd._lib.configure_hw_queues() before HIP initialises)",
+                          RuntimeWarning, stacklevel=2)
         self._check(self._lib.emp_set_pipeline(self._h, m))
         self.pipe_mode = m
         self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)
@@ -805,8 +810,11 @@ class Planner:
         if self.pipelined and a.torch:
             # The outputs of the calls in flight stay referenced here even if the caller drops them at once: their
             # memory must not come back from torch's allocator into a later call's outputs while this call, or a
-            # consumer queued behind it on its result stream, still uses it.  (Call k + n runs on this call's lane,
-            # i.e. behind it.)
+            # consumer queued behind it on its result stream, still uses it.  Entry k is released when call k + n
+            # has been issued; the memory may then go to call k + n + 1, which runs on ANOTHER lane - so call k + n
+            # (emp_plan_cycle, lane mode) first orders the main stream behind the tail of its lane, i.e. behind call k
+            # and its consumers, and every later call is ordered behind the main stream.  (Staged mode: the front
+            # stage of call k + 2 waits for the back stage of call k.)
             self._inflight.append((list(res.values()), a.keep))
             if len(self._inflight) > self.in_flight:
                 self._inflight.pop(0)

@@ -217,11 +217,6 @@ static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
 
 using namespace emp;
 
-// Lane mode (emp_set_pipeline) needs a hardware queue per stream; the HIP runtime maps all streams of a process onto
-// GPU_MAX_HW_QUEUES queues (default 4) and reads the variable when it initialises.  Set it when the library is loaded
-// unless the process has chosen a value itself.
-__attribute__((constructor)) static void emp_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 extern "C" {
 
 int emp_abi_version(void) { return EMP_ABI_VERSION; }
@@ -307,6 +302,7 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
         if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
         if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
+        if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
@@ -453,6 +449,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         if (m != EMP_PIPELINE_STAGED && !ln.stream) EMP_HIP(ctx, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         if (!ln.ev_in) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
         if (!ln.ev_front) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
+        if (!ln.ev_tail) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
         if (!ln.ev_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
     }
     if (m == EMP_PIPELINE_STAGED && !ctx->back_stream) {
@@ -1062,6 +1059,13 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if (staged) {
         if (lane.ln->done_valid) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_done, 0));
     } else if (piped) {
+        // The lane's previous occupant (call k - n) and whatever its caller queued behind it on the lane's stream (record
+        // packing) must be done before anything ordered on the main stream from here on may touch memory they use: the
+        // caller keeps a call's outputs alive only until this call is issued, and the NEXT call runs on another lane.
+        if (lane.ln->done_valid) {
+            EMP_HIP(ctx, hipEventRecord(lane.ln->ev_tail, ctx->stream));
+            EMP_HIP(ctx, hipStreamWaitEvent(lane.main_stream, lane.ln->ev_tail, 0));
+        }
         EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
     }

@@ -54,10 +54,13 @@ struct emp_ctx {
     // tensor and pair table, behind everything queued on `stream` when it was issued; the dispatcher overlaps the kernels
     // of n consecutive cycles wherever it finds room.
     // ev_in: recorded on `stream` by a LANES call, its lane waits for it.  ev_front: end of a STAGED front stage.
+    // ev_tail: LANES, the lane stream's tail when the lane is taken again - the main stream waits for it, so that memory
+    // the caller releases once call k + n is issued is not handed to a call on ANOTHER lane while call k, or a consumer
+    // queued behind it on the lane, still runs (the lanes are ordered behind the main stream, not against each other).
     // ev_done: end of the lane's latest cycle - what the next user of the lane's pool and every other entry point wait for.
     struct Lane {
         hipStream_t stream = nullptr;
-        hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr;
+        hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr, ev_tail = nullptr;
         bool done_valid = false;
         std::vector<Buf> pool;
     };

@@ -82,26 +82,46 @@ def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=
     return out
 
 
-def motion_planning(conn, device_id: int = 0, dp=None, strict: bool = False):
+def answer_refused(reply, status, match_index, previous, on_infeasible):
+    """What the planning loop sends for a request that was refused (reply None).  IndexError cases raise, as the
+    reference does (path_planning.py:63, :267).  An infeasible path / smoothing QP has no faithful answer - the reference
+    ignores cvxopt's status (path_planning.py:211-218) and sends whatever its last iterate was - so the policy is the
+    caller's:
+      "previous" (default)  the last valid trajectory and path again, with the NEW match index: an unmodified reference
+                            driver unpacks the reply and hands element 0 straight to its controller (test_9.py:395-399), so
+                            it must be a trajectory; ValueError if there has been no valid reply yet;
+      "raise"               ValueError (the planning process ends, like the reference's on an exception);
+      "sentinel"            (None, match_point_list, [], []) for a driver patched to keep its previous path."""
+    if reply is not None:
+        return reply
+    if status & (2 | 4):
+        raise IndexError("list index out of range")
+    if on_infeasible == "sentinel":
+        return (None, [int(match_index)], [], [])
+    if on_infeasible == "previous" and previous is not None:
+        return (previous[0], [int(match_index)], previous[2], previous[3])     # the new match index is still valid (test_9.py:99)
+    if on_infeasible not in ("previous", "raise"):
+        raise ValueError(f"on_infeasible must be 'previous', 'raise' or 'sentinel', not {on_infeasible!r}")
+    raise ValueError("path or smoothing QP infeasible" + ("" if on_infeasible == "raise" else " and no previous trajectory to repeat"))
+
+
+def motion_planning(conn, device_id: int = 0, dp=None, on_infeasible: str = "previous", strict: bool = False):
     """Drop-in for the reference's planning process (test_9.py:92-220): ``multiprocessing.Process(target=
     motion_planning, args=(conn,))``.  Blocks on ``conn.recv()`` like the reference and creates its device context here,
-    in the child.  A request on which the reference raises IndexError (path_planning.py:63, :267) raises IndexError
-    here too - the child ends, as the reference's does.  A request whose path or smoothing QP is infeasible has no
-    faithful answer: the reference ignores cvxopt's status (path_planning.py:211-218) and sends whatever its last
-    iterate was.  Here the loop stays alive and answers ``(None, match_point_list, [], [])`` - the parent keeps its
-    previous path - unless ``strict``, which raises ValueError instead.  ``dp`` overrides the lattice
-    (default: the reference's keyword defaults, path_planning.py:277-279)."""
+    in the child.  A request on which the reference raises IndexError raises IndexError here too - the child ends, as the
+    reference's does.  A request whose path or smoothing QP is infeasible: see ``answer_refused`` (default: the previous
+    valid trajectory again, so that an UNMODIFIED driver keeps running; ``strict=True`` is ``on_infeasible="raise"``).
+    ``dp`` overrides the lattice (default: the reference's keyword defaults, path_planning.py:277-279)."""
     planner = Planner(device_id)                                            # created in the child process
+    previous = None
+    if strict:
+        on_infeasible = "raise"
     while 1:
         request = conn.recv()
         stages = {}
         reply, status = plan_requests(planner, [request], dp=dp, stages=stages)[0]
         if status & 1:
             print(INFEASIBLE_BANNER)                                        # path_planning.py:351
-        if reply is None:
-            if status & (2 | 4):
-                raise IndexError("list index out of range")
-            if strict:
-                raise ValueError("path or smoothing QP infeasible")
-            reply = (None, [int(stages["match"][0])], [], [])            # the new match index is still valid (test_9.py:99)
-        conn.send(reply)
+        if reply is not None:
+            previous = reply
+        conn.send(answer_refused(reply, status, stages["match"][0], previous, on_infeasible))

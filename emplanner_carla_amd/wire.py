@@ -76,6 +76,16 @@ class Layout:
     def from_hello(payload: bytes) -> "Layout":
         from .api import dp_params
         f = _HELLO.unpack(payload)
+        # A peer's HELLO sizes every buffer of the session (request / reply records, the device arrays of a batch): refuse
+        # anything a planner could not mean before a single byte is allocated from it.
+        import math
+        if not (1 <= f[0] <= MAX_ROW and 1 <= f[1] <= MAX_COL and 0 <= f[10] <= MAX_OBSTACLE_SLOTS and 0 <= f[11] <= MAX_OBSTACLE_SLOTS):
+            raise WireError(f"HELLO outside the limits: row {f[0]} (<= {MAX_ROW}), col {f[1]} (<= {MAX_COL}), obstacle slots "
+                            f"{f[10]} / {f[11]} (<= {MAX_OBSTACLE_SLOTS})")
+        if not all(math.isfinite(v) for v in f[2:10]) or not (f[2] > 0 and f[3] > 0 and f[4] > 0):
+            raise WireError("HELLO: sample_s, sample_l and sampling_res must be positive, every weight finite")
+        if f[1] * math.ceil(f[2] / f[4]) + 2 > MAX_PATH_POINTS:
+            raise WireError(f"HELLO: a path of col * ceil(sample_s / sampling_res) = {f[1] * math.ceil(f[2] / f[4])} points exceeds {MAX_PATH_POINTS}")
         dp = dp_params(row=f[0], col=f[1], sample_s=f[2], sample_l=f[3], sampling_res=f[4], w_collision_cost=f[5],
                        w_smooth_cost=[f[6], f[7], f[8]], w_reference_cost=f[9])
         lay = Layout(dp, f[10], f[11])
@@ -202,15 +212,20 @@ def recv_frame(sock, max_payload: int = 1 << 30):
     return ftype, count, _recv_exact(sock, length) if length else b""
 
 
+#: what a HELLO may ask for (the library itself takes rows <= 32... and paths of <= 255 points)
+MAX_ROW, MAX_COL, MAX_OBSTACLE_SLOTS, MAX_PATH_POINTS = 64, 256, 64, 255
+
+
 class PlannerServer:
     """``PlannerServer(plan_arrays).serve_forever()``: ``plan_arrays(arrays, dp) -> (st_ref, match, CycleResult, max_pts)``
     is what answers a batch (``serve`` below binds it to a GPU planner; tests bind a stub).  One thread per connection;
     the planner call itself is serialised (one device context)."""
 
     def __init__(self, plan_arrays, host: str = "127.0.0.1", port: int = 0, max_payload: int = 256 << 20,
-                 max_paths: int = 4096):
+                 max_paths: int = 4096, max_path_bytes: int = 64 << 20, max_reply_bytes: int = 256 << 20):
         self.plan_arrays = plan_arrays
         self.max_payload, self.max_paths = int(max_payload), int(max_paths)     # per frame / per session
+        self.max_path_bytes, self.max_reply_bytes = int(max_path_bytes), int(max_reply_bytes)   # per session / per frame
         self.sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self.sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         self.sock.bind((host, port))
@@ -250,10 +265,15 @@ class PlannerServer:
                             raise WireError("SET_PATH length does not match its point count")
                         if pid not in paths and len(paths) >= self.max_paths:
                             raise WireError(f"more than {self.max_paths} paths in one session")
+                        held = sum(v.nbytes for k, v in paths.items() if k != pid)
+                        if held + n * 32 > self.max_path_bytes:
+                            raise WireError(f"the session's global paths would exceed {self.max_path_bytes} bytes")
                         paths[pid] = np.frombuffer(payload, "<f8", n * 4, 8).reshape(n, 4).copy()
                     elif ftype == T_PLAN:
                         if layout is None:
                             raise WireError("PLAN before HELLO")
+                        if count * layout.reply_stride > self.max_reply_bytes:
+                            raise WireError(f"{count} replies of {layout.reply_stride} bytes exceed {self.max_reply_bytes}")
                         ids, arrays = layout.decode_requests(payload, count, paths)
                         with self._lock:
                             st_ref, match, res, _ = self.plan_arrays(arrays, layout.dp)
@@ -262,8 +282,10 @@ class PlannerServer:
                         return
                     else:
                         raise WireError(f"unknown frame type {ftype}")
-                except (WireError, struct.error, ValueError, RuntimeError) as exc:
-                    # a malformed frame or a planner error is answered, not dropped: the session goes on
+                except (ConnectionError, OSError):
+                    raise
+                except Exception as exc:      # noqa: BLE001 - whatever a hostile or broken frame provokes (arithmetic on
+                    # its fields, an index, memory) is answered, not dropped, and never kills the session thread silently
                     send_frame(conn, T_ERROR, f"{type(exc).__name__}: {exc}".encode())
         except (ConnectionError, OSError):
             pass
@@ -271,8 +293,9 @@ class PlannerServer:
             conn.close()
 
 
-def serve(host: str = "0.0.0.0", port: int = 5055, device_id: int = 0):
-    """The planner process: one GPU context, any number of client connections (``python -m emplanner_carla_amd.wire``)."""
+def serve(host: str = "127.0.0.1", port: int = 5055, device_id: int = 0):
+    """The planner process: one GPU context, any number of client connections (``python -m emplanner_carla_amd.wire``).
+    There is no authentication: the default binds the loopback interface; pass another address only on a trusted network."""
     from . import service
     from .api import Planner
     planner = Planner(device_id)
@@ -324,25 +347,25 @@ class PlannerClient:
         self.sock.close()
 
 
-def motion_planning_remote(conn, host: str, port: int, dp=None):
+def motion_planning_remote(conn, host: str, port: int, dp=None, on_infeasible: str = "previous"):
     """Drop-in body of the reference's planning process (test_9.py:92-220) that plans on a remote server: requests come in
     over the driver's Pipe, go out over the socket, the reply tuple goes back over the Pipe.  Failure handling as in
-    ``service.motion_planning``."""
+    ``service.motion_planning`` (``service.answer_refused``)."""
+    from .service import answer_refused
     client = PlannerClient(host, port, dp=dp)
+    previous = None
     while 1:
         request = conn.recv()
         reply, status = client.plan([request])[0]
-        if reply is None:
-            if status & (2 | 4):
-                raise IndexError("list index out of range")
-            reply = (None, [int(request[7][0])], [], [])
-        conn.send(reply)
+        if reply is not None:
+            previous = reply
+        conn.send(answer_refused(reply, status, request[7][0], previous, on_infeasible))
 
 
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser(description="EM-Planner service on the GPU (wire format: emplanner_carla_amd/wire.py)")
-    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--host", default="127.0.0.1", help="interface to bind (no authentication: loopback by default)")
     ap.add_argument("--port", type=int, default=5055)
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args()

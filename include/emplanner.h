@@ -134,10 +134,12 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  *   n = 2..EMP_PIPELINE_MAX  n batches on n lanes (a stream and a pool of temporaries each; ABI version 7): call k runs
  *                          whole on lane k mod n, behind everything queued on emp_stream() when it is issued, and the
  *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.27 ms
- *                          per step) at the price of every kernel's own duration (the sweep: 45 us).  Needs as many
- *                          hardware queues as streams: the library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless
- *                          the variable is already set (the HIP runtime reads it when it initialises; its default of 4
- *                          makes lanes share a queue and serialises them).
+ *                          per step) at the price of every kernel's own duration (the sweep: 45 us).  Wants as many
+ *                          hardware queues as streams (n lanes + emp_stream()): the HIP runtime maps a process's streams
+ *                          onto GPU_MAX_HW_QUEUES queues (default 4) and reads the variable when it initialises, so the
+ *                          HOST PROGRAM exports e.g. GPU_MAX_HW_QUEUES=8 before it first touches HIP - the library does
+ *                          not change the environment.  With fewer queues lanes share one and serialise (3 lanes on 4
+ *                          queues beside torch's stream: slower than 2); beyond 7 lanes they share in any case.
  * Consequences for the caller: the outputs of a call are complete on emp_result_stream() - in lane mode the lane of the
  * LATEST emp_plan_cycle call, so ask after every call - and emp_synchronize waits for every stream; each call in flight
  * needs its OWN output buffers, and its inputs must stay unchanged until it is done.  Every other entry point first

@@ -110,6 +110,40 @@ def _segment_cost(a, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w_smooth, w_ref)
     return (smooth + coll) + w_ref * S_l
 
 
+def jerk_quirk_sum_sample_loop(a3, a4, a5, s0, sample_s):
+    """The reference's third-derivative sum in ITS order (path_planning.py:492-499 / :565-572): per sample
+    s_i = s0 + i sample_s / 10 the term 6 c3 + 24 c4 s_i + 60 c5 (s_i * 2), squared and accumulated sample by sample -
+    from the same exact absolute-s coefficients as the closed form in `_segment_cost`.  Not used by any parity test of
+    the kernels (they and `_segment_cost` use the closed form 10 A^2 + 2 A K1 T1 + K1^2 T2, a different rounding of the
+    same number); tests/test_oracle_golden.py checks that the two agree to a few ulp of the sum's largest term, so that
+    the closed form cannot drift from the reference's arithmetic unnoticed."""
+    a3, a4, a5, s0 = np.broadcast_arrays(*(np.asarray(v, dtype=np.float64) for v in (a3, a4, a5, s0)))
+    c5 = a5
+    c4 = a4 - (5.0 * a5) * s0
+    c3 = (a3 - (4.0 * a4) * s0) + ((10.0 * a5) * s0) * s0
+    total = np.zeros(a3.shape)
+    for i in range(10):
+        s = s0 + (i * sample_s) / 10.0
+        d3 = (6.0 * c3 + (24.0 * c4) * s) + (60.0 * c5) * (s * 2.0)
+        total = total + d3 * d3
+    return total
+
+
+def jerk_quirk_sum_closed_form(a3, a4, a5, s0, sample_s):
+    """The closed form as `_segment_cost` and csrc/emp_core.h (jerk_quirk_sum) evaluate it, operation for operation."""
+    a3, a4, a5, s0 = np.broadcast_arrays(*(np.asarray(v, dtype=np.float64) for v in (a3, a4, a5, s0)))
+    c4 = a4 - (5.0 * a5) * s0
+    c3 = (a3 - (4.0 * a4) * s0) + ((10.0 * a5) * s0) * s0
+    T1 = T2 = 0.0
+    for i in range(10):
+        t = (i * sample_s) / 10.0
+        T1 = T1 + t
+        T2 = T2 + t * t
+    K1 = 24.0 * c4 + (60.0 * a5) * 2.0
+    A = 6.0 * c3 + K1 * s0
+    return (10.0 * (A * A) + (2.0 * A) * (K1 * T1)) + (K1 * K1) * T2
+
+
 def lattice_l(row, sample_l):
     """Lateral offset of lattice row i (reference path_planning.py:326)."""
     return ((row + 1) / 2 - 1 - np.arange(row)) * sample_l

@@ -287,3 +287,25 @@ def test_only_the_cycle_call_is_ordered_on_the_result_stream():
     assert "self.planner.pipelined and self.cycle" in done and "torch_result_stream()" in done
     code = "\n".join(line.split("#")[0] for line in done.split('"""')[2].splitlines())
     assert ".record_stream(" not in code, "outputs are kept alive by Planner.plan_cycle, not tied to a stream"
+
+
+def test_planning_loop_policy_for_refused_requests():
+    """service.answer_refused: what the planning process sends when a request has no plan (no GPU involved).  IndexError
+    statuses raise as in the reference; an infeasible QP repeats the previous trajectory by default (an unmodified
+    reference driver hands element 0 of the reply to its controller, test_9.py:395-399), raises or sends the sentinel on
+    request."""
+    from emplanner_carla_amd.service import answer_refused
+    prev = ([(0.0, 0.0, 0.0, 0.0)], [7], [1.0], [0.5])
+    good = ([(1.0, 1.0, 0.0, 0.0)], [9], [2.0], [0.25])
+    assert answer_refused(good, 0, 9, prev, "previous") is good
+    assert answer_refused(None, 8, 11, prev, "previous") == (prev[0], [11], prev[2], prev[3])
+    assert answer_refused(None, 16, 11, prev, "sentinel") == (None, [11], [], [])
+    for status in (2, 4, 2 | 8):
+        with pytest.raises(IndexError):
+            answer_refused(None, status, 11, prev, "previous")
+    with pytest.raises(ValueError):
+        answer_refused(None, 8, 11, prev, "raise")
+    with pytest.raises(ValueError, match="no previous"):
+        answer_refused(None, 8, 11, None, "previous")
+    with pytest.raises(ValueError, match="on_infeasible"):
+        answer_refused(None, 8, 11, prev, "whatever")

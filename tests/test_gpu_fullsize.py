@@ -380,6 +380,54 @@ def test_pipelined_cycles_equal_plain_cycles(planner, pipe):
         planner.set_pipeline(False)
 
 
+@pytest.mark.parametrize("pipe", [2, 3])
+def test_lanes_of_very_different_durations_do_not_reuse_live_outputs(planner, pipe):
+    """Lane mode with a caller that works on the planner's stream, packs each call's records on its result stream and
+    drops the results at once (what bench.py's multi-GPU step does), on batches of VERY different sizes: a 4096-scene
+    call holds its lane for many small calls of the other lanes, whose outputs torch's allocator carves out of whatever
+    was released last.  Every call's records must equal the plain, unpipelined call's.  (Round-2 review: the layer
+    released call k's outputs when call k + n was issued, and call k + n + 1 - on another lane, ordered against nothing
+    but the main stream - could be handed that memory while call k still ran.)"""
+    import torch
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    M = None
+    dev = torch.device("cuda:0")
+    sizes = [4096, 48, 64, 80, 48, 64, 4096, 96, 48, 64, 80, 48, 2048, 64, 48]
+    batches = []
+    for k, n in enumerate(sizes):
+        b = S.make_batch(range(700 * k, 700 * k + n), cfg)
+        batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+    from emplanner_carla_amd.api import max_path_points
+    M = max_path_points(p)
+    torch.cuda.synchronize()
+    planner.set_pipeline(0)
+    want = []
+    for ins in batches:
+        r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+        want.append(planner.pack_records(r, p.col, M).cpu().numpy())
+    planner.synchronize()
+    planner.set_pipeline(pipe)
+    try:
+        ts = planner.torch_stream()
+        for rep in range(3):
+            got = []
+            with torch.cuda.stream(ts):
+                for ins in batches:
+                    r = planner.plan_cycle(p, q, sp, max_pts=M, **ins)
+                    got.append(planner.pack_records(r, p.col, M))
+                    del r                                    # the layer alone keeps the outputs of the calls in flight
+            planner.synchronize()
+            torch.cuda.synchronize()
+            for k, (g, w) in enumerate(zip(got, want)):
+                g = g.cpu().numpy()
+                ok = (w[:, 0].astype(np.int64) & ~1) == 0          # refused scenes: only the status is specified
+                assert np.array_equal(g[:, 0], w[:, 0]), f"round {rep}, call {k}: status"
+                assert np.array_equal(g[ok], w[ok]), f"round {rep}, call {k} ({sizes[k]} scenes): records differ from the plain call"
+    finally:
+        planner.set_pipeline(0)
+
+
 @pytest.mark.parametrize("pipe", PIPE_MODES)
 def test_pipelined_records_packed_on_the_result_stream(planner, pipe):
     """What a rank of the multi-GPU bench does per step when several batches are in flight: plan on the planner's first

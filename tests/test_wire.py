@@ -122,6 +122,37 @@ def test_server_loop_with_a_stub_planner():
         bad[-8:-4] = (lay.cap + 1).to_bytes(4, "little")
         with pytest.raises(wire.WireError):
             wire.Layout.from_hello(bytes(bad))
+        # a HELLO sizes every buffer of the session: lattices and capacities no planner means are refused before anything
+        # is allocated from them, non-positive spacings before anything divides by them (round-2 review)
+        import struct
+        good = list(wire._HELLO.unpack(wire.Layout(dp_params()).hello()))
+        for field, value in ((0, 10 ** 6), (0, 0), (1, 10 ** 7), (1, -3), (10, 2 ** 31), (11, 10 ** 5), (2, 0.0), (4, 0.0), (4, -1.0),
+                             (3, float("nan")), (2, float("inf")), (4, 1e-9)):
+            f = list(good)
+            f[field] = value
+            with pytest.raises(wire.WireError, match="HELLO"):
+                wire.Layout.from_hello(wire._HELLO.pack(*f))
+        # and a session survives a hostile HELLO: ERROR frame, then business as usual
+        cl = wire.PlannerClient(*srv.address, dp=dp_params(sample_s=14.7), max_static=4, max_dynamic=2)
+        f = list(good)
+        f[1] = 10 ** 7
+        wire.send_frame(cl.sock, wire.T_HELLO, wire._HELLO.pack(*f))
+        ftype, _, payload = wire.recv_frame(cl.sock)
+        assert ftype == wire.T_ERROR and b"HELLO" in payload
+        assert cl.plan(reqs[:1])[0][0] is not None
+        # per-session cap on the global paths held
+        small = wire.PlannerServer(stub, max_path_bytes=2000)
+        threading.Thread(target=small.serve_forever, daemon=True).start()
+        try:
+            c2 = wire.PlannerClient(*small.address, dp=dp_params(sample_s=14.7), max_static=4, max_dynamic=2)
+            wire.send_frame(c2.sock, wire.T_SET_PATH, struct.pack("<II", 1, 50) + np.zeros((50, 4)).tobytes())      # 1600 B: fine
+            wire.send_frame(c2.sock, wire.T_SET_PATH, struct.pack("<II", 2, 50) + np.zeros((50, 4)).tobytes())      # 3200 B: refused
+            ftype, _, payload = wire.recv_frame(c2.sock)
+            assert ftype == wire.T_ERROR and b"exceed" in payload
+            c2.close()
+        finally:
+            small.shutdown()
+        cl.close()
     finally:
         srv.shutdown()
 
