@@ -53,6 +53,7 @@ if record:
                 "insts_valu": int(v["SQ_INSTS_VALU"]), "insts_salu": int(v["SQ_INSTS_SALU"]),
                 "valu_busy_quad_cycles": int(v["SQ_ACTIVE_INST_VALU"]),
                 "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
+                "valu_issue_busy_frac": round(v["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0 / (v["SQ_BUSY_CYCLES"] / 32.0), 4),
                 "source": f"profiles/{tag}_sq.csv (rocprofv3 --pmc SQ passes of bench.py --no-pipeline, tools/pmc_sq.sh)"},
                 ("config", "scenes_per_gpu", "scene_dist"))
         if k.startswith("speed_dp_kernel"):
