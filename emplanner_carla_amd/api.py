@@ -356,7 +356,7 @@ class Planner:
         self._check(self._lib.emp_dp_edge_costs(
             self._h, C.byref(p), B, mo, a.inp(obs_s, np.float64, (B, mo)), a.inp(obs_l, np.float64, (B, mo)),
             a.inp(n_obs, np.int32, (B,)), a.inp(start, np.float64, (B, 4)), c0p, ep, int(layout), a.where))
-        if layout == L.EMP_EDGE_CANONICAL:
+        if layout == L.EMP_EDGE_CANONICAL or p.row > 32:      # beyond 32 rows the library's tensor is the canonical one either way
             e = e.reshape(B, p.col - 1, p.row, p.row)
         return c0, e
 

@@ -12,17 +12,18 @@
 
 namespace emp {
 thread_local std::string g_create_error;
+constexpr int kMaxTiledRow = 32;       // the tiled kernels (scenes packed into wavefronts, pair table in LDS) up to here
 
 static int make_dp_dev(emp_ctx* ctx, const emp_dp_params* p, int B, int max_obs, DpDev* d) {
     EMP_REQUIRE(ctx, p != nullptr, "dp params are NULL");
-    EMP_REQUIRE(ctx, p->row >= 1 && p->row <= 32, "row must be in [1, 32]");
+    EMP_REQUIRE(ctx, p->row >= 1 && p->row <= kMaxWideRow, "row must be in [1, 256]");
     EMP_REQUIRE(ctx, p->col >= 1 && p->col <= 255 * 16, "col must be in [1, 4080]");
     EMP_REQUIRE(ctx, B >= 0, "negative batch");
     EMP_REQUIRE(ctx, max_obs >= 0 && max_obs <= 256, "max_obs must be in [0, 256]");
     EMP_REQUIRE(ctx, p->sample_s > 0 && p->sample_l > 0 && p->sampling_res > 0, "sample_s, sample_l, sampling_res must be > 0");
     d->row = p->row;
     d->col = p->col;
-    d->S = 64 / p->row;
+    d->S = p->row <= kMaxTiledRow ? 64 / p->row : 1;      // wider lattices: one scene per block, canonical edge tensor
     d->tiles = (B + d->S - 1) / d->S;
     d->B = B;
     d->max_obs = max_obs > 0 ? max_obs : 1;
@@ -37,7 +38,12 @@ static int make_dp_dev(emp_ctx* ctx, const emp_dp_params* p, int B, int max_obs,
     return EMP_OK;
 }
 
-static size_t tiled_elems(const DpDev& d) { return (size_t)d.tiles * (size_t)(d.col - 1) * d.row * 64; }
+static bool wide(const DpDev& d) { return d.row > kMaxTiledRow; }
+// elements of the edge tensor the DP kernels exchange: tiled up to 32 rows, canonical [B][col-1][row][row] beyond
+static size_t tiled_elems(const DpDev& d) {
+    if (wide(d)) return (size_t)d.B * (size_t)(d.col - 1) * d.row * d.row;
+    return (size_t)d.tiles * (size_t)(d.col - 1) * d.row * 64;
+}
 
 // ---- device-level stage launchers (all pointers are device memory; nothing synchronises) -----
 // pair table of the lattice (emp_dp_kernels.h dp_pair_table_kernel): rebuilt only when the lattice parameters change,
@@ -65,6 +71,16 @@ static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
 static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, double* start_cost, double* edge, bool tiled) {
     if (d.B == 0) return EMP_OK;
+    if (wide(d)) {          // more than 32 rows: generic kernel, canonical tensor whatever `tiled` says (emp_dp_kernels.h)
+        const double* pair_tab = nullptr;
+        { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
+        EMP_REQUIRE(ctx, d.B <= 0x7fffffff && d.col - 1 <= 65535, "batch or lattice too large for the wide-row edge kernel's grid");
+        KernelTimer t(ctx, "dp_edge");
+        hipLaunchKernelGGL(dp_edge_wide_kernel, dim3(d.B, d.col > 1 ? d.col - 1 : 1), dim3(((d.row + 63) / 64) * 64), 0, ctx->stream,
+                           d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge);
+        EMP_LAUNCH_CHECK(ctx);
+        return EMP_OK;
+    }
     const size_t lds = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples + kSampleMoments) * sizeof(double);
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
     int ncol = d.col - 1;
@@ -94,6 +110,16 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
 static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, const double* edge,
                         const int* n_obs, double* rows, double* min_cost, int* status) {
     if (d.B == 0) return EMP_OK;
+    if (wide(d)) {          // more than 32 rows: one block per scene, predecessors in device memory
+        emp_ctx::Buf& pre = ctx->named["dp_wide_pre_" + std::to_string(ctx->active_lane)];
+        const int grc = grow_buffer(ctx, pre, (size_t)d.B * d.col * d.row);
+        if (grc) return grc;
+        KernelTimer t(ctx, "dp_sweep");
+        hipLaunchKernelGGL(dp_sweep_wide_kernel, dim3(d.B), dim3(((d.row + 63) / 64) * 64), 2 * (size_t)d.row * sizeof(double),
+                           ctx->stream, d, start_cost, edge, n_obs, (unsigned char*)pre.p, rows, min_cost, status);
+        EMP_LAUNCH_CHECK(ctx);
+        return EMP_OK;
+    }
     static const int variant = getenv("EMP_SWEEP_VARIANT") ? atoi(getenv("EMP_SWEEP_VARIANT")) : 0;
     KernelTimer t(ctx, "dp_sweep", true);   // the roofline kernel: events stamped by the dispatch itself
 #define EMP_SWEEP(R, PD, WPB) EMP_SWEEP_NT(R, PD, WPB, false)
@@ -205,7 +231,8 @@ static int dev_dp_fused(emp_ctx* ctx, const DpDev& d, const double* obs_s, const
 static int dev_dp_plan(emp_ctx* ctx, const DpDev& d, const double* obs_s, const double* obs_l, const int* n_obs,
                        const double* start, emp_dp_mode mode, double* rows, double* min_cost, int* status) {
     if (d.B == 0) return EMP_OK;
-    if (mode == EMP_DP_FUSED) return dev_dp_fused(ctx, d, obs_s, obs_l, n_obs, start, rows, min_cost, status);
+    // the single-kernel form lives on the tiled layout: lattices wider than 32 rows take the two-kernel form either way
+    if (mode == EMP_DP_FUSED && !wide(d)) return dev_dp_fused(ctx, d, obs_s, obs_l, n_obs, start, rows, min_cost, status);
     double *edge, *start_cost;
     int rc = dp_edge_tensor(ctx, d, &edge, &start_cost);
     if (rc) return rc;
@@ -534,8 +561,8 @@ double emp_kernel_ms(emp_ctx* ctx, const char* kernel) {
 
 // ---- DP ----------------------------------------------------------------------------------
 uint64_t emp_edge_tensor_elems(const emp_dp_params* p, int32_t B, emp_edge_layout layout) {
-    if (!p || p->row < 1 || p->row > 64 || p->col < 1 || B < 0) return 0;
-    if (layout == EMP_EDGE_CANONICAL) return (uint64_t)B * (p->col - 1) * p->row * p->row;
+    if (!p || p->row < 1 || p->row > emp::kMaxWideRow || p->col < 1 || B < 0) return 0;
+    if (layout == EMP_EDGE_CANONICAL || p->row > emp::kMaxTiledRow) return (uint64_t)B * (p->col - 1) * p->row * p->row;
     const int S = 64 / p->row;
     const uint64_t tiles = ((uint64_t)B + S - 1) / S;
     return tiles * (uint64_t)(p->col - 1) * p->row * 64;

@@ -430,6 +430,115 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// lattices wider than 32 rows (ref path_planning.py:276-279 takes any `row`; its loops :301-346)
+// ---------------------------------------------------------------------------------------------
+// The tiled kernels above pack 64 / row scenes into a wavefront and keep the pair table (17 row^2 doubles) in LDS; beyond
+// 32 rows neither holds (one scene no longer fits a wavefront past 64 rows, the table no longer fits the LDS past 34).
+// Wide lattices take this generic pair instead - the same device functions on the same operands, so the results are
+// bit-identical to what the tiled kernels would compute - with the edge tensor in the canonical layout
+// [B][col-1][i][k] (k fastest): correctness for every `row` up to kMaxWideRow, not speed (the reference's own
+// default is 12 rows; BASELINE's widest lattice has 21).
+constexpr int kMaxWideRow = 256;       // a predecessor index is one byte
+
+// grid = (B, max(col - 1, 1)), block = row rounded up to a wavefront (<= 256 threads): thread i costs the `row` edges
+// from column j-1 into row i of column j; pair table, sample offsets and obstacles are read from device memory.
+__global__ __launch_bounds__(256) void dp_edge_wide_kernel(DpDev P, const double* __restrict__ pair_tab,
+                                                           const double* __restrict__ obs_s, const double* __restrict__ obs_l,
+                                                           const int* __restrict__ n_obs, const double* __restrict__ start,
+                                                           double* __restrict__ start_cost, double* __restrict__ edge) {
+    const int row = P.row, rr = P.row * P.row;
+    const int b = blockIdx.x, j = 1 + blockIdx.y, i = threadIdx.x;
+    if (i >= row) return;
+    const int nob = min(max(n_obs[b], 0), P.max_obs);
+    const double* my_obs_s = obs_s + (size_t)b * P.max_obs;
+    const double* my_obs_l = obs_l + (size_t)b * P.max_obs;
+    if (blockIdx.y == 0 && start_cost != nullptr) {      // start edges (column 0), ref :306-318
+        const double ps = start[b * 4 + 0], pl = start[b * 4 + 1], pdl = start[b * 4 + 2], pddl = start[b * 4 + 3];
+        const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, i, P.sample_l), P.sample_s);
+        start_cost[(size_t)b * row + i] = segment_cost(q, ps, P.sample_s, my_obs_s, my_obs_l, nob, P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+    }
+    if (j >= P.col) return;
+    const double* t_smp = pair_tab + (size_t)kTableFields * rr;
+    double* out = edge + (size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + (size_t)i * row;
+    dp_edge_column(P, j, i, start[b * 4 + 0], nob, pair_tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) { out[k] = cost; });
+}
+
+// One block per scene, thread i = destination row (rows beyond the block size are taken in strides); the cost front
+// of the previous column lives in LDS (two buffers), predecessors in device memory `pre` [B][col][row] bytes.  The
+// arithmetic of dp_sweep_kernel's generic path: cand = (front[k] + e) (+ 10000 on the penalty rows), strict '<' with k
+// ascending from (+inf, predecessor 1), first-minimum terminal, bypass without obstacles (ref :301-363).
+__global__ __launch_bounds__(256) void dp_sweep_wide_kernel(DpDev P, const double* __restrict__ start_cost,
+                                                            const double* __restrict__ edge, const int* __restrict__ n_obs,
+                                                            unsigned char* __restrict__ pre, double* __restrict__ rows_out,
+                                                            double* __restrict__ min_cost_out, int* __restrict__ status_out) {
+    extern __shared__ double front_lds[];                 // [2][row]
+    const int row = P.row, rr = P.row * P.row;
+    const int b = blockIdx.x;
+    const double INF = __builtin_inf();
+    double* cur = front_lds;
+    double* nxt = front_lds + row;
+    for (int i = threadIdx.x; i < row; i += blockDim.x) {
+        double c = start_cost[(size_t)b * row + i];
+        if (i < (row >> 1)) c = c + kLanePenalty;         // ref :318
+        cur[i] = c;
+    }
+    __syncthreads();
+    unsigned char* my_pre = pre + (size_t)b * P.col * row;
+    for (int j = 1; j < P.col; ++j) {
+        const double* ej = edge + (size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr;
+        for (int i = threadIdx.x; i < row; i += blockDim.x) {
+            const bool left = i < (row >> 1);
+            double best = INF;
+            int arg = 1;                                  // ref :304
+            for (int k = 0; k < row; ++k) {
+                double cand = cur[k] + ej[(size_t)i * row + k];   // ref :340
+                if (left) cand = cand + kLanePenalty;             // ref :342
+                if (cand < best) {                                // strict, k ascending (:344)
+                    best = cand;
+                    arg = k;
+                }
+            }
+            nxt[i] = best;
+            my_pre[(size_t)j * row + i] = (unsigned char)arg;
+        }
+        __syncthreads();
+        double* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (threadIdx.x == 0) {
+        const bool bypass = (n_obs != nullptr) && (n_obs[b] == 0);
+        double* out = rows_out + (size_t)b * P.col;
+        if (bypass) {                                     // ref :362-363 no obstacles: centre row, DP skipped
+            const double centre = (double)(row + 1) / 2.0 - 1.0;
+            for (int j = 0; j < P.col; ++j) out[j] = centre;
+            if (min_cost_out) min_cost_out[b] = INF;
+            status_out[b] = 0;
+        } else {
+            double best = INF;
+            int arg = 0;
+            bool first = true;
+            for (int k = 0; k < row; ++k) {               // first minimum, ref :349
+                const double ck = cur[k];
+                if (first || ck < best) {
+                    best = ck;
+                    arg = k;
+                    first = false;
+                }
+            }
+            int idx = arg;
+            out[P.col - 1] = (double)idx;
+            for (int j = P.col - 1; j >= 1; --j) {        // ref :355-359
+                idx = my_pre[(size_t)j * row + idx];
+                out[j - 1] = (double)idx;
+            }
+            if (min_cost_out) min_cost_out[b] = best;
+            status_out[b] = (best > P.w_coll) ? 1 : 0;    // ref :351 (EMP_ST_DP_INFEASIBLE)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused DP: edge costs staged in LDS and swept in place (EMP_DP_FUSED)
 // ---------------------------------------------------------------------------------------------
 // ref: DP_algorithm up to the backtrack, path_planning.py:301-361, as ONE kernel that never writes the edge tensor.

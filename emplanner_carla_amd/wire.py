@@ -212,8 +212,8 @@ def recv_frame(sock, max_payload: int = 1 << 30):
     return ftype, count, _recv_exact(sock, length) if length else b""
 
 
-#: what a HELLO may ask for (the library itself takes rows <= 32... and paths of <= 255 points)
-MAX_ROW, MAX_COL, MAX_OBSTACLE_SLOTS, MAX_PATH_POINTS = 64, 256, 64, 255
+#: what a HELLO may ask for (the library itself takes rows <= 256 and paths of <= 255 points)
+MAX_ROW, MAX_COL, MAX_OBSTACLE_SLOTS, MAX_PATH_POINTS = 256, 256, 64, 255
 
 
 class PlannerServer:

@@ -178,7 +178,11 @@ int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
  *   EMP_EDGE_CANONICAL  edge[b][j-1][i][k]  k fastest: cost of row k (column j-1) -> row i (column j)
  *   EMP_EDGE_TILED      the layout the sweep kernel streams: scenes are grouped in tiles of
  *                       S = 64 / row scenes and stored [tile][j-1][k][s][i] so that one wavefront
- *                       reads 64 consecutive doubles per source row k         */
+ *                       reads 64 consecutive doubles per source row k
+ * `row` may be anything in [1, 256] (ref path_planning.py:276-279 takes any; :301-346).  Up to 32 rows the DP runs on the
+ * tiled kernels; wider lattices take a generic pair of kernels (one block per scene, pair table in device memory) whose
+ * tensor is the CANONICAL one whichever layout is asked for (emp_edge_tensor_elems says so), and EMP_DP_FUSED falls back
+ * to the two-kernel form there.  Same arithmetic, bit for bit; built for correctness, not measured for speed.           */
 typedef enum emp_edge_layout { EMP_EDGE_CANONICAL = 0, EMP_EDGE_TILED = 1 } emp_edge_layout;
 uint64_t emp_edge_tensor_elems(const emp_dp_params* p, int32_t B, emp_edge_layout layout);
 
@@ -211,7 +215,7 @@ int emp_dp_plan(emp_ctx* ctx, const emp_dp_params* p, int32_t B, int32_t max_obs
                 emp_dp_mode mode, double* rows, double* min_cost, int32_t* status, emp_mem where);
 
 /* min-plus sweep + backtrack on caller-provided costs (ref: path_planning.py:301-361), for tests
- * and for the HBM-roofline measurement.  start_cost [B][row], edge in EMP_EDGE_TILED layout. */
+ * and for the HBM-roofline measurement.  start_cost [B][row], edge in EMP_EDGE_TILED layout (canonical beyond 32 rows). */
 int emp_dp_sweep(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double* start_cost, const double* edge,
                  double* rows, double* min_cost, int32_t* status, emp_mem where);
 

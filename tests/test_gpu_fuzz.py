@@ -25,6 +25,9 @@ SHAPES = [  # row, col, sample_s, sample_l, res, n_obs
     (3, 12, 7.5, 1.5, 2, 2), (4, 20, 4.5, 1.0, 1, 4), (6, 16, 5.2, 1.2, 2, 3), (7, 30, 3.2, 1.0, 1, 6),
     (9, 24, 2.5, 1.5, 2, 8), (11, 14, 6.3, 0.8, 2, 5), (15, 18, 4.2, 0.6, 2, 7), (5, 10, 9.3, 1.5, 1, 0),
     (12, 8, 10.4, 1.0, 2, 12), (21, 26, 3.5, 0.5, 1, 9),
+    # wider than 32 rows (round 3): the generic one-block-per-scene kernels - 33 and 48 (one scene per wavefront), 64 (a full
+    # wavefront), 80 (two wavefronts per scene), each with lateral spacings that keep the lattice inside +-7 m
+    (33, 10, 4.2, 0.4, 2, 6), (48, 7, 5.3, 0.3, 1, 5), (64, 6, 6.1, 0.22, 2, 8), (80, 5, 4.6, 0.18, 2, 4),
 ]
 
 
@@ -98,3 +101,36 @@ def test_cycle_vs_port_on_random_lattices(planner, i):
         assert_rel(r.traj[k, :m, 3], want[:, 3], 1e-6, "kappa")
         compared += 1
     assert compared >= 1 or cfg.n_obs >= 9
+
+
+@pytest.mark.parametrize("row", [33, 80, 200])
+def test_wide_lattice_edge_tensor_bit_exact_and_layout(planner, row):
+    """More than 32 rows: the generic kernels' edge tensor equals oracle/exact.py bit for bit, the 'tiled' layout IS the
+    canonical one there, the single-kernel DP mode falls back to the two-kernel form, and the sweep entry point consumes
+    the tensor the edge entry point produced."""
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd.api import dp_params_from_cfg
+    cfg = S.LatticeConfig(f"wide_{row}", row=row, col=4, sample_s=5.7, sample_l=13.0 / row, sampling_res=2, n_obs=5, n_ref=40)
+    b = S.make_batch(range(300, 300 + 6), cfg)
+    p = dp_params_from_cfg(cfg)
+    c0, e = planner.dp_edge_costs(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    x0, xe = ex.edge_costs(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l)
+    np.testing.assert_array_equal(c0, x0)
+    np.testing.assert_array_equal(e, xe)
+    c0t, et = planner.dp_edge_costs(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, layout=L.EMP_EDGE_TILED)
+    np.testing.assert_array_equal(et, e)
+    assert planner.edge_tensor_elems(p, 6, L.EMP_EDGE_TILED) == 6 * 3 * row * row
+    rows, mc, st = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    rows_f, mc_f, st_f = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, mode=L.EMP_DP_FUSED)
+    np.testing.assert_array_equal(rows, rows_f)
+    np.testing.assert_array_equal(mc, mc_f)
+    xrows, xfeas, _ = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l, cfg.sampling_res)
+    np.testing.assert_array_equal(rows, xrows)
+    np.testing.assert_array_equal((st & 1) == 1, ~xfeas)
+    if hasattr(planner, "dp_sweep"):
+        r2, m2, s2 = planner.dp_sweep(p, c0, np.ascontiguousarray(et).reshape(-1))
+        sel = b.n_obs > 0                                  # the sweep entry point knows no bypass
+        np.testing.assert_array_equal(r2[sel], rows[sel])
+    with pytest.raises(Exception):
+        planner.dp_plan(dp_params_from_cfg(S.LatticeConfig("too_wide", row=257, col=3, sample_s=5.0, sample_l=0.05, sampling_res=2,
+                                                           n_obs=0, n_ref=30)), b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
