@@ -218,7 +218,7 @@ def main():
                     "command holds one mode's launches only)")
     ap.add_argument("--force-gather-path", action="store_true",
                     help="run the N > 1 per-step code (pack + gather streams) on one GPU; the gather itself is then the identity")
-    ap.add_argument("--gather", choices=["rank0", "all"], default="rank0",
+    ap.add_argument("--gather", choices=["rank0", "all", "none"], default="rank0",
                     help="N > 1: gather the records to rank 0 (default: what BASELINE's 'RCCL gather' asks for) or all_gather them")
     ap.add_argument("--records", choices=["full", "trajectory"], default="full",
                     help="what a record carries: everything a cycle returns (179 doubles per scene at 40x9) or status + "
@@ -290,11 +290,12 @@ def main():
     pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()
 
-    gather_path = world > 1 or args.force_gather_path
+    gather_path = (world > 1 or args.force_gather_path) and args.gather != "none"     # "none": compute scaling only
     sg = None
     if gather_path:      # the per-step result exchange (emplanner_carla_amd/dist.py StepGather): pack on the result stream,
         sg = emp_dist.StepGather(p.col, M, total, planner=pl, fields=args.records, device=device,     # gather on its own
-                                 dst=0 if args.gather == "rank0" else None)
+                                 dst=0 if args.gather == "rank0" else None, timing=True)
+    with_gather = [gather_path]
 
     def step():
         # torch work of a step runs on the planner's own streams, ordered with its kernels without any cross-stream
@@ -308,7 +309,7 @@ def main():
                 sets = pl.st_graph(*st_inputs[0])
                 pl.speed_dp(sdp, *sets, st_inputs[1], tables=False)
                 pl.set_fence(True)
-        return sg.submit(res) if gather_path else res, res
+        return sg.submit(res) if with_gather[0] else res, res
 
     def fence():
         pl.synchronize()
@@ -330,17 +331,59 @@ def main():
     # Inside the timed region only the roofline kernel is bracketed by HIP events (an event pair costs a few
     # microseconds of stream time per launch; six bracketed kernels per step cost ~7 % of the step).
     pl.set_timing(True, only="dp_sweep")
+    if sg is not None:
+        sg.timed = []                    # the gathers of the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, res = step()
     fence()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if world > 1:
         el = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
     sweep_ms, sweep_launches = pl.kernel_ms("dp_sweep"), pl.kernel_launches("dp_sweep")
+    # ---- what a first multi-GPU run needs to explain itself (N > 1, or the N > 1 code forced onto one GPU) -------------
+    diag = None
+    if gather_path:
+        sg.drain()
+        gms = sg.gather_ms()
+        per_rank = [elapsed / args.steps * 1e3]
+        if world > 1:
+            mine = torch.tensor([local_elapsed / args.steps * 1e3], dtype=torch.float64, device=device)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [float(x.item()) for x in allr]
+        # the same K steps WITHOUT pack and gather, between the same fences: what the exchange costs the step
+        fence()
+        pl.set_timing(False)
+        with_gather[0] = False
+        for _ in range(max(2, 2 * in_flight)):
+            step()
+        fence()
+        n0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        nog = time.perf_counter() - n0
+        if world > 1:
+            el2 = torch.tensor([nog], dtype=torch.float64, device=device)
+            dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+            nog = float(el2.item())
+        with_gather[0] = True
+        ms_with, ms_without = elapsed / args.steps * 1e3, nog / args.steps * 1e3
+        diag = {"backend": (dist.get_backend() if world > 1 else "none (one process)"),
+                "world_size_seen_by_the_process_group": (dist.get_world_size() if world > 1 else 1),
+                "ms_per_step_per_rank": [round(v, 4) for v in per_rank],
+                "ms_per_step_min_max_over_ranks": [round(min(per_rank), 4), round(max(per_rank), 4)],
+                "ms_per_step_without_pack_and_gather": round(ms_without, 4),
+                "gather_ms_on_its_stream": None if gms is None else {"mean": round(gms[0], 4), "min": round(gms[1], 4), "max": round(gms[2], 4), "count": gms[3]},
+                "gather_hidden_behind_compute_frac": None}
+        if gms is not None and gms[0] > 0:
+            exposed = max(0.0, ms_with - ms_without)
+            diag["gather_hidden_behind_compute_frac"] = round(max(0.0, 1.0 - exposed / gms[0]), 3)
     # The other pipeline form, as a second, separately reported measurement (same steps, same fences; N = 1 only): the
     # headline is taken in the form that keeps the sweep's bandwidth, lane mode trades it for throughput.
     alt = None
@@ -477,6 +520,8 @@ def main():
                            "fully_planned_cycles_per_s counts only the scenes planned to the end",
             "value": round(value, 1),
             "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_world_size": (dist.get_world_size() if world > 1 else None),     # what the process group itself reports
+            "process_group_backend": (dist.get_backend() if world > 1 else None),
             "untimed_steps_before_the_timed_region": args.warmup + settle,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -501,7 +546,10 @@ def main():
                               "bytes_sent_per_rank_and_step": sg.bytes_per_rank_and_step(count),
                               "bytes_received_by_rank0_per_step": sg.bytes_per_rank_and_step(count) * (world - 1)
                               if args.gather == "rank0" else sg.bytes_per_rank_and_step(count) * (world - 1),
-                              "records_complete_on_rank0": gathered_ok}
+                              "records_complete_on_rank0": gathered_ok, **(diag or {})}
+        elif world > 1 or args.gather == "none":
+            line["gather"] = {"mode": "none", "note": "no pack, no gather: compute scaling only",
+                              "world_size_seen_by_the_process_group": (dist.get_world_size() if world > 1 else 1)}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample if not wide else 2, 0, args.scene_dist)
             workers = usable_cores(64) if args.cpu_pool < 0 else args.cpu_pool

@@ -134,13 +134,15 @@ class StepGather:
     streams and ``planner`` may be any object with ``pack_records`` or None (torch packing)."""
 
     def __init__(self, col: int, max_pts: int, total: int, planner=None, fields: str = "full", dst: int | None = 0,
-                 group=None, device=None, depth: int = 3):
+                 group=None, device=None, depth: int = 3, timing: bool = False):
         self.col, self.max_pts, self.total = int(col), int(max_pts), int(total)
         self.cap = path_capacity(max_pts)
         self.planner, self.fields, self.dst, self.group, self.depth = planner, fields, dst, group, int(depth)
         self.width = record_width(col, max_pts, self.cap, fields)
         self.in_flight = []
         self.stream = None
+        self.timing = bool(timing)       # event pairs around every gather on its stream (``gather_ms``)
+        self.timed = []
         if device is not None and getattr(device, "type", "cpu") == "cuda":
             import torch
             self.stream = torch.cuda.Stream(device=device)
@@ -159,9 +161,15 @@ class StepGather:
             rec = pack_records(res, self.col, self.max_pts, path_cap=self.cap, planner=self.planner, fields=self.fields)
         self.stream.wait_stream(rs)
         with torch.cuda.stream(self.stream):
+            began = None
+            if self.timing:
+                began = torch.cuda.Event(enable_timing=True)
+                began.record(self.stream)
             out = gather_records(rec, self.total, group=self.group, dst=self.dst)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=self.timing)
             done.record(self.stream)
+            if self.timing:
+                self.timed.append((began, done))
         self.in_flight.append((rec, out, done))
         if len(self.in_flight) > self.depth:
             self.in_flight.pop(0)[2].synchronize()       # `depth` steps old: long done, costs nothing
@@ -169,6 +177,16 @@ class StepGather:
 
     def unpack(self, out):
         return unpack_records(out, self.col, self.max_pts, path_cap=self.cap, fields=self.fields)
+
+    def gather_ms(self, reset: bool = True):
+        """(mean, min, max, count) of the gathers' own durations on their stream in ms, from the event pairs recorded since
+        the last reset (``timing=True``; call after ``drain``).  None without timing or without a stream."""
+        if not self.timed:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.timed]
+        if reset:
+            self.timed = []
+        return sum(ms) / len(ms), min(ms), max(ms), len(ms)
 
     def drain(self):
         for _, _, done in self.in_flight:

@@ -71,6 +71,23 @@ def test_other_bench_lines(extra, metric_part):
         assert d["gather"]["mode"] == "all" and d["gather"]["doubles_per_scene"] == 94 and d["gather"]["records_complete_on_rank0"]
 
 
+def test_bench_two_ranks_without_gather_separates_compute_scaling():
+    """--gather none: the same two ranks with no pack and no gather at all - the line that tells compute scaling from
+    the cost of the exchange."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--settle-steps", "4", "--scenes-per-gpu", "1024", "--no-cpu-baseline", "--gather", "none"]
+    env = dict(os.environ, EMP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["gather"]["mode"] == "none" and d["rccl_world_size"] == 2 and d["value"] > 1e4
+
+
 @pytest.mark.parametrize("extra", [("--gather", "rank0"), ("--gather", "all", "--records", "trajectory"), ("--pipeline", "3")],
                          ids=["gather_rank0", "all_gather_trajectory", "three_lanes"])
 def test_bench_two_ranks_on_one_gpu(extra):
@@ -95,4 +112,12 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert d["config"]["total_scenes"] == 2048 and d["config"]["scenes_per_gpu"] == 1024
     assert d["value"] > 1e4 and d["gather"]["records_complete_on_rank0"] is True      # (gloo moves the records through the host)
     assert d["gather"]["mode"] == ("all" if "all" in extra else "rank0")
+    # the self-diagnosis of a first multi-GPU run: what the process group reports, every rank's own step time, the gather's
+    # duration on its stream, the step without pack and gather, and how much of the gather hides behind compute
+    g = d["gather"]
+    assert d["rccl_world_size"] == 2 and d["process_group_backend"] == "gloo" and g["world_size_seen_by_the_process_group"] == 2
+    assert len(g["ms_per_step_per_rank"]) == 2 and g["ms_per_step_min_max_over_ranks"][0] <= g["ms_per_step_min_max_over_ranks"][1]
+    assert g["ms_per_step_min_max_over_ranks"][1] <= d["ms_per_step"] * 1.0001
+    assert g["ms_per_step_without_pack_and_gather"] > 0 and g["gather_ms_on_its_stream"]["count"] == 6
+    assert g["gather_ms_on_its_stream"]["mean"] > 0 and 0.0 <= g["gather_hidden_behind_compute_frac"] <= 1.0
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
