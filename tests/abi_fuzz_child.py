@@ -49,11 +49,14 @@ def dp(pp=p, nB=B, mo=MO, os_=obs_s, ol_=obs_l, no=n_obs, s0=start, mode=1, r=ro
 
 assert dp() == 0
 clean = rows.copy()
-for field, bad in (("row", 0), ("row", -3), ("row", 33), ("col", 0), ("col", -1), ("col", 5000), ("sample_s", 0.0),
+for field, bad in (("row", 0), ("row", -3), ("row", 257), ("col", 0), ("col", -1), ("col", 5000), ("sample_s", 0.0),
                    ("sample_s", -2.5), ("sample_l", 0.0), ("sampling_res", 0.0)):
     pp = dp_params_from_cfg(cfg)
     setattr(pp, field, bad)
     expect(dp(pp=pp), f"emp_dp_plan {field}={bad}")
+pp = dp_params_from_cfg(cfg)
+pp.row = 33                                             # beyond one wavefront's 32 rows: the generic wide kernels take it
+expect(dp(pp=pp), "emp_dp_plan row=33 (wide lattice)", allow_ok=True)
 expect(dp(pp=None), "emp_dp_plan params NULL")
 expect(dp(nB=-1), "emp_dp_plan B=-1")
 expect(dp(mo=-1), "emp_dp_plan max_obs=-1")
