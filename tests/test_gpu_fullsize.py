@@ -189,7 +189,9 @@ def test_knot_tie_scenes_of_the_benchmark_batch_are_the_other_branch_and_nothing
             assert_rel(got, other, RTOL, f"seed {seed}: beyond tolerance of the port AND of its flipped tie branch")
             # and the two branches really are what separates them: sub-millimetre, at the first points (the smoothing QP
             # carries a decaying trace of it along the first dozen)
-            assert np.abs(want - other)[:, :2].max() < 2e-3 and not near[:2].all() and near[m // 2:].all()
+            # (positions only: curvature is a second difference of them and keeps the trace visible at 1e-6 of its
+            # 1e-3 1/m scale further along)
+            assert np.abs(want - other)[:, :2].max() < 2e-3 and not near[:2].all() and near[m // 2:, :2].all()
             flipped_needed += 1
         compared += 1
     assert compared >= 6
