@@ -85,16 +85,28 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
     int ncol = d.col - 1;
     int chunks = 1;
-    if (ncol > 0) {
-        chunks = (2048 + d.tiles - 1) / d.tiles;      // ~2000-8000 blocks measure the same; fewer are slower
-        if (chunks > ncol) chunks = ncol;
-        if (chunks < 1) chunks = 1;
+    // Block size: as many wavefronts per block as it takes to fill a CU's twenty wavefront slots (five per SIMD) with the
+    // blocks its LDS holds - and no more, because a block needs a free slot on as many SIMDs as it has wavefronts at the same
+    // moment: beside the previous batch's path-QP wavefronts (staged pipeline) a two-wavefront block of the 40 x 9 lattice
+    // (12 KB of LDS: 13 blocks per CU) finds room where a four-wavefront block does not (step 0.322 -> 0.289 ms), while the
+    // 120 x 21 lattice's 60 KB table allows two blocks per CU, which therefore carry ten wavefronts each.
+    // EMP_EDGE_BLOCK (development) overrides it.
+    static const int eb_env = [] { const char* e = getenv("EMP_EDGE_BLOCK"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 0; }();
+    int wpb = 4;
+    {
+        const int blocks_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+        wpb = (20 + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
+        if (wpb < 2) wpb = 2;
+        if (wpb > 16) wpb = 16;
     }
-    // each of the block's 4 wavefronts takes whole columns: chunk sizes are multiples of 4 where possible
+    if (eb_env) wpb = eb_env / 64;
+    const int eb = wpb * 64;
+    // each of the block's wavefronts takes whole columns: about two per wavefront, chunk sizes multiples of the wavefront count
+    if (ncol > 0) { chunks = (ncol + 2 * wpb - 1) / (2 * wpb); if (chunks < 1) chunks = 1; }
     int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
-    cols_per_chunk = cols_per_chunk >= 4 ? (cols_per_chunk / 4) * 4 : 4;
+    cols_per_chunk = cols_per_chunk >= wpb ? (cols_per_chunk / wpb) * wpb : wpb;
     chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
-    dim3 grid(d.tiles, chunks), block(256);
+    dim3 grid(d.tiles, chunks), block(eb);
     const double* pair_tab = nullptr;
     { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
     auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
@@ -731,9 +743,19 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     const size_t per_group = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
     int rc;
     KernelTimer t(ctx, "path_qp");
-    if (cap <= 34) {                                                  // N, ns <= 32: two scenes per wavefront
+    // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations; EMP_PATH_QP_PAIR=1 (development, A/B runs) keeps the
+    // two-scenes-per-wavefront kernels of rounds 1-2.
+    static const bool pair_form = [] { const char* e = getenv("EMP_PATH_QP_PAIR"); return e && e[0] == '1'; }();
+    if (cap <= 34 && !pair_form) {
+        const bool r3 = cap <= 26;
+        const size_t per_wave = 8 * ((size_t)5 * cap + 4 * (size_t)max_obs + (r3 ? path_qp_words_rows<3>() : path_qp_words_rows<4>())) * sizeof(double);
+        auto kern = r3 ? cycle_qp_rows_kernel<3> : cycle_qp_rows_kernel<4>;
+        if ((rc = set_lds(ctx, kern, per_wave))) return rc;
+        hipLaunchKernelGGL(kern, dim3((B + 7) / 8), dim3(64), per_wave, ctx->stream, B, max_pts,
+                           max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+    } else if (cap <= 34) {                                           // N, ns <= 32: two scenes per wavefront
         const size_t per_pair = 2 * ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words_pair()) * sizeof(double);
-        auto kern = ctx->pipe_mode == EMP_PIPELINE_STAGED ? cycle_qp_wave_kernel_tight : cycle_qp_wave_kernel<32>;
+        auto kern = cycle_qp_wave_kernel<32>;
         if ((rc = set_lds(ctx, kern, per_pair))) return rc;
         hipLaunchKernelGGL(kern, dim3((B + 1) / 2), dim3(64), per_pair, ctx->stream, B, max_pts,
                            max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);

@@ -182,7 +182,7 @@ template <bool TILED>
 // (Tried with several batches in flight: padding the allocation to 104 registers, so that four wavefronts leave room on
 // a SIMD for a wavefront of the sweep or the Cartesian tail that a fifth edge wavefront cannot take.  The overlapped sweep
 // got 15 % shorter, the edge kernel 3 % longer, and the step longer in every pipeline mode: not kept.)
-__global__ __launch_bounds__(256, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
+__global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, const double* __restrict__ pair_tab,
                                                       const double* __restrict__ obs_s,
                                                       const double* __restrict__ obs_l,
                                                       const int* __restrict__ n_obs,

@@ -239,7 +239,12 @@ struct RangeQp {
             const double dscale = fmax(qscale, zmax);
             EMP_QP_TRACE("it %d rd %.3e rp %.3e mu %.3e\n", iters, rd_max, rp_max, mu);
             if (rd_max <= eps_d_rel * dscale && rp_max <= eps_p && mu <= eps_mu) return 0;
-            if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu <= 1000.0 * eps_mu) acceptable = true;
+            if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu <= 1000.0 * eps_mu) {
+                acceptable = true;
+                // complementarity converged, dual residual inside the acceptable band: further iterations at this mu
+                // only add rounding noise to it (z / s weights of 1e15 and more in the normal matrix)
+                if (rp_max <= eps_p && mu <= eps_mu) return 0;
+            }
             if (!(mu == mu) || mu > 1e30) return 2;
             if (iters >= kQpStallIter && rp_max > kQpStallResidual) return 2;
             // ---- M = P + G'WG

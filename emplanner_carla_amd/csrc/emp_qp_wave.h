@@ -111,7 +111,7 @@ template <int G>
 __device__ __forceinline__ bool group_any(bool p) {             // true if p holds on any lane of MY group
     const unsigned long long m = __ballot(p);
     if constexpr (G == 64) return m != 0ull;
-    else return ((m >> ((threadIdx.x & 63) & 32)) & 0xffffffffull) != 0ull;
+    else return ((m >> ((threadIdx.x & 63) & ~(G - 1))) & ((1ull << G) - 1ull)) != 0ull;     // G = 32, 16, 8: aligned groups
 }
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
@@ -512,8 +512,9 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
             if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
             else if (!(mu == mu) || mu > 1e30 || (iters >= kQpStallIter && rp_max > kQpStallResidual)) state = 2;
             else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
-            if (rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu)
-                acceptable = true;
+            const bool acc_now = rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu;
+            if (acc_now) acceptable = true;
+            if (state == 1 && acc_now && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;     // see range_qp_solve_wave_fast
         }
         __syncthreads();
         const bool go = state == 1;
@@ -860,8 +861,12 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
                 // running into the iteration-16 rule above, and a kernel lasts as long as its slowest problem.
                 else if (rp_max > kQpStallResidual && zmax > kQpInfeasibleZ * pscale) state = 2;
                 else if (iters >= kQpMaxIter || iters >= iter_cap) state = acceptable ? 0 : 2;
-                if (rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu)
-                    acceptable = true;
+                const bool acc_now = rd_max <= 100.0 * Q.eps_d_rel * dscale && rp_max <= 10.0 * Q.eps_p && mu <= 1000.0 * Q.eps_mu;
+                if (acc_now) acceptable = true;
+                // Converged complementarity with the dual residual inside the acceptable band: at this mu the normal matrix
+                // carries weights z / s of 1e15 and more, another iteration adds rounding noise to the residual instead of
+                // removing it (benchmark scene 446: rd 5.6e-6, 1.1e-5 in another summation order, then 2e-2, 2e+4) - stop.
+                if (state == 1 && acc_now && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
             }
         }
         const bool go = state == 1;
@@ -937,6 +942,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
         ratio = group_max<G>(ratio);
         const double tau = qp_step_fraction(mu);
         const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
+        EMP_QP_DEBUG("   alpha %.6e\n", alpha);
         if (go2) {
             if (has_t) {
 #pragma unroll

@@ -12,6 +12,7 @@
 #include "emp_frenet_core.h"
 #include "emp_qp_core.h"
 #include "emp_qp_wave.h"
+#include "emp_qp_rows.h"
 
 namespace emp {
 
@@ -533,7 +534,8 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 // One scene per GROUP of G lanes (G = 32: two scenes per wavefront when cap <= 34 stations, else G = 64).
 // dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)  (G = 32: + path_qp_words_pair() instead)
 // ---------------------------------------------------------------------------------------------
-template <int G>
+// R > 0: eight scenes per wavefront (G = 8), R stations per lane (emp_qp_rows.h; cap <= 8 R + 2 stations).
+template <int G, int R = 0>
 __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, int cap, const QpDev& Q,
                                                            const double* __restrict__ dp_s,
                                                            const double* __restrict__ dp_l,
@@ -550,7 +552,8 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
     const int b = blockIdx.x * GPW + grp;
     const bool present = b < B;
-    const int per_group = 5 * cap + 4 * max_obs + (G == 32 ? path_qp_words_pair() : path_qp_words(cap));
+    static_assert(R == 0 || G == 8, "the rows solver runs on groups of eight lanes");
+    const int per_group = 5 * cap + 4 * max_obs + (R > 0 ? path_qp_words_rows<(R > 0 ? R : 3)>() : G == 32 ? path_qp_words_pair() : path_qp_words(cap));
     double* lds = lds_all + (size_t)grp * per_group;
     const size_t o = (size_t)(present ? b : 0) * max_pts;
     double* sd = lds;                 // decimated station s   [cap]
@@ -609,8 +612,13 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         if (Q.debug_stage == 1) live = false;
         int it = 0;
         const int sb = present ? b : 0;
-        const int rc = path_qp_group<G>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp,
-                                        ql, nullptr, nullptr, &it, live, Q.debug_stage);
+        int rc;
+        if constexpr (R > 0)
+            rc = path_qp_group_rows<R>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp, ql, &it,
+                                       live, Q.debug_stage);
+        else
+            rc = path_qp_group<G>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp,
+                                  ql, nullptr, nullptr, &it, live, Q.debug_stage);
         if (live && rc) {
             fail = kStQpFailed;
             live = false;
@@ -667,13 +675,13 @@ template <int G>
 __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(EMP_CYCLE_QP_PARAMS) {
     cycle_qp_body<G>(EMP_CYCLE_QP_ARGS);
 }
-// The same kernel held to 128 registers (four wavefronts per SIMD instead of three; 104 B of scratch per lane).  Alone it
-// is 7 % slower (153 against 143 us).  In the staged pipeline its wavefronts sit on the SIMDs for as long as their slowest
-// scene while the next batch's edge kernel looks for registers beside them: there the step gains 2 % (0.314 against
-// 0.321 ms, same box).  With whole cycles on lanes the chip is issue-bound and the spill instructions cost 5 %: the
-// launcher takes this form in staged mode only.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void cycle_qp_wave_kernel_tight(EMP_CYCLE_QP_PARAMS) {
-    cycle_qp_body<32>(EMP_CYCLE_QP_ARGS);
+// Eight scenes per wavefront, R stations per lane (emp_qp_rows.h): a quarter of the wavefronts, each as long as before.
+#ifndef EMP_QP_ROWS_ATTR
+#define EMP_QP_ROWS_ATTR
+#endif
+template <int R>
+__global__ __launch_bounds__(64) EMP_QP_ROWS_ATTR void cycle_qp_rows_kernel(EMP_CYCLE_QP_PARAMS) {
+    cycle_qp_body<8, R>(EMP_CYCLE_QP_ARGS);
 }
 #undef EMP_CYCLE_QP_PARAMS
 #undef EMP_CYCLE_QP_ARGS
