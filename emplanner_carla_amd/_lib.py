@@ -116,6 +116,7 @@ PROTOTYPES = {
     "emp_set_timing_filter": (C.c_int, [_vp, C.c_char_p]),
     "emp_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "emp_result_stream": (_vp, [_vp]),
+    "emp_pipeline_depth": (C.c_int, [_vp]),
     "emp_set_fence": (C.c_int, [_vp, C.c_int]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
@@ -190,7 +191,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 7:
+    if lib.emp_abi_version() != 8:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

@@ -249,6 +249,7 @@ class Planner:
         self.pipelined = False
         self.pipe_mode = 0
         self.in_flight = 1
+        self._retain = 1
         self._inflight = []
         self._cur = None
 
@@ -308,7 +309,8 @@ class Planner:
                           RuntimeWarning, stacklevel=2)
         self._check(self._lib.emp_set_pipeline(self._h, m))
         self.pipe_mode = m
-        self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)
+        self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)       # batches that overlap on the GPU
+        self._retain = max(int(self._lib.emp_pipeline_depth(self._h)), self.in_flight)     # calls whose outputs stay referenced
         self.pipelined = m != 0
         self._inflight = []                      # emp_set_pipeline has drained every stream
 
@@ -813,10 +815,10 @@ class Planner:
             # consumer queued behind it on its result stream, still uses it.  Entry k is released when call k + n
             # has been issued; the memory may then go to call k + n + 1, which runs on ANOTHER lane - so call k + n
             # (emp_plan_cycle, lane mode) first orders the main stream behind the tail of its lane, i.e. behind call k
-            # and its consumers, and every later call is ordered behind the main stream.  (Staged mode: the front
-            # stage of call k + 2 waits for the back stage of call k.)
+            # and its consumers, and every later call is ordered behind the main stream.  (Staged mode: call
+            # k + emp_pipeline_depth() is not issued before the back stage of call k is done.)
             self._inflight.append((list(res.values()), a.keep))
-            if len(self._inflight) > self.in_flight:
+            if len(self._inflight) > self._retain:
                 self._inflight.pop(0)
         return CycleResult(**res)
 

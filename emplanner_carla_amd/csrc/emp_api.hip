@@ -142,8 +142,10 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
         if (lds > 48 * 1024)                                                                                \
             EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB, NT>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipEvent_t stop_ev = t.stop ? t.stop : ctx->front_stop;                                             \
         hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
-                              ctx->stream, t.start, t.stop, 0, d, start_cost, edge, n_obs, rows, min_cost, status); \
+                              ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status); \
+        ctx->front_attached = stop_ev;                                                                      \
     } while (0)
     // Ring depth PD (columns in flight per wavefront), measured at 4096 scenes: 2 is best for rows 5..12 (row 9:
     // 20.4 us against 23.2 at PD = 8, 21.4 at PD = 1), 3 for the 21-row lattice; nontemporal loads change nothing.
@@ -481,7 +483,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     EMP_HIP(ctx, hipSetDevice(ctx->device));
     EMP_HIP(ctx, (hipError_t)sync_all(ctx));
     const int m = mode < 0 ? 0 : mode;
-    const int need = m == EMP_PIPELINE_STAGED ? 2 : m;
+    const int need = m == EMP_PIPELINE_STAGED ? emp_ctx::kStagedPools : m;
     if ((int)ctx->lanes.size() < need) ctx->lanes.resize(need);
     for (int i = 0; i < need; ++i) {
         emp_ctx::Lane& ln = ctx->lanes[i];
@@ -503,6 +505,11 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     ctx->pipe_mode = m;
     ctx->lane = 0;
     return EMP_OK;
+}
+
+int emp_pipeline_depth(emp_ctx* ctx) {
+    if (!ctx) return EMP_ERR_INVALID;
+    return ctx->pipe_mode == 0 ? 1 : ctx->lanes_in_use();
 }
 
 int emp_set_fence(emp_ctx* ctx, int enabled) {
@@ -1106,7 +1113,8 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         }
     } lane(ctx, pmode);
     if (staged) {
-        if (lane.ln->done_valid) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_done, 0));
+        // the pool's previous user is four calls back: a host-side wait (emp_context.h, kStagedPools)
+        if (lane.ln->done_valid) EMP_HIP(ctx, hipEventSynchronize(lane.ln->ev_done));
     } else if (piped) {
         // The lane's previous occupant (call k - n) and whatever its caller queued behind it on the lane's stream (record
         // packing) must be done before anything ordered on the main stream from here on may touch memory they use: the
@@ -1172,11 +1180,21 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                           d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
-    if ((rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st))) return rc;
+    ctx->front_stop = staged ? lane.ln->ev_front : nullptr;
+    ctx->front_attached = nullptr;
+    rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st);
+    ctx->front_stop = nullptr;
+    if (rc) return rc;
     const QpDev Q = make_qp_dev(q);
     if (staged) {      // the back stage (short kernels that last as long as their slowest scene) goes to the back stream
-        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_front, ctx->stream));
-        EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, lane.ln->ev_front, 0));
+        // behind the sweep's own completion event where the launch attached one (a marker packet behind the sweep costs the
+        // front queue ~5 us per step), else behind an event recorded here
+        hipEvent_t front_done = ctx->front_attached;
+        if (!front_done) {
+            EMP_HIP(ctx, hipEventRecord(lane.ln->ev_front, ctx->stream));
+            front_done = lane.ln->ev_front;
+        }
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, front_done, 0));
         ctx->stream = ctx->back_stream;        // ~LaneSwap puts the main stream back
     }
     if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;

@@ -66,12 +66,22 @@ struct emp_ctx {
     };
     std::vector<Lane> lanes;            // created on demand, kept until emp_destroy
     hipStream_t back_stream = nullptr;  // STAGED: the back stages (highest queue priority)
+    // STAGED: the event the front stage's LAST kernel (the sweep) is asked to signal when it completes (hipExtLaunchKernelGGL's
+    // stop event: no marker packet behind the kernel), and the event that launch did attach - its own timing event when the
+    // kernel is being timed, else front_stop, else nullptr (launchers that attach nothing: the caller records an event).
+    hipEvent_t front_stop = nullptr, front_attached = nullptr;
     int pipe_mode = 0;                  // 0 off, 1 STAGED, n >= 2 LANES with n lanes
     int lane = 0;                       // lane of the latest pipelined cycle call
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     bool pipelined() const { return pipe_mode != 0; }
-    int lanes_in_use() const { return pipe_mode == 1 ? 2 : pipe_mode; }
+    // STAGED rotates kStagedPools pools of temporaries although only two calls overlap on the GPU: call k reuses the pool
+    // of call k - 4 and the HOST waits for that call's back stage (long finished unless the host runs more than four
+    // calls ahead, which this also bounds) - no barrier packet on the queue of the front stages.  With two pools the
+    // stream had to wait for call k - 2 on the GPU: a cross-queue dependency in front of every projection kernel, ~11 us
+    // of the command processor's time per 0.29 ms step on the queue that is the step's critical path.
+    static constexpr int kStagedPools = 4;
+    int lanes_in_use() const { return pipe_mode == 1 ? kStagedPools : pipe_mode; }
     hipStream_t result_stream() const {
         return pipe_mode == 0 ? stream : pipe_mode == 1 ? back_stream : lanes[lane].stream;
     }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 7
+#define EMP_ABI_VERSION 8
 
 typedef struct emp_ctx emp_ctx;
 
@@ -148,6 +148,12 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
 #define EMP_PIPELINE_MAX 8
 int emp_set_pipeline(emp_ctx* ctx, int mode);
 void* emp_result_stream(emp_ctx* ctx);
+/* How many consecutive emp_plan_cycle calls may have work in flight in the current mode (ABI version 8): the output buffers
+ * of call k may be reused once call k + emp_pipeline_depth() has been ISSUED.  1 when the pipeline is off, n in lane mode,
+ * 4 in staged mode: two batches overlap there, but the pools of temporaries rotate over four calls and emp_plan_cycle
+ * waits ON THE HOST for the call four back (a call that finished long ago unless the host runs further ahead than that,
+ * which it then may not) - a stream-side wait for the pool's previous user cost ~11 us of every 0.29 ms step. */
+int emp_pipeline_depth(emp_ctx* ctx);
 /* The fence of the pipelined modes (on by default): every entry point other than a pipelined emp_plan_cycle first lets
  * emp_stream() wait for the cycles in flight, so that it may read their outputs.  Switched off, such calls are queued on
  * emp_stream() at once and overlap the cycles in flight - for work that does not depend on them (the S-T speed planner of
