@@ -99,6 +99,10 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         if (wpb < 2) wpb = 2;
         if (wpb > 16) wpb = 16;
     }
+    // (a tensor beyond the 256 MiB Infinity Cache - 32768 scenes of the 40 x 9 lattice - keeps four wavefronts per block: the
+    // faster front stage otherwise leaves the sweep, which then streams from DRAM for 150 us, beside the previous batch's
+    // path QP: 0.75 of the roofline against 0.61)
+    if (tiled && tiled_elems(d) * sizeof(double) > ((size_t)256 << 20) && wpb < 4) wpb = 4;
     if (eb_env) wpb = eb_env / 64;
     const int eb = wpb * 64;
     // each of the block's wavefronts takes whole columns: about two per wavefront, chunk sizes multiples of the wavefront count
