@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libemplanner.so")
 SOURCES = ["emp_api.hip"]
 HEADERS = ["emp_core.h", "emp_context.h", "emp_dp_kernels.h", "emp_qp_core.h", "emp_frenet_core.h",
-           "emp_qp_wave.h", "emp_qp_rows.h", "emp_tail_kernels.h", "emp_st_core.h", "emp_st_kernels.h", "emp_mpc_kernels.h",
+           "emp_qp_wave.h", "emp_qp_rows.h", "emp_smooth_rows.h", "emp_tail_kernels.h", "emp_st_core.h", "emp_st_kernels.h", "emp_mpc_kernels.h",
            "emp_st_backend_core.h", "emp_st_backend_kernels.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]

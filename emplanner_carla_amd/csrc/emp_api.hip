@@ -788,6 +788,20 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
     const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
     const int cap = path_cap + 1;                                        // trajectory = planning start + path points
     const size_t lds = ((size_t)max_ref + 3 * (size_t)cap + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
+    // Four scenes per wavefront up to 32 trajectory points (emp_tail_kernels.h, cycle_cartesian_rows_kernel);
+    // EMP_CARTESIAN_WAVE=1 (development, A/B runs) keeps the one-scene-per-wavefront kernels of rounds 1-2.
+    static const bool wave_form = [] { const char* e = getenv("EMP_CARTESIAN_WAVE"); return e && e[0] == '1'; }();
+    if (cap <= 32 && !wave_form) {
+        const size_t lds4 = (4 * ((size_t)max_ref + 5 * (size_t)cap) + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
+        auto k4 = cap <= 24 ? cycle_cartesian_rows_kernel<3> : cycle_cartesian_rows_kernel<4>;
+        int rc4 = set_lds(ctx, k4, lds4);
+        if (rc4) return rc4;
+        KernelTimer t4(ctx, "to_cartesian");
+        hipLaunchKernelGGL(k4, dim3((B + 3) / 4), dim3(64), lds4, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map,
+                           n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status);
+        EMP_LAUNCH_CHECK(ctx);
+        return EMP_OK;
+    }
     auto kern = cap > 32 ? cycle_cartesian_wave_kernel_wide : cycle_cartesian_wave_kernel_narrow;
     int rc = set_lds(ctx, kern, lds);
     if (rc) return rc;

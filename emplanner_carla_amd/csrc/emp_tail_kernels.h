@@ -13,6 +13,7 @@
 #include "emp_qp_core.h"
 #include "emp_qp_wave.h"
 #include "emp_qp_rows.h"
+#include "emp_smooth_rows.h"
 
 namespace emp {
 
@@ -814,6 +815,175 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     cycle_cartesian_body<false>(EMP_CARTESIAN_ARGS);
 }
 #undef EMP_CARTESIAN_ARGS
+
+// ---------------------------------------------------------------------------------------------
+// The same last part of the cycle with FOUR scenes per wavefront (trajectories of at most 8 R points: R = 3 the
+// benchmark's 23, R = 4 up to 32): 16 lanes per scene - Frenet -> Cartesian one point per lane in passes of 16, the x
+// and the y smoothing problem on the scene's two 8-lane groups with R points per lane (emp_smooth_rows.h), heading /
+// curvature one point per lane again.  A quarter of the wavefronts of cycle_cartesian_wave_kernel_narrow for the same
+// work: what that kernel spends per scene on 23 of 64 lanes (trigonometry) and on sweeps for two problems (smoothing)
+// is shared by four scenes here.  A problem whose active-set classification does not settle (none on any test or
+// benchmark scene) is solved by the whole wavefront with the half-wave solvers of the narrow kernel, one scene at a time.
+// dynamic LDS (doubles): 4 * (max_ref + 5 * cap) + 2 * BoxRangeQp::words(cap, cap)
+// ---------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
+    int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
+    const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
+    const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
+    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);
+    const int lane = threadIdx.x & 63, sc = lane >> 4, sl = lane & 15;
+    const int b = blockIdx.x * 4 + sc;
+    const bool present = b < B;
+    const size_t bb = present ? (size_t)b : 0;
+    const int per_scene = max_ref + 5 * cap;
+    double* sm = lds + (size_t)sc * per_scene;   // [max_ref]
+    double* txy = sm + max_ref;                  // [cap][2] interleaved x, y
+    double* th = txy + 2 * cap;                  // [cap]
+    double* px = th + cap;                       // [cap] smoothed x
+    double* py = px + cap;                       // [cap] smoothed y
+    double* qmem = lds + (size_t)4 * per_scene;  // the fall-back solver's storage (whole wavefront)
+    const int st = present ? status[bb] : 0;
+    int add = 0;                                 // status bits this kernel adds (scene-uniform)
+    bool alive = present && !(st & (kStQpFailed | kStBoundIndex | kStTruncated));
+    const double* line = ref_line + bb * max_ref * 4;
+    const int P = alive ? min(max(n_ref[bb], 0), max_ref) : 0;       // clamped to the row's capacity
+    const int n = alive ? path_len[bb] : 0;
+    for (int i = sl; i < P; i += 16) sm[i] = s_map[bb * max_ref + i];
+    __syncthreads();
+    // planning start (ref :31-34)
+    bool off = false;
+    const double bs = alive ? begin_sl[2 * bb] : 0.0, bl = alive ? begin_sl[2 * bb + 1] : 0.0;
+    const int idx0 = walk_from_zero(sm, P, bs, &off);
+    if (alive && (off || P < 2)) {
+        add = kStSOutOfRange;
+        alive = false;
+    }
+    if (alive && sl == 0) {
+        const Node m0 = node_at(line, idx0);
+        const double ds = bs - sm[idx0];
+        const double th0 = m0.theta + m0.kappa * ds;
+        txy[0] = (m0.x + ds * cos(m0.theta)) + bl * (-sin(th0));
+        txy[1] = (m0.y + ds * sin(m0.theta)) + bl * cos(th0);
+    }
+    // path points: count = leading points with s <= s_map[-1] (ref :40-41), index = running max of walks (:42-43)
+    const double s_last = alive ? sm[P - 1] : 0.0;
+    int carry = idx0, count = alive ? n : 0;
+    bool stop = !alive;
+    int nmax = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) nmax = max(nmax, __builtin_amdgcn_readlane(alive ? n : 0, 16 * g));
+    for (int base = 0; base < nmax; base += 16) {
+        const int i = base + sl;
+        const bool in = !stop && i < n;
+        const double s = in ? path_s[bb * max_pts + i] : 0.0;
+        const unsigned bad16 = (unsigned)((__ballot(in && s > s_last) >> (16 * sc)) & 0xffffull);
+        const int first_bad = __builtin_ffs((int)bad16);                               // 1-based lane of the scene, 0 if none
+        if (!stop && first_bad) count = min(count, base + first_bad - 1);
+        bool o2 = false;
+        int k = in ? walk_from_zero(sm, P, fmin(s, s_last), &o2) : 0;
+        for (int d = 1; d < 16; d <<= 1) {                 // inclusive running maximum across the scene's lanes
+            const int v = __shfl_up(k, d, 16);
+            if (sl >= d) k = max(k, v);
+        }
+        k = max(k, carry);
+        carry = __shfl(k, 15, 16);
+        if (in && i < count && i + 1 < cap) {
+            const Node mm = node_at(line, k);
+            const double ds = s - sm[k];
+            const double thp = mm.theta + mm.kappa * ds;
+            const double l = path_l[bb * max_pts + i];
+            txy[2 * (i + 1)] = (mm.x + ds * cos(mm.theta)) + l * (-sin(thp));       // ref :44-46
+            txy[2 * (i + 1) + 1] = (mm.y + ds * sin(mm.theta)) + l * cos(thp);
+        }
+        if (first_bad) stop = true;
+    }
+    int m = count + 1;
+    __syncthreads();
+    if (alive && (m > cap || m > max_pts + 1 || m > 8 * R)) {
+        add = kStTruncated;
+        alive = false;
+    }
+    if (alive && m < 2) {
+        add = kStSmoothFailed;
+        alive = false;
+    }
+    // smoothing (ref planning_utils.py:262-361): x on the scene's lanes 0-7, y on 8-15, R points per lane
+    const int grp = sl >> 3, gl = sl & 7;
+    double ref[R], u[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = gl * R + r;
+        const double v = txy[2 * (j < cap ? j : 0) + grp];
+        ref[r] = (alive && j < m) ? v : 0.0;
+    }
+    int it = 0;
+    const int rc = box_qp_active_set_rows<R>(ref, alive ? m : 0, grp ? sy : sx, u, &it);
+    const unsigned long long unsettled = __ballot(alive && rc < 0), wrong = __ballot(alive && rc > 0);
+    const bool need_fb = ((unsettled >> (16 * sc)) & 0xffffull) != 0ull;
+    if (((wrong >> (16 * sc)) & 0xffffull) != 0ull) {
+        add = kStSmoothFailed;
+        alive = false;
+    }
+    if (alive && !need_fb) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j = gl * R + r;
+            if (j < m) (grp ? py : px)[j] = u[r];
+        }
+    }
+    __syncthreads();
+    if (unsettled != 0ull) {             // wave-uniform; never taken on the test and benchmark scenes
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if (((unsettled >> (16 * s2)) & 0xffffull) == 0ull) continue;
+            const int m2 = __builtin_amdgcn_readlane(m, 16 * s2);
+            double* base2 = lds + (size_t)s2 * per_scene;
+            double *qx = nullptr, *qy = nullptr;
+            int it2 = 0;
+            const int rc2 = smooth_pair_wave<false>(qmem, base2 + max_ref, 2, m2, sx, sy, &qx, &qy, &it2);
+            if (rc2 == 0) {
+                for (int i = lane; i < m2; i += 64) {
+                    base2[max_ref + 3 * cap + i] = qx[i];
+                    base2[max_ref + 4 * cap + i] = qy[i];
+                }
+            } else if (sc == s2) {
+                add = kStSmoothFailed;
+                alive = false;
+            }
+            __syncthreads();
+        }
+    }
+    // heading / curvature (ref planning_utils.py:185-228), one point per lane
+    double* out_rows = traj + bb * (max_pts + 1) * 4;
+    const int mm = alive ? m : 0;
+    for (int i = sl; i < mm; i += 16) {
+        const int a = (i - 1 > 0) ? i - 1 : 0, c = (i < mm - 2) ? i : mm - 2;
+        const double dx = ((px[a + 1] - px[a]) + (px[c + 1] - px[c])) / 2.0;
+        const double dy = ((py[a + 1] - py[a]) + (py[c + 1] - py[c])) / 2.0;
+        th[i] = atan2(dy, dx);
+    }
+    __syncthreads();
+    for (int i = sl; i < mm; i += 16) {
+        const int a = (i - 1 > 0) ? i - 1 : 0, c = (i < mm - 2) ? i : mm - 2;
+        const double dx = ((px[a + 1] - px[a]) + (px[c + 1] - px[c])) / 2.0;
+        const double dy = ((py[a + 1] - py[a]) + (py[c + 1] - py[c])) / 2.0;
+        const double dpre = th[a + 1] - th[a], daft = th[c + 1] - th[c];
+        double* o = out_rows + (size_t)i * 4;
+        o[0] = px[i];
+        o[1] = py[i];
+        o[2] = th[i];
+        o[3] = sin((dpre + daft) / 2.0) / sqrt(dx * dx + dy * dy);
+    }
+    if (present) {
+        for (int i = mm * 4 + sl; i < (max_pts + 1) * 4; i += 16) out_rows[i] = 0.0;       // padding reads as 0
+        if (sl == 0) {
+            traj_len[bb] = mm;
+            if (add) status[bb] = st | add;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // stand-alone forms of the projection helpers (one lane per scene, points in order)
