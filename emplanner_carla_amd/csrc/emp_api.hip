@@ -147,8 +147,16 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
             EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB, NT>,                      \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
         hipEvent_t stop_ev = t.stop ? t.stop : ctx->front_stop;                                             \
-        hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
-                              ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status); \
+        if ((R) > 0 && ctx->bt_pre && ctx->bt_term) {                                                       \
+            hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT, false>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                                  ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status, \
+                                  ctx->bt_pre, ctx->bt_term);                                               \
+            ctx->bt_deferred = true;                                                                        \
+        } else {                                                                                            \
+            hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                                  ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status, \
+                                  (unsigned char*)nullptr, (int*)nullptr);                                  \
+        }                                                                                                   \
         ctx->front_attached = stop_ev;                                                                      \
     } while (0)
     // Ring depth PD (columns in flight per wavefront), measured at 4096 scenes: 2 is best for rows 5..12 (row 9:
@@ -187,11 +195,14 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
 }
 
 static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const double* start, int max_pts,
-                         double* path_s, double* path_l, int* path_len, int* status, int or_status) {
+                         double* path_s, double* path_l, int* path_len, int* status, int or_status,
+                         const unsigned char* pre = nullptr, const int* term = nullptr, const int* n_obs = nullptr,
+                         double* rows_out = nullptr) {
     if (d.B == 0) return EMP_OK;
     KernelTimer t(ctx, "dp_enrich");
-    hipLaunchKernelGGL(dp_enrich_wave_kernel, dim3(d.B), dim3(64), 0, ctx->stream, d, rows, start, max_pts, path_s, path_l,
-                       path_len, status, or_status);
+    const size_t lds = pre ? (size_t)d.col * sizeof(double) + (size_t)d.col * d.row : 0;
+    hipLaunchKernelGGL(dp_enrich_wave_kernel, dim3(d.B), dim3(64), lds, ctx->stream, d, rows, start, max_pts, path_s, path_l,
+                       path_len, status, or_status, pre, term, n_obs, rows_out);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -1198,10 +1209,24 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                           d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;
     if (has_dyn) d_no = d_ntot;                            // downstream stages see the projected + virtual obstacles
+    // the sweep may leave the backtrack to the densification kernel (emp_dp_kernels.h, BT == false): two temporaries for it
+    unsigned char* d_pre = nullptr;
+    int* d_term = nullptr;
+    if (mode == EMP_DP_TWO_KERNEL && !wide(d)) {
+        if ((rc = st.tmp((size_t)d.tiles * d.col * 64, &d_pre, false))) return rc;
+        if ((rc = st.tmp((size_t)B, &d_term, false))) return rc;
+    }
     ctx->front_stop = staged ? lane.ln->ev_front : nullptr;
     ctx->front_attached = nullptr;
+    ctx->bt_pre = d_pre;
+    ctx->bt_term = d_term;
+    ctx->bt_deferred = false;
     rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st);
     ctx->front_stop = nullptr;
+    ctx->bt_pre = nullptr;
+    ctx->bt_term = nullptr;
+    const bool deferred = ctx->bt_deferred;
+    ctx->bt_deferred = false;
     if (rc) return rc;
     const QpDev Q = make_qp_dev(q);
     if (staged) {      // the back stage (short kernels that last as long as their slowest scene) goes to the back stream
@@ -1215,7 +1240,9 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, front_done, 0));
         ctx->stream = ctx->back_stream;        // ~LaneSwap puts the main stream back
     }
-    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1))) return rc;
+    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
+                            deferred ? d_term : nullptr, d_no, d_rows)))
+        return rc;
     if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
                            d_st)))
         return rc;

@@ -70,6 +70,11 @@ struct emp_ctx {
     // stop event: no marker packet behind the kernel), and the event that launch did attach - its own timing event when the
     // kernel is being timed, else front_stop, else nullptr (launchers that attach nothing: the caller records an event).
     hipEvent_t front_stop = nullptr, front_attached = nullptr;
+    // The planning cycle leaves the DP backtrack to the densification kernel (dp_sweep_kernel, BT == false): the caller offers
+    // the two buffers, the sweep's launcher sets bt_deferred when it used them (compiled row counts only).
+    unsigned char* bt_pre = nullptr;
+    int* bt_term = nullptr;
+    bool bt_deferred = false;
     int pipe_mode = 0;                  // 0 off, 1 STAGED, n >= 2 LANES with n lanes
     int lane = 0;                       // lane of the latest pipelined cycle call
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now

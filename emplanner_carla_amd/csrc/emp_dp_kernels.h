@@ -74,13 +74,18 @@ __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __r
 }
 
 // kSoftGain / d2 for 16 < d2 < 36: the instruction sequence the compiler emits for an IEEE binary64 division
-// (reciprocal seed, two Newton steps, quotient, residual, final fma) without its range scaling and special-case
-// fix-up, which do nothing for operands of this size - the same bits in 8 instead of 12 instructions, eight times
-// per obstacle scan.
+// (reciprocal seed, Newton steps, quotient, residual, final fma) without its range scaling and special-case fix-up,
+// which do nothing for operands of this size.  EMP_SOFT_NEWTON_STEPS = 2 is the compiler's sequence (the same bits in 8
+// instead of 12 instructions, eight times per obstacle scan); 1 (round 3 experiment, profiles/r03_edge/README.md) drops a
+// step: the seed's 2^-24 or better becomes 2^-48, the residual 5000 - d2 q is exact (fma) and the correction is wrong by
+// q 2^-96 at most, so the final fma misrounds one quotient in 2^43.
+#ifndef EMP_SOFT_NEWTON_STEPS
+#define EMP_SOFT_NEWTON_STEPS 2
+#endif
 __device__ __forceinline__ double soft_cost_quotient(double d2) {
     double r = __builtin_amdgcn_rcp(d2);
     r = __builtin_fma(r, __builtin_fma(-d2, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-d2, r, 1.0), r);
+    if (EMP_SOFT_NEWTON_STEPS > 1) r = __builtin_fma(r, __builtin_fma(-d2, r, 1.0), r);
     const double q = kSoftGain * r;
     return __builtin_fma(__builtin_fma(-d2, q, kSoftGain), r, q);
 }
@@ -256,13 +261,20 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
 // One wavefront per tile of S scenes; block = WPB wavefronts.  LDS: predecessor bytes [wave][col][64].
 // ROW > 0: compile-time row count, register double buffer of PD columns (loads for the next group are
 // in flight while the current group is reduced).  ROW == 0: generic fallback with a runtime row count.
-template <int ROW, int PD, int WPB, bool NT = false>
+// BT == false (the planning cycle, round 3): the backtrack is left to the densification kernel that follows - this kernel
+// hands it the predecessor bytes (`pre_out` [tiles][col][64], the LDS table as it stands) and the terminal row (`term_out`
+// [B]) instead of the rows.  The chain of col - 1 dependent LDS reads by one lane per scene was 1.6 us at the end of every
+// wavefront of a 20-us launch that is otherwise a pure stream - on the queue that is the step's critical path; behind the
+// densification kernel's own start-up on the back stage's queue it costs the step nothing.
+template <int ROW, int PD, int WPB, bool NT = false, bool BT = true>
 __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const double* __restrict__ start_cost,
                                                        const double* __restrict__ edge,
                                                        const int* __restrict__ n_obs,
                                                        double* __restrict__ rows_out,
                                                        double* __restrict__ min_cost_out,
-                                                       int* __restrict__ status_out) {
+                                                       int* __restrict__ status_out,
+                                                       unsigned char* __restrict__ pre_out = nullptr,
+                                                       int* __restrict__ term_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];   // [WPB][64] doubles, then [WPB][col][64] bytes
     // One wavefront per tile, ~75 instructions per column between two waits for HBM: with two batches in flight it shares
     // its SIMD with the previous batch's path-QP / Cartesian wavefronts, which raise their priority to 3; at priority 0
@@ -408,6 +420,19 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
     // bytes in registers and followed the chains with v_readlane, row indices in scalar registers, seven scenes interleaved,
     // fully unrolled: 26 us - every wave64 vector instruction of that chain costs four cycles, and there are 273 of them.
     // Without any backtrack the launch takes 19.0.)
+    if constexpr (!BT) {
+        if (live && i == 0) {
+            const bool bypass = (n_obs != nullptr) && (n_obs[b] == 0);
+            term_out[b] = arg;
+            if (min_cost_out) min_cost_out[b] = bypass ? INF : best;
+            status_out[b] = (!bypass && best > P.w_coll) ? 1 : 0;    // ref :351 (EMP_ST_DP_INFEASIBLE)
+        }
+        // the wavefront's predecessor table, 16 bytes per lane and round (column 0 is never read)
+        const uint4* src = reinterpret_cast<const uint4*>(pre);
+        uint4* dst = reinterpret_cast<uint4*>(pre_out + (size_t)tile * P.col * 64);
+        for (int w = lane; w < P.col * 4; w += 64) dst[w] = src[w];
+        return;
+    }
     if (live && i == 0) {
         const bool bypass = (n_obs != nullptr) && (n_obs[b] == 0);
         double* out = rows_out + (size_t)b * P.col;
@@ -745,16 +770,48 @@ __global__ __launch_bounds__(256, 4) void dp_fused_kernel(DpDev P, const double*
 // from the chosen rows alone (s0 = plan_start_s + c * sample_s, l0 = the previous node, dl0 = ddl0 = 0 after the
 // first segment), so the quintics are independent and only the output offsets need a prefix sum over the
 // per-segment sample counts (ref :405 / :423: len(arange(0, int(end_s - start_s), res))).
+// pre / term != nullptr (the planning cycle): the sweep left the backtrack to this kernel (dp_sweep_kernel, BT == false) -
+// the scene's predecessor bytes are gathered into LDS, lane 0 follows the chain (ref :355-361; no obstacles: the centre row,
+// :362-363) and `rows_out` [B][col] receives the rows.  dynamic LDS then: col doubles + col * row bytes.
 __global__ __launch_bounds__(64) void dp_enrich_wave_kernel(DpDev P, const double* __restrict__ rows,
                                                            const double* __restrict__ start, int max_pts,
                                                            double* __restrict__ path_s, double* __restrict__ path_l,
                                                            int* __restrict__ path_len, int* __restrict__ status,
-                                                           int or_status) {
+                                                           int or_status, const unsigned char* __restrict__ pre = nullptr,
+                                                           const int* __restrict__ term = nullptr,
+                                                           const int* __restrict__ n_obs = nullptr,
+                                                           double* __restrict__ rows_out = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double enrich_lds[];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const double ps = start[b * 4 + 0];
     double* os = path_s + (size_t)b * max_pts;
     double* ol = path_l + (size_t)b * max_pts;
     const double* my_rows = rows + (size_t)b * P.col;
+    if (pre != nullptr) {
+        double* lrows = enrich_lds;                                                   // [col]
+        unsigned char* bt = reinterpret_cast<unsigned char*>(lrows + P.col);          // [col][row]
+        const int tile = b / P.S, base = (b - tile * P.S) * P.row;
+        const unsigned char* tp = pre + (size_t)tile * P.col * 64 + base;
+        for (int j = 1 + lane; j < P.col; j += 64)
+            for (int r = 0; r < P.row; ++r) bt[j * P.row + r] = tp[j * 64 + r];
+        __syncthreads();
+        if (lane == 0) {
+            if (n_obs != nullptr && n_obs[b] == 0) {                                   // ref :362-363
+                const double centre = (double)(P.row + 1) / 2.0 - 1.0;
+                for (int j = 0; j < P.col; ++j) lrows[j] = centre;
+            } else {
+                int idx = term[b];
+                lrows[P.col - 1] = (double)idx;
+                for (int j = P.col - 1; j >= 1; --j) {                                // ref :355-359
+                    idx = bt[j * P.row + idx];
+                    lrows[j - 1] = (double)idx;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = lane; j < P.col; j += 64) rows_out[(size_t)b * P.col + j] = lrows[j];
+        my_rows = lrows;
+    }
     int n_before = 0;
     bool trunc = false;
     double last_s = ps, last_l = start[b * 4 + 1];

@@ -112,6 +112,17 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     double* sm = lk + max_ref;
     const double* line = ref_line + (size_t)b * max_ref * 4;
     const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
+    // Every coordinate the ten match scans below start from is fetched HERE, next to the reference line: one round trip
+    // to memory for the whole kernel.  Loaded where they are used - one obstacle per scan, each scan behind the previous
+    // one - they cost a dependent trip each: a third of the kernel's 30 us, on the queue that is the step's critical path.
+    const int k = n_obs ? min(max(n_obs[b], 0), max_obs) : 0;   // clamped to the row's capacity
+    const double ox = origin_xy[2 * b], oy = origin_xy[2 * b + 1];
+    const double px = start_xy[2 * b], py = start_xy[2 * b + 1];
+    double obx = 0.0, oby = 0.0;                        // obstacle `lane` of the first 64 (the rest are loaded in the loop)
+    if (lane < k) {
+        obx = obs_xy[((size_t)b * max_obs + lane) * 2];
+        oby = obs_xy[((size_t)b * max_obs + lane) * 2 + 1];
+    }
     for (int i = lane; i < P; i += 64) {
         lx[i] = line[4 * i];
         ly[i] = line[4 * i + 1];
@@ -146,7 +157,6 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     __syncthreads();
     auto node = [&](int i) { return Node{lx[i], ly[i], lth[i], lk[i]}; };
     // origin of the s axis (ref :457-471)
-    const double ox = origin_xy[2 * b], oy = origin_xy[2 * b + 1];
     const int m0 = match_scan_wave(lx, ly, P, ox, oy, 50);
     const double s0 = projection_s(node(m0), sm[m0], ox, oy);
     __syncthreads();
@@ -158,24 +168,25 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     __syncthreads();
     // obstacles (ref test_9.py:122): matches one after the other (each scan is wave-parallel), then one
     // obstacle per lane for the projection arithmetic; l uses the FIRST obstacle's match (quirk :413)
-    const int k = n_obs ? min(max(n_obs[b], 0), max_obs) : 0;   // clamped to the row's capacity
     int my_match = 0, first_match = 0;
     for (int j = 0; j < k; ++j) {
-        const double x = obs_xy[((size_t)b * max_obs + j) * 2], y = obs_xy[((size_t)b * max_obs + j) * 2 + 1];
+        if (j >= 64 && (j & 63) == 0 && (j & ~63) + lane < k) {       // the next 64 obstacles (rows of more than 64 slots)
+            obx = obs_xy[((size_t)b * max_obs + (j & ~63) + lane) * 2];
+            oby = obs_xy[((size_t)b * max_obs + (j & ~63) + lane) * 2 + 1];
+        }
+        const double x = __shfl(obx, j & 63, 64), y = __shfl(oby, j & 63, 64);
         const int mj = match_scan_wave(lx, ly, P, x, y, 50);
         if (j == 0) first_match = mj;
         if ((j & 63) == lane) my_match = mj;
         if ((j & 63) == 63 || j == k - 1) {                 // flush a full set of lanes
             const int jj = (j & ~63) + lane;
             if (jj <= j) {
-                const double px = obs_xy[((size_t)b * max_obs + jj) * 2], py = obs_xy[((size_t)b * max_obs + jj) * 2 + 1];
-                obs_s[(size_t)b * obs_cap + jj] = projection_s(node(my_match), sm[my_match], px, py);
-                obs_l[(size_t)b * obs_cap + jj] = lateral_offset(project_on(node(first_match), px, py), px, py);
+                obs_s[(size_t)b * obs_cap + jj] = projection_s(node(my_match), sm[my_match], obx, oby);
+                obs_l[(size_t)b * obs_cap + jj] = lateral_offset(project_on(node(first_match), obx, oby), obx, oby);
             }
         }
     }
     // planning start (ref test_9.py:134 and :172-177)
-    const double px = start_xy[2 * b], py = start_xy[2 * b + 1];
     const int ms = match_scan_wave(lx, ly, P, px, py, 50);
     if (lane == 0) {
         const Node proj = project_on(node(ms), px, py);
