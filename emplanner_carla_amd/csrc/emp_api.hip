@@ -808,8 +808,9 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
         int rc4 = set_lds(ctx, k4, lds4);
         if (rc4) return rc4;
         KernelTimer t4(ctx, "to_cartesian");
+        static const int force_fb = [] { const char* e = getenv("EMP_SMOOTH_FORCE_FALLBACK"); return (e && e[0] == '1') ? 1 : 0; }();   // tests
         hipLaunchKernelGGL(k4, dim3((B + 3) / 4), dim3(64), lds4, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map,
-                           n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status);
+                           n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status, force_fb);
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
     }

@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
     const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
-    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
+    double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status, int force_fallback) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);
     const int lane = threadIdx.x & 63, sc = lane >> 4, sl = lane & 15;
@@ -931,7 +931,8 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
         ref[r] = (alive && j < m) ? v : 0.0;
     }
     int it = 0;
-    const int rc = box_qp_active_set_rows<R>(ref, alive ? m : 0, grp ? sy : sx, u, &it);
+    int rc = box_qp_active_set_rows<R>(ref, alive ? m : 0, grp ? sy : sx, u, &it);
+    if (force_fallback && rc == 0) rc = -1;          // test hook (EMP_SMOOTH_FORCE_FALLBACK=1): every scene takes the fall-back
     const unsigned long long unsettled = __ballot(alive && rc < 0), wrong = __ballot(alive && rc > 0);
     const bool need_fb = ((unsettled >> (16 * sc)) & 0xffffull) != 0ull;
     if (((wrong >> (16 * sc)) & 0xffffull) != 0ull) {

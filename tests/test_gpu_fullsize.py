@@ -599,3 +599,30 @@ def test_both_path_qp_kernels_agree_on_the_benchmark_batch(tmp_path):
     assert np.array_equal(a["traj_len"], b["traj_len"])
     assert np.abs(a["path_l"][ok] - b["path_l"][ok]).max() < 1e-7
     assert np.abs(a["traj"][ok] - b["traj"][ok]).max() < 1e-7
+
+
+def test_cartesian_tail_kernels_agree_on_the_benchmark_batch(tmp_path):
+    """The cycle's Cartesian tail runs four scenes per wavefront (cycle_cartesian_rows_kernel); the one-scene-per-wavefront
+    kernel of rounds 1-2 stays behind EMP_CARTESIAN_WAVE=1.  Same operations per coordinate in the same order: the
+    trajectories of the 4096 benchmark scenes must be BIT-identical.  Third run: EMP_SMOOTH_FORCE_FALLBACK=1 sends every
+    scene of the new kernel through its fall-back (the half-wave interior-point / active-set solvers, the whole wavefront
+    on one scene at a time) - a path no test or benchmark scene takes by itself; it must classify alike and agree to 1e-9."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "qp_form_compare.py")
+    outs = {}
+    for name, env_extra in (("rows", {}), ("wave", {"EMP_CARTESIAN_WAVE": "1"}), ("fallback", {"EMP_SMOOTH_FORCE_FALLBACK": "1"})):
+        out = str(tmp_path / f"{name}.npz")
+        run = subprocess.run([sys.executable, tool, out], cwd=root, env=dict(os.environ, **env_extra), capture_output=True,
+                             text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs[name] = np.load(out)
+    a, b, c = outs["rows"], outs["wave"], outs["fallback"]
+    for other in (b, c):
+        assert np.array_equal(a["status"], other["status"]) and np.array_equal(a["traj_len"], other["traj_len"])
+    ok = (a["status"] & ~1) == 0
+    assert ok.sum() > 3000
+    assert np.array_equal(a["traj"], b["traj"]), "the two kernels perform the same operations: bit-identical"
+    assert np.abs(a["traj"][ok] - c["traj"][ok]).max() < 1e-9
