@@ -129,12 +129,12 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  *   EMP_PIPELINE_STAGED    two batches: the back stage (densified DP path, path QP, Cartesian tail) of call k runs on a
  *                          second stream while the front stage (projection, edge costs, sweep) of call k+1 runs on
  *                          emp_stream().  The front stages stay serial, so the sweep runs next to nothing but the end
- *                          of a back stage and keeps its share of the HBM roofline (0.32 ms per 4096-scene step, sweep
- *                          21 us).
+ *                          of a back stage and keeps its share of the HBM roofline (0.26 ms per 4096-scene step, sweep
+ *                          21 us).  A call may wait ON THE HOST for the call four back (emp_pipeline_depth).
  *   n = 2..EMP_PIPELINE_MAX  n batches on n lanes (a stream and a pool of temporaries each; ABI version 7): call k runs
  *                          whole on lane k mod n, behind everything queued on emp_stream() when it is issued, and the
- *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.27 ms
- *                          per step) at the price of every kernel's own duration (the sweep: 45 us).  Wants as many
+ *                          dispatcher overlaps the kernels of n consecutive cycles.  Highest throughput (n = 3: 0.258 ms
+ *                          per step) at the price of every kernel's own duration (the sweep: 40 us).  Wants as many
  *                          hardware queues as streams (n lanes + emp_stream()): the HIP runtime maps a process's streams
  *                          onto GPU_MAX_HW_QUEUES queues (default 4) and reads the variable when it initialises, so the
  *                          HOST PROGRAM exports e.g. GPU_MAX_HW_QUEUES=8 before it first touches HIP - the library does
