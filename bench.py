@@ -223,6 +223,8 @@ def main():
     ap.add_argument("--records", choices=["full", "trajectory"], default="full",
                     help="what a record carries: everything a cycle returns (179 doubles per scene at 40x9) or status + "
                          "trajectory only (94)")
+    ap.add_argument("--ordered-inputs", action="store_true", help="cfg5: keep every cycle ordered behind the main stream's work "
+                    "(the S-T kernels of the step before), as a caller whose inputs come from that stream needs it")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -287,6 +289,10 @@ def main():
         args.pipeline = "2" if wide else "staged"
     pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
     pl.set_pipeline(pmode)
+    if wide and not args.ordered_inputs:
+        # the scene data is resident and complete before the first step: the cycles need not run behind the S-T kernels that
+        # step() queues on the main stream between them (include/emplanner.h, emp_set_input_order)
+        pl.set_input_order(False)
     pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()
 

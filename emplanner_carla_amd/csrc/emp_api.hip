@@ -522,6 +522,12 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     return EMP_OK;
 }
 
+int emp_set_input_order(emp_ctx* ctx, int enabled) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    ctx->order_inputs = enabled != 0;
+    return EMP_OK;
+}
+
 int emp_pipeline_depth(emp_ctx* ctx) {
     if (!ctx) return EMP_ERR_INVALID;
     return ctx->pipe_mode == 0 ? 1 : ctx->lanes_in_use();
@@ -1153,8 +1159,10 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
             EMP_HIP(ctx, hipEventRecord(lane.ln->ev_tail, ctx->stream));
             EMP_HIP(ctx, hipStreamWaitEvent(lane.main_stream, lane.ln->ev_tail, 0));
         }
-        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
-        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
+        if (ctx->order_inputs) {
+            EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
+            EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
+        }
     }
     Stage st(ctx, where, piped);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
