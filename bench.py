@@ -207,8 +207,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="auto", help="emp_set_pipeline mode: 'staged' (two batches, back stage of one over "
                     "the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n lanes "
-                    "(highest throughput, every kernel slower); 'auto' (default) = staged for cfg2, 2 lanes for cfg5 (whose "
-                    "S-T kernels run on the main stream beside the cycles on the lanes)")
+                    "(a little more throughput, every kernel slower); 'auto' (default) = staged")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
     ap.add_argument("--settle-steps", type=int, default=-1, help="untimed steps before the timed region, warm-up included "
                     "(clock settling; 0 = only the --warmup steps; default: ~50 ms of work - 150 steps at 4096 scenes of "
@@ -223,8 +222,6 @@ def main():
     ap.add_argument("--records", choices=["full", "trajectory"], default="full",
                     help="what a record carries: everything a cycle returns (179 doubles per scene at 40x9) or status + "
                          "trajectory only (94)")
-    ap.add_argument("--ordered-inputs", action="store_true", help="cfg5: keep every cycle ordered behind the main stream's work "
-                    "(the S-T kernels of the step before), as a caller whose inputs come from that stream needs it")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -286,13 +283,9 @@ def main():
     # Several batches in flight (include/emplanner.h, emp_set_pipeline).  Every step is a complete pass over the batch;
     # the K timed steps are all finished at the closing fence.
     if args.pipeline == "auto":
-        args.pipeline = "2" if wide else "staged"
+        args.pipeline = "staged"      # (cfg5 until round 3: 2 lanes - the same 6.4 ms per step now, with the sweep at 0.39 instead of 0.71)
     pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
     pl.set_pipeline(pmode)
-    if wide and not args.ordered_inputs:
-        # the scene data is resident and complete before the first step: the cycles need not run behind the S-T kernels that
-        # step() queues on the main stream between them (include/emplanner.h, emp_set_input_order)
-        pl.set_input_order(False)
     pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()
 

@@ -117,7 +117,6 @@ PROTOTYPES = {
     "emp_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "emp_result_stream": (_vp, [_vp]),
     "emp_pipeline_depth": (C.c_int, [_vp]),
-    "emp_set_input_order": (C.c_int, [_vp, C.c_int]),
     "emp_set_fence": (C.c_int, [_vp, C.c_int]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),

@@ -319,11 +319,6 @@ class Planner:
         overlap them (``False``: only for work that does not read a cycle's outputs)."""
         self._check(self._lib.emp_set_fence(self._h, 1 if enabled else 0))
 
-    def set_input_order(self, enabled: bool):
-        """emp_set_input_order: whether a lane-mode ``plan_cycle`` runs behind everything queued on the planner's main stream
-        when it is issued (default) or beside it (``False``: the caller's inputs are complete before the call)."""
-        self._check(self._lib.emp_set_input_order(self._h, 1 if enabled else 0))
-
     def torch_result_stream(self):
         """The stream on which the latest cycle's outputs become complete (its lane in pipelined mode)."""
         if not self.pipelined:

@@ -522,12 +522,6 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     return EMP_OK;
 }
 
-int emp_set_input_order(emp_ctx* ctx, int enabled) {
-    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    ctx->order_inputs = enabled != 0;
-    return EMP_OK;
-}
-
 int emp_pipeline_depth(emp_ctx* ctx) {
     if (!ctx) return EMP_ERR_INVALID;
     return ctx->pipe_mode == 0 ? 1 : ctx->lanes_in_use();
@@ -771,15 +765,17 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     const size_t per_group = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
     int rc;
     KernelTimer t(ctx, "path_qp");
-    // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations; EMP_PATH_QP_PAIR=1 (development, A/B runs) keeps the
-    // two-scenes-per-wavefront kernels of rounds 1-2.
+    // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations, four up to 66; EMP_PATH_QP_PAIR=1 (development, A/B runs)
+    // keeps the kernels of rounds 1-2 (two scenes per wavefront up to 34 stations, one beyond).
     static const bool pair_form = [] { const char* e = getenv("EMP_PATH_QP_PAIR"); return e && e[0] == '1'; }();
-    if (cap <= 34 && !pair_form) {
-        const bool r3 = cap <= 26;
-        const size_t per_wave = 8 * ((size_t)5 * cap + 4 * (size_t)max_obs + (r3 ? path_qp_words_rows<3>() : path_qp_words_rows<4>())) * sizeof(double);
-        auto kern = r3 ? cycle_qp_rows_kernel<3> : cycle_qp_rows_kernel<4>;
+    if (cap <= 66 && !pair_form) {                                    // 8 (4) scenes per wavefront on groups of 8 (16) lanes
+        const int gp = cap <= 34 ? 8 : 16;
+        const size_t words = cap <= 26 ? path_qp_words_rows<8, 3>() : cap <= 34 ? path_qp_words_rows<8, 4>() : path_qp_words_rows<16, 4>();
+        const size_t per_wave = (size_t)(64 / gp) * ((size_t)5 * cap + 4 * (size_t)max_obs + words) * sizeof(double);
+        auto kern = cap <= 26 ? cycle_qp_rows_kernel<8, 3> : cap <= 34 ? cycle_qp_rows_kernel<8, 4> : cycle_qp_rows_kernel<16, 4>;
         if ((rc = set_lds(ctx, kern, per_wave))) return rc;
-        hipLaunchKernelGGL(kern, dim3((B + 7) / 8), dim3(64), per_wave, ctx->stream, B, max_pts,
+        const int spw = 64 / gp;
+        hipLaunchKernelGGL(kern, dim3((B + spw - 1) / spw), dim3(64), per_wave, ctx->stream, B, max_pts,
                            max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     } else if (cap <= 34) {                                           // N, ns <= 32: two scenes per wavefront
         const size_t per_pair = 2 * ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words_pair()) * sizeof(double);
@@ -805,17 +801,18 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
     const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
     const int cap = path_cap + 1;                                        // trajectory = planning start + path points
     const size_t lds = ((size_t)max_ref + 3 * (size_t)cap + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
-    // Four scenes per wavefront up to 32 trajectory points (emp_tail_kernels.h, cycle_cartesian_rows_kernel);
+    // Four scenes per wavefront up to 32 trajectory points, two up to 64 (emp_tail_kernels.h, cycle_cartesian_rows_kernel);
     // EMP_CARTESIAN_WAVE=1 (development, A/B runs) keeps the one-scene-per-wavefront kernels of rounds 1-2.
     static const bool wave_form = [] { const char* e = getenv("EMP_CARTESIAN_WAVE"); return e && e[0] == '1'; }();
-    if (cap <= 32 && !wave_form) {
-        const size_t lds4 = (4 * ((size_t)max_ref + 5 * (size_t)cap) + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
-        auto k4 = cap <= 24 ? cycle_cartesian_rows_kernel<3> : cycle_cartesian_rows_kernel<4>;
+    if (cap <= 64 && !wave_form) {
+        const int spw = cap <= 32 ? 4 : 2;
+        const size_t lds4 = ((size_t)spw * ((size_t)max_ref + 5 * (size_t)cap) + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
+        auto k4 = cap <= 24 ? cycle_cartesian_rows_kernel<8, 3> : cap <= 32 ? cycle_cartesian_rows_kernel<8, 4> : cycle_cartesian_rows_kernel<16, 4>;
         int rc4 = set_lds(ctx, k4, lds4);
         if (rc4) return rc4;
         KernelTimer t4(ctx, "to_cartesian");
         static const int force_fb = [] { const char* e = getenv("EMP_SMOOTH_FORCE_FALLBACK"); return (e && e[0] == '1') ? 1 : 0; }();   // tests
-        hipLaunchKernelGGL(k4, dim3((B + 3) / 4), dim3(64), lds4, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map,
+        hipLaunchKernelGGL(k4, dim3((B + spw - 1) / spw), dim3(64), lds4, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map,
                            n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status, force_fb);
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
@@ -1159,10 +1156,8 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
             EMP_HIP(ctx, hipEventRecord(lane.ln->ev_tail, ctx->stream));
             EMP_HIP(ctx, hipStreamWaitEvent(lane.main_stream, lane.ln->ev_tail, 0));
         }
-        if (ctx->order_inputs) {
-            EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
-            EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
-        }
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
     }
     Stage st(ctx, where, piped);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;

@@ -79,7 +79,6 @@ struct emp_ctx {
     int lane = 0;                       // lane of the latest pipelined cycle call
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
-    bool order_inputs = true;           // emp_set_input_order: a LANES cycle runs behind everything queued on `stream` when it is issued
     bool pipelined() const { return pipe_mode != 0; }
     // STAGED rotates kStagedPools pools of temporaries although only two calls overlap on the GPU: call k reuses the pool
     // of call k - 4 and the HOST waits for that call's back stage (long finished unless the host runs more than four

@@ -26,26 +26,33 @@
 
 namespace emp {
 
-// ---- reductions over an aligned group of 8 lanes: two quad permutes and the half-row mirror
-template <class Op>
+// ---- reductions over an aligned group of GP = 8 or 16 lanes: two quad permutes, the half-row mirror, (16:) the row mirror
+template <int GP, class Op>
 __device__ __forceinline__ double oct_reduce(double v, Op op) {
+    static_assert(GP == 8 || GP == 16, "groups of 8 or 16 lanes");
     v = op(v, dpp_move<0xB1>(v));      // quad_perm [1,0,3,2]
     v = op(v, dpp_move<0x4E>(v));      // quad_perm [2,3,0,1]
     v = op(v, dpp_move<0x141>(v));     // row_half_mirror
+    if constexpr (GP == 16) v = op(v, dpp_move<0x140>(v));     // row_mirror
     return v;
 }
-__device__ __forceinline__ double oct_max(double v) { return oct_reduce(v, [](double a, double b) { return fmax(a, b); }); }
-__device__ __forceinline__ double oct_min(double v) { return oct_reduce(v, [](double a, double b) { return fmin(a, b); }); }
-__device__ __forceinline__ double oct_sum(double v) { return oct_reduce(v, [](double a, double b) { return a + b; }); }
+template <int GP>
+__device__ __forceinline__ double oct_max(double v) { return oct_reduce<GP>(v, [](double a, double b) { return fmax(a, b); }); }
+template <int GP>
+__device__ __forceinline__ double oct_min(double v) { return oct_reduce<GP>(v, [](double a, double b) { return fmin(a, b); }); }
+template <int GP>
+__device__ __forceinline__ double oct_sum(double v) { return oct_reduce<GP>(v, [](double a, double b) { return a + b; }); }
+template <int GP>
 __device__ __forceinline__ bool oct_any(bool p) {
     const unsigned long long m = __ballot(p);
-    return ((m >> ((threadIdx.x & 63) & ~7)) & 0xffull) != 0ull;
+    return ((m >> ((threadIdx.x & 63) & ~(GP - 1))) & ((1ull << GP) - 1ull)) != 0ull;
 }
-// largest value of a group-uniform int over the eight groups of the wavefront (scalar result)
+// largest value of a group-uniform int over the groups of the wavefront (scalar result)
+template <int GP>
 __device__ __forceinline__ int oct_wave_max(int v) {
     int r = __builtin_amdgcn_readlane(v, 0);
 #pragma unroll
-    for (int g = 1; g < 8; ++g) r = max(r, __builtin_amdgcn_readlane(v, 8 * g));
+    for (int g = 1; g < 64 / GP; ++g) r = max(r, __builtin_amdgcn_readlane(v, GP * g));
     return r;
 }
 
@@ -59,7 +66,7 @@ __device__ __forceinline__ int oct_wave_max(int v) {
 // carries over a group's end (into idle lanes, or into the first lane of the next group) is zero, and a failed group
 // is left with the identity factor, as in band_chol_group.
 // ---------------------------------------------------------------------------------------------
-template <int R>
+template <int GP, int R>
 __device__ __forceinline__ bool band_chol_rows(double (&a)[R][4], double (&rinv)[R], double (&low)[R][4], int N, int gl,
                                                bool active, int steps) {
     static_assert(R >= 3, "a lane must hold at least KD = 3 rows");
@@ -119,7 +126,7 @@ __device__ __forceinline__ bool band_chol_rows(double (&a)[R][4], double (&rinv)
         const double offd = fabs(a[r][1]) + fabs(a[r][2]) + fabs(a[r][3]);
         bad = bad || (rowv[r] && !(diag[r] > 0.0 && diag[r] < 1e300 && offd < 1e300));
     }
-    const bool failed = oct_any(bad);
+    const bool failed = oct_any<GP>(bad);
     if (failed) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -190,12 +197,12 @@ __device__ __forceinline__ void band_solve_rows(const double (&a)[R][4], const d
 
 // ---------------------------------------------------------------------------------------------
 // Interior point for the path QP (RangeQp<3, 2, 3>, window offset -2), R stations and R unknowns per lane.
-// Q must be bound with bind_fast(mem, 8 R, 8 R, N, ns) behind at least 12 readable doubles (the coefficient slots of
+// Q must be bound with bind_fast(mem, GP R, GP R, N, ns) behind at least 12 readable doubles (the coefficient slots of
 // path_qp_group_rows): windows are read with plain lane offsets, up to three rows outside their arrays, and what lies
 // outside a problem is replaced by zero after the load.  Q.g must be the same for every lane of the wavefront.
 // returns (per group) 0 converged, 2 failed / infeasible.
 // ---------------------------------------------------------------------------------------------
-template <int R>
+template <int GP, int R>
 __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_cap, double* keep) {
     constexpr int F = 2, W = 3;
     const int N = Q.N, ns = Q.ns, rows = ns * F * 2;
@@ -203,7 +210,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
     int iters = 0;
     bool acceptable = false;
     const int base = gl * R;                                   // first station / first unknown of this lane
-    const int steps = oct_wave_max((state == 1) ? (N + R - 1) / R : 0);
+    const int steps = oct_wave_max<GP>((state == 1) ? (N + R - 1) / R : 0);
     // form weights and their products, wave-uniform: scalar registers
     double g[F][W], gg0[W][F], gg1[W - 1][F], gg2[W - 2][F];   // gg_d[p][f] = g[f][p] g[f][p + d]
 #pragma unroll
@@ -294,8 +301,8 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
         pdiag = fmax(pdiag, ld(Q.P, (base + r) * 4, ok));
         qabs = fmax(qabs, fabs(ld(Q.q, base + r, ok)));
     }
-    const double pscale = oct_max(pdiag);                     // largest Hessian diagonal
-    const double qscale = fmax(oct_max(qabs), 1.0);
+    const double pscale = oct_max<GP>(pdiag);                     // largest Hessian diagonal
+    const double qscale = fmax(oct_max<GP>(qabs), 1.0);
     {
         const double z0 = Q.initial_multiplier(pscale);
         double v[R][F], c_it[R][F], lo_it[R][F], hi_it[R][F];
@@ -312,7 +319,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                 if ((tmask >> r) & 1u) smin = fmin(smin, fmin(su[r][f], sl[r][f]));
             }
         }
-        smin = oct_min(smin);
+        smin = oct_min<GP>(smin);
         const double shift = (smin < 1.0) ? (1.0 - smin) : 0.0;   // slacks pushed to >= 1 (infeasible start)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -397,10 +404,10 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                 fa[r][2] = (ok && m + 2 < N) ? e2 : 0.0;
                 fa[r][3] = (ok && m + 3 < N) ? e3 : 0.0;
             }
-            rd_max = oct_max(rd_max);
-            rp_max = oct_max(rp_max);
-            zmax = oct_max(zmax);
-            mu = oct_sum(mu) / (double)rows;
+            rd_max = oct_max<GP>(rd_max);
+            rp_max = oct_max<GP>(rp_max);
+            zmax = oct_max<GP>(zmax);
+            mu = oct_sum<GP>(mu) / (double)rows;
             if (run) {
                 const double dscale = fmax(qscale, zmax);
                 if (rd_max <= Q.eps_d_rel * dscale && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
@@ -423,7 +430,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
         }
         const bool go = state == 1;
         // ---- 3: factorisation
-        const bool okf = band_chol_rows<R>(fa, frinv, flow, N, gl, go, steps);
+        const bool okf = band_chol_rows<GP, R>(fa, frinv, flow, N, gl, go, steps);
         EMP_QP_DEBUG_ROWS("R    chol ok %d\n", (int)okf);
         if (go && !okf) {
             state = acceptable ? 0 : 2;
@@ -469,7 +476,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                                                  fmax(-dzua[r][f] * izu[r][f], -dzla[r][f] * izl[r][f])));
                 }
             }
-            ratio = oct_max(ratio);
+            ratio = oct_max<GP>(ratio);
             const double a_aff = (ratio > 1.0) ? fast_rcp(ratio) : 1.0;
             double mu_aff = 0.0;
 #pragma unroll
@@ -481,7 +488,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                                   (sl[r][f] + a_aff * dsla[r][f]) * (zl[r][f] + a_aff * dzla[r][f]);
                 }
             }
-            mu_aff = oct_sum(mu_aff) / (double)rows;
+            mu_aff = oct_sum<GP>(mu_aff) / (double)rows;
             double sigma = (mu > 0.0) ? mu_aff * fast_rcp(mu) : 0.0;
             sigma = sigma * sigma * sigma;
 #pragma unroll
@@ -528,7 +535,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                                                  fmax(-dzu[r][f] * izu[r][f], -dzl[r][f] * izl[r][f])));
                 }
             }
-            ratio = oct_max(ratio);
+            ratio = oct_max<GP>(ratio);
             const double tau = qp_step_fraction(mu);
             const double alpha = (ratio > tau) ? tau * fast_rcp(ratio) : 1.0;   // min(1, tau / ratio)
             EMP_QP_DEBUG_ROWS("R    alpha %.6e\n", alpha);
@@ -561,27 +568,27 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
     return state;
 }
 
-// doubles of LDS one problem of path_qp_group_rows<R> needs: 36 coefficient slots, the solver's arrays at capacity 8 R and
-// the last acceptable iterate
-template <int R>
-__host__ __device__ constexpr int path_qp_words_rows() { return 36 + PathRangeQp::words_fast(8 * R, 8 * R) + 8 * R; }   // + the kept iterate
+// doubles of LDS one problem of path_qp_group_rows<GP, R> needs: GP R + 4 coefficient slots (n + 2 of them are used), the
+// solver's arrays at capacity GP R and the last acceptable iterate
+template <int GP, int R>
+__host__ __device__ constexpr int path_qp_words_rows() { return (GP * R + 4) + PathRangeQp::words_fast(GP * R, GP * R) + GP * R; }
 
 // ---------------------------------------------------------------------------------------------
-// Path QP on one group of 8 lanes (eight scenes per wavefront); n <= 8 R + 2 stations (R = 3: 26, R = 4: 34).
-// Same contract as path_qp_group: every lane of the wavefront must call it; returns (per group) 0 ok, 1 infeasible,
-// 2 failed.  lds: this group's path_qp_words_rows<R>() doubles.
+// Path QP on one group of GP lanes (64 / GP scenes per wavefront); n <= GP R + 2 stations (GP = 8: R = 3: 26, R = 4: 34;
+// GP = 16, R = 4: 66 - BASELINE configs[4]'s 61).  Same contract as path_qp_group: every lane of the wavefront must call
+// it; returns (per group) 0 ok, 1 infeasible, 2 failed.  lds: this group's path_qp_words_rows<GP, R>() doubles.
 // ---------------------------------------------------------------------------------------------
-template <int R>
+template <int GP, int R>
 __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const double* l_max, int n, double l0, double dl0,
                                          double ddl0, const PathQpParams& prm, double* out_l, int* iters_out, bool live,
                                          int debug_stage = 0) {
-    constexpr int GP = 8;
+    constexpr int kCc = GP * R + 4;
     const int gl = (threadIdx.x & 63) & (GP - 1);
     *iters_out = 0;
     PathRangeQp Q;
     double* cc = lds;
     const int nn = live ? n : 4;
-    Q.bind_fast(lds + 36, GP * R, GP * R, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
+    Q.bind_fast(lds + kCc, GP * R, GP * R, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
     int rc = path_qp_setup_group<GP>(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm, gl, live);
     if (!live) rc = 2;
     __syncthreads();
@@ -591,7 +598,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
     {
         double fa[R][4], flow[R][4], frinv[R], b0[R];
         const bool act = ok && Q.N > 0;
-        const int steps = oct_wave_max(act ? (Q.N + R - 1) / R : 0);
+        const int steps = oct_wave_max<GP>(act ? (Q.N + R - 1) / R : 0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool has = act && base + r < Q.N;
@@ -603,7 +610,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
             const double qr = Q.q[base + r];
             b0[r] = has ? -qr : 0.0;
         }
-        const bool okc = band_chol_rows<R>(fa, frinv, flow, Q.N, gl, act, steps);
+        const bool okc = band_chol_rows<GP, R>(fa, frinv, flow, Q.N, gl, act, steps);
         band_solve_rows<R>(fa, frinv, flow, b0, steps);
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -613,7 +620,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
     __syncthreads();
     ok = rc == 0;
     const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
-    const int rs = path_qp_solve_rows<R>(Q, gl, ok && Q.N > 0, cap_it, lds + 36 + PathRangeQp::words_fast(GP * R, GP * R));
+    const int rs = path_qp_solve_rows<GP, R>(Q, gl, ok && Q.N > 0, cap_it, lds + kCc + PathRangeQp::words_fast(GP * R, GP * R));
     if (ok && Q.N > 0) {
         *iters_out = Q.iters;
         if (rs && debug_stage < 10) rc = rs;
@@ -623,7 +630,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
         bool bad = false;
         for (int it = gl; it < Q.ns * 2; it += GP)
             if (Q.c[it] > Q.hi[it] + 1e-9 || Q.c[it] < Q.lo[it] - 1e-9) bad = true;
-        if (oct_any(bad)) rc = 1;
+        if (oct_any<GP>(bad)) rc = 1;
     }
     ok = rc == 0;
     for (int m = gl; m < (ok ? Q.N : 0); m += GP) cc[m + 3] = Q.u[m];

@@ -14,7 +14,7 @@ namespace emp {
 
 // Banded Cholesky, half bandwidth 2, R consecutive rows per lane (row j = gl * R + r); see band_chol_rows.
 // a[r][0..2] = A[j][j..j+2] on entry, the factor row on return; low[r][e] = U[j-e][e] (e = 1, 2).
-template <int R>
+template <int GP, int R>
 __device__ __forceinline__ bool band_chol_rows2(double (&a)[R][3], double (&rinv)[R], double (&low)[R][3], int N, int gl,
                                                 bool active, int steps) {
     static_assert(R >= 2, "a lane must hold at least KD = 2 rows");
@@ -62,7 +62,7 @@ __device__ __forceinline__ bool band_chol_rows2(double (&a)[R][3], double (&rinv
         const double offd = fabs(a[r][1]) + fabs(a[r][2]);
         bad = bad || (rowv[r] && !(diag[r] > 0.0 && diag[r] < 1e300 && offd < 1e300));
     }
-    const bool failed = oct_any(bad);
+    const bool failed = oct_any<GP>(bad);
     if (failed) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -122,15 +122,15 @@ __device__ __forceinline__ void band_solve_rows2(const double (&a)[R][3], const 
     for (int r = 0; r < R; ++r) b[r] = x[r];
 }
 
-// One box QP per group of 8 lanes by the primal-dual active-set iteration (box_qp_active_set_lanes, same arithmetic per
+// One box QP per group of GP lanes (8 or 16) by the primal-dual active-set iteration (box_qp_active_set_lanes, same arithmetic per
 // coordinate): ref[r] = the lane's reference coordinates j = gl * R + r (anything for j >= m), box ref +- thr.
 // Every lane of the wavefront must call it.  Returns (per group) 0 settled (x holds the minimiser), -1 classification
 // still changing after kBoxAsMaxIter rounds (the caller falls back to the interior point), 2 bad input.
-template <int R>
+template <int GP, int R>
 __device__ inline int box_qp_active_set_rows(const double (&ref)[R], int m, const SmoothQpParams& prm, double (&x)[R],
                                              int* iters_out) {
-    const int gl = (threadIdx.x & 63) & 7, base = gl * R;
-    const bool valid = m >= 2 && m <= 8 * R && prm.thr > 0.0;
+    const int gl = (threadIdx.x & 63) & (GP - 1), base = gl * R;
+    const bool valid = m >= 2 && m <= GP * R && prm.thr > 0.0;
     *iters_out = 0;
     bool has[R];
     double Prow[R][3], Plow[R][3], q[R], lo[R], hi[R];
@@ -173,8 +173,8 @@ __device__ inline int box_qp_active_set_rows(const double (&ref)[R], int m, cons
     }
     const double c = 2.0 * (6.0 * prm.w_smooth + 2.0 * prm.w_length + prm.w_ref);   // the Hessian's interior diagonal
     int state = valid ? 1 : 0, iters = 0;                  // 1 running, 0 done, -1 gave up
-    const int steps = oct_wave_max(valid ? (m + R - 1) / R : 0);
-    const bool g_first = gl == 0, g_last = gl == 7;
+    const int steps = oct_wave_max<GP>(valid ? (m + R - 1) / R : 0);
+    const bool g_first = gl == 0, g_last = gl == GP - 1;
     // value i of the lane's row window [-2, R + 1]: own rows, the left neighbour's last two, the right neighbour's first two
     auto window = [&](const double (&v)[R], double (&w)[R + 4]) {
         const double p2 = lane_up1(v[R - 2]), p1 = lane_up1(v[R - 1]), n0 = lane_dn1(v[0]), n1 = lane_dn1(v[1]);
@@ -207,7 +207,7 @@ __device__ inline int box_qp_active_set_rows(const double (&ref)[R], int m, cons
             const double free_rhs = -q[r] - (((Prow[r][1] * abw[r + 3] + Prow[r][2] * abw[r + 4]) + Plow[r][1] * abw[r + 1]) + Plow[r][2] * abw[r]);
             rhs[r] = act[r] ? ab[r] : ((go && has[r]) ? free_rhs : 0.0);
         }
-        const bool okf = band_chol_rows2<R>(fa, frinv, flow, m, gl, go, steps);
+        const bool okf = band_chol_rows2<GP, R>(fa, frinv, flow, m, gl, go, steps);
         band_solve_rows2<R>(fa, frinv, flow, rhs, steps);
         double xs[R], xw[R + 4];
 #pragma unroll
@@ -231,7 +231,7 @@ __device__ inline int box_qp_active_set_rows(const double (&ref)[R], int m, cons
             ncode[r] = nc;
             changed_here = changed_here || (nc != code[r]);
         }
-        const bool changed = oct_any(changed_here);
+        const bool changed = oct_any<GP>(changed_here);
         if (go) {
 #pragma unroll
             for (int r = 0; r < R; ++r) code[r] = ncode[r];

@@ -564,8 +564,8 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
     const int lane = threadIdx.x & 63, grp = lane / G, gl = lane & (G - 1);
     const int b = blockIdx.x * GPW + grp;
     const bool present = b < B;
-    static_assert(R == 0 || G == 8, "the rows solver runs on groups of eight lanes");
-    const int per_group = 5 * cap + 4 * max_obs + (R > 0 ? path_qp_words_rows<(R > 0 ? R : 3)>() : G == 32 ? path_qp_words_pair() : path_qp_words(cap));
+    static_assert(R == 0 || G == 8 || G == 16, "the rows solver runs on groups of 8 or 16 lanes");
+    const int per_group = 5 * cap + 4 * max_obs + (R > 0 ? path_qp_words_rows<(R > 0 ? G : 8), (R > 0 ? R : 3)>() : G == 32 ? path_qp_words_pair() : path_qp_words(cap));
     double* lds = lds_all + (size_t)grp * per_group;
     const size_t o = (size_t)(present ? b : 0) * max_pts;
     double* sd = lds;                 // decimated station s   [cap]
@@ -626,7 +626,7 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         const int sb = present ? b : 0;
         int rc;
         if constexpr (R > 0)
-            rc = path_qp_group_rows<R>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp, ql, &it,
+            rc = path_qp_group_rows<G, R>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp, ql, &it,
                                        live, Q.debug_stage);
         else
             rc = path_qp_group<G>(qmem, lmin, lmax, n, start[4 * sb + 1], start[4 * sb + 2], start[4 * sb + 3], Q.qp,
@@ -687,13 +687,14 @@ template <int G>
 __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(EMP_CYCLE_QP_PARAMS) {
     cycle_qp_body<G>(EMP_CYCLE_QP_ARGS);
 }
-// Eight scenes per wavefront, R stations per lane (emp_qp_rows.h): a quarter of the wavefronts, each as long as before.
+// 64 / GP scenes per wavefront on groups of GP lanes, R stations per lane (emp_qp_rows.h): a quarter (GP = 8) of the
+// wavefronts of the two-per-wavefront kernel, each as long as before.
 #ifndef EMP_QP_ROWS_ATTR
 #define EMP_QP_ROWS_ATTR
 #endif
-template <int R>
+template <int GP, int R>
 __global__ __launch_bounds__(64) EMP_QP_ROWS_ATTR void cycle_qp_rows_kernel(EMP_CYCLE_QP_PARAMS) {
-    cycle_qp_body<8, R>(EMP_CYCLE_QP_ARGS);
+    cycle_qp_body<GP, R>(EMP_CYCLE_QP_ARGS);
 }
 #undef EMP_CYCLE_QP_PARAMS
 #undef EMP_CYCLE_QP_ARGS
@@ -835,9 +836,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // work: what that kernel spends per scene on 23 of 64 lanes (trigonometry) and on sweeps for two problems (smoothing)
 // is shared by four scenes here.  A problem whose active-set classification does not settle (none on any test or
 // benchmark scene) is solved by the whole wavefront with the half-wave solvers of the narrow kernel, one scene at a time.
-// dynamic LDS (doubles): 4 * (max_ref + 5 * cap) + 2 * BoxRangeQp::words(cap, cap)
+// With GP = 16 a scene takes 32 lanes and trajectories of up to 64 points fit (BASELINE configs[4]'s 63): two per wavefront.
+// dynamic LDS (doubles): (32 / GP) * (max_ref + 5 * cap) + 2 * BoxRangeQp::words(cap, cap)
 // ---------------------------------------------------------------------------------------------
-template <int R>
+template <int GP, int R>
 __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     int B, int max_ref, int max_pts, int cap, SmoothQpParams sx, SmoothQpParams sy, const double* __restrict__ ref_line,
     const double* __restrict__ s_map, const int* __restrict__ n_ref, const double* __restrict__ begin_sl,
@@ -845,8 +847,9 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status, int force_fallback) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);
-    const int lane = threadIdx.x & 63, sc = lane >> 4, sl = lane & 15;
-    const int b = blockIdx.x * 4 + sc;
+    constexpr int SL = 2 * GP, SPW = 64 / SL;     // lanes per scene, scenes per wavefront
+    const int lane = threadIdx.x & 63, sc = lane / SL, sl = lane & (SL - 1);
+    const int b = blockIdx.x * SPW + sc;
     const bool present = b < B;
     const size_t bb = present ? (size_t)b : 0;
     const int per_scene = max_ref + 5 * cap;
@@ -855,14 +858,14 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     double* th = txy + 2 * cap;                  // [cap]
     double* px = th + cap;                       // [cap] smoothed x
     double* py = px + cap;                       // [cap] smoothed y
-    double* qmem = lds + (size_t)4 * per_scene;  // the fall-back solver's storage (whole wavefront)
+    double* qmem = lds + (size_t)SPW * per_scene;  // the fall-back solver's storage (whole wavefront)
     const int st = present ? status[bb] : 0;
     int add = 0;                                 // status bits this kernel adds (scene-uniform)
     bool alive = present && !(st & (kStQpFailed | kStBoundIndex | kStTruncated));
     const double* line = ref_line + bb * max_ref * 4;
     const int P = alive ? min(max(n_ref[bb], 0), max_ref) : 0;       // clamped to the row's capacity
     const int n = alive ? path_len[bb] : 0;
-    for (int i = sl; i < P; i += 16) sm[i] = s_map[bb * max_ref + i];
+    for (int i = sl; i < P; i += SL) sm[i] = s_map[bb * max_ref + i];
     __syncthreads();
     // planning start (ref :31-34)
     bool off = false;
@@ -885,22 +888,23 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     bool stop = !alive;
     int nmax = 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) nmax = max(nmax, __builtin_amdgcn_readlane(alive ? n : 0, 16 * g));
-    for (int base = 0; base < nmax; base += 16) {
+    for (int g = 0; g < SPW; ++g) nmax = max(nmax, __builtin_amdgcn_readlane(alive ? n : 0, SL * g));
+    constexpr unsigned long long kSceneMask = (SL == 32) ? 0xffffffffull : 0xffffull;
+    for (int base = 0; base < nmax; base += SL) {
         const int i = base + sl;
         const bool in = !stop && i < n;
         const double s = in ? path_s[bb * max_pts + i] : 0.0;
-        const unsigned bad16 = (unsigned)((__ballot(in && s > s_last) >> (16 * sc)) & 0xffffull);
+        const unsigned bad16 = (unsigned)((__ballot(in && s > s_last) >> (SL * sc)) & kSceneMask);
         const int first_bad = __builtin_ffs((int)bad16);                               // 1-based lane of the scene, 0 if none
         if (!stop && first_bad) count = min(count, base + first_bad - 1);
         bool o2 = false;
         int k = in ? walk_from_zero(sm, P, fmin(s, s_last), &o2) : 0;
-        for (int d = 1; d < 16; d <<= 1) {                 // inclusive running maximum across the scene's lanes
-            const int v = __shfl_up(k, d, 16);
+        for (int d = 1; d < SL; d <<= 1) {                 // inclusive running maximum across the scene's lanes
+            const int v = __shfl_up(k, d, SL);
             if (sl >= d) k = max(k, v);
         }
         k = max(k, carry);
-        carry = __shfl(k, 15, 16);
+        carry = __shfl(k, SL - 1, SL);
         if (in && i < count && i + 1 < cap) {
             const Node mm = node_at(line, k);
             const double ds = s - sm[k];
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     }
     int m = count + 1;
     __syncthreads();
-    if (alive && (m > cap || m > max_pts + 1 || m > 8 * R)) {
+    if (alive && (m > cap || m > max_pts + 1 || m > GP * R)) {
         add = kStTruncated;
         alive = false;
     }
@@ -921,8 +925,8 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
         add = kStSmoothFailed;
         alive = false;
     }
-    // smoothing (ref planning_utils.py:262-361): x on the scene's lanes 0-7, y on 8-15, R points per lane
-    const int grp = sl >> 3, gl = sl & 7;
+    // smoothing (ref planning_utils.py:262-361): x on the scene's first GP lanes, y on the other GP, R points per lane
+    const int grp = sl / GP, gl = sl & (GP - 1);
     double ref[R], u[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -931,11 +935,11 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
         ref[r] = (alive && j < m) ? v : 0.0;
     }
     int it = 0;
-    int rc = box_qp_active_set_rows<R>(ref, alive ? m : 0, grp ? sy : sx, u, &it);
+    int rc = box_qp_active_set_rows<GP, R>(ref, alive ? m : 0, grp ? sy : sx, u, &it);
     if (force_fallback && rc == 0) rc = -1;          // test hook (EMP_SMOOTH_FORCE_FALLBACK=1): every scene takes the fall-back
     const unsigned long long unsettled = __ballot(alive && rc < 0), wrong = __ballot(alive && rc > 0);
-    const bool need_fb = ((unsettled >> (16 * sc)) & 0xffffull) != 0ull;
-    if (((wrong >> (16 * sc)) & 0xffffull) != 0ull) {
+    const bool need_fb = ((unsettled >> (SL * sc)) & kSceneMask) != 0ull;
+    if (((wrong >> (SL * sc)) & kSceneMask) != 0ull) {
         add = kStSmoothFailed;
         alive = false;
     }
@@ -948,13 +952,13 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     }
     __syncthreads();
     if (unsettled != 0ull) {             // wave-uniform; never taken on the test and benchmark scenes
-        for (int s2 = 0; s2 < 4; ++s2) {
-            if (((unsettled >> (16 * s2)) & 0xffffull) == 0ull) continue;
-            const int m2 = __builtin_amdgcn_readlane(m, 16 * s2);
+        for (int s2 = 0; s2 < SPW; ++s2) {
+            if (((unsettled >> (SL * s2)) & kSceneMask) == 0ull) continue;
+            const int m2 = __builtin_amdgcn_readlane(m, SL * s2);
             double* base2 = lds + (size_t)s2 * per_scene;
             double *qx = nullptr, *qy = nullptr;
             int it2 = 0;
-            const int rc2 = smooth_pair_wave<false>(qmem, base2 + max_ref, 2, m2, sx, sy, &qx, &qy, &it2);
+            const int rc2 = smooth_pair_wave<(GP * R > 32)>(qmem, base2 + max_ref, 2, m2, sx, sy, &qx, &qy, &it2);
             if (rc2 == 0) {
                 for (int i = lane; i < m2; i += 64) {
                     base2[max_ref + 3 * cap + i] = qx[i];
@@ -970,14 +974,14 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     // heading / curvature (ref planning_utils.py:185-228), one point per lane
     double* out_rows = traj + bb * (max_pts + 1) * 4;
     const int mm = alive ? m : 0;
-    for (int i = sl; i < mm; i += 16) {
+    for (int i = sl; i < mm; i += SL) {
         const int a = (i - 1 > 0) ? i - 1 : 0, c = (i < mm - 2) ? i : mm - 2;
         const double dx = ((px[a + 1] - px[a]) + (px[c + 1] - px[c])) / 2.0;
         const double dy = ((py[a + 1] - py[a]) + (py[c + 1] - py[c])) / 2.0;
         th[i] = atan2(dy, dx);
     }
     __syncthreads();
-    for (int i = sl; i < mm; i += 16) {
+    for (int i = sl; i < mm; i += SL) {
         const int a = (i - 1 > 0) ? i - 1 : 0, c = (i < mm - 2) ? i : mm - 2;
         const double dx = ((px[a + 1] - px[a]) + (px[c + 1] - px[c])) / 2.0;
         const double dy = ((py[a + 1] - py[a]) + (py[c + 1] - py[c])) / 2.0;
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
         o[3] = sin((dpre + daft) / 2.0) / sqrt(dx * dx + dy * dy);
     }
     if (present) {
-        for (int i = mm * 4 + sl; i < (max_pts + 1) * 4; i += 16) out_rows[i] = 0.0;       // padding reads as 0
+        for (int i = mm * 4 + sl; i < (max_pts + 1) * 4; i += SL) out_rows[i] = 0.0;       // padding reads as 0
         if (sl == 0) {
             traj_len[bb] = mm;
             if (add) status[bb] = st | add;

@@ -154,12 +154,6 @@ void* emp_result_stream(emp_ctx* ctx);
  * waits ON THE HOST for the call four back (a call that finished long ago unless the host runs further ahead than that,
  * which it then may not) - a stream-side wait for the pool's previous user cost ~11 us of every 0.29 ms step. */
 int emp_pipeline_depth(emp_ctx* ctx);
-/* Lane mode orders every cycle behind whatever is queued on emp_stream() when it is issued, so that its inputs may come from
- * work on that stream (on by default).  A caller whose inputs are complete before the call - resident scene data - switches the
- * ordering off (ABI version 8): the cycles then run beside the OTHER entry points' work on emp_stream() instead of behind it
- * (bench.py --config cfg5: the S-T speed DP of step k no longer holds back the cycle of step k + 1).  Staged mode and the
- * unpipelined mode run their first kernel on emp_stream() and are ordered by it in any case. */
-int emp_set_input_order(emp_ctx* ctx, int enabled);
 /* The fence of the pipelined modes (on by default): every entry point other than a pipelined emp_plan_cycle first lets
  * emp_stream() wait for the cycles in flight, so that it may read their outputs.  Switched off, such calls are queued on
  * emp_stream() at once and overlap the cycles in flight - for work that does not depend on them (the S-T speed planner of
