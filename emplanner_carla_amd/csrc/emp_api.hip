@@ -105,8 +105,13 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     if (tiled && tiled_elems(d) * sizeof(double) > ((size_t)256 << 20) && wpb < 4) wpb = 4;
     if (eb_env) wpb = eb_env / 64;
     const int eb = wpb * 64;
-    // each of the block's wavefronts takes whole columns: about two per wavefront, chunk sizes multiples of the wavefront count
-    if (ncol > 0) { chunks = (ncol + 2 * wpb - 1) / (2 * wpb); if (chunks < 1) chunks = 1; }
+    // each of the block's wavefronts takes whole columns: two per wavefront, or one while that leaves the chip short of blocks
+    // (a single scene: 29 us with one column per wavefront, 44 with two); chunk sizes multiples of the wavefront count
+    if (ncol > 0) {
+        const int cpw = ((long long)d.tiles * ((ncol + 2 * wpb - 1) / (2 * wpb)) >= 1024) ? 2 : 1;
+        chunks = (ncol + cpw * wpb - 1) / (cpw * wpb);
+        if (chunks < 1) chunks = 1;
+    }
     int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
     cols_per_chunk = cols_per_chunk >= wpb ? (cols_per_chunk / wpb) * wpb : wpb;
     chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
@@ -768,7 +773,10 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations, four up to 66; EMP_PATH_QP_PAIR=1 (development, A/B runs)
     // keeps the kernels of rounds 1-2 (two scenes per wavefront up to 34 stations, one beyond).
     static const bool pair_form = [] { const char* e = getenv("EMP_PATH_QP_PAIR"); return e && e[0] == '1'; }();
-    if (cap <= 66 && !pair_form) {                                    // 8 (4) scenes per wavefront on groups of 8 (16) lanes
+    // (small batches keep the two-per-wavefront kernel: a batch that cannot fill the chip is served by latency, and an
+    // interior-point iteration of that kernel is 2500 instructions against 3000, for the slower of two scenes instead of eight)
+    const bool few = B < 1024 && cap <= 34;
+    if (cap <= 66 && !pair_form && !few) {                            // 8 (4) scenes per wavefront on groups of 8 (16) lanes
         const int gp = cap <= 34 ? 8 : 16;
         const size_t words = cap <= 26 ? path_qp_words_rows<8, 3>() : cap <= 34 ? path_qp_words_rows<8, 4>() : path_qp_words_rows<16, 4>();
         const size_t per_wave = (size_t)(64 / gp) * ((size_t)5 * cap + 4 * (size_t)max_obs + words) * sizeof(double);
