@@ -355,6 +355,9 @@ def test_pipelined_cycles_equal_plain_cycles(planner, pipe):
         plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
     planner.set_pipeline(pipe)
     assert planner.in_flight == (2 if pipe == "staged" else pipe)
+    # emp_pipeline_depth (ABI 8): how many further calls a call's outputs must outlive - the staged form rotates four pools
+    # of temporaries (two batches overlap) and waits on the host for the pool's previous user; six calls go round it
+    assert planner._lib.emp_pipeline_depth(planner._h) == (4 if pipe == "staged" else pipe) == planner._retain
     try:
         with torch.cuda.stream(planner.torch_stream()):                       # the bench's way: no cross-stream waits
             res = [planner.plan_cycle(p, q, sp, **ins) for ins in batches]
