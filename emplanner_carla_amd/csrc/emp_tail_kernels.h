@@ -142,16 +142,14 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
             const double dx = lx[i] - lx[i - 1], dy = ly[i] - ly[i - 1];
             d = sqrt(dx * dx + dy * dy);
         }
-        double mine = 0.0;
+        // s_i = chord_i + s_{i-1}, one add per point in the reference's order.  As a lane-shift sweep (emp_qp_wave.h): every
+        // lane adds its chord to its left neighbour's CURRENT sum at every step, lanes 0..k are final after step k - three
+        // vector instructions per step where the loop over readlane'd chords took fourteen (a quarter of this kernel).
         const int cnt = min(64, P - base);
-        for (int k = 0; k < cnt; ++k) {
-            union { double f; int w[2]; } a, r;
-            a.f = d;
-            r.w[0] = __builtin_amdgcn_readlane(a.w[0], k);
-            r.w[1] = __builtin_amdgcn_readlane(a.w[1], k);
-            carry = (base + k >= 1) ? r.f + carry : 0.0;          // s = chord + previous s
-            if (k == lane) mine = carry;
-        }
+        if (lane == 0) d = (base >= 1) ? d + carry : 0.0;            // the chunk's first point continues the previous chunk
+        double mine = d;
+        for (int k = 1; k < cnt; ++k) mine = d + lane_up1(mine);     // lane 0: neighbour reads 0, d + 0.0 == d bit for bit
+        carry = __shfl(mine, cnt - 1, 64);
         if (i < P) sm[i] = mine;
     }
     __syncthreads();
