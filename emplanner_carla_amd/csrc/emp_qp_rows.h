@@ -1,21 +1,24 @@
-// emp_qp_rows.h - the path QP with EIGHT problems per wavefront (device only).
+// emp_qp_rows.h - the path QP with EIGHT (or four) problems per wavefront (device only).
 //
 // emp_qp_wave.h solves the banded range QP with one station and one unknown per lane: two 32-lane groups per wavefront,
 // and every step of the banded Cholesky / substitution sweeps is executed by all 64 lanes for the benefit of ONE row per
 // problem.  On the benchmark's path QPs (n = 21 stations: 17 unknowns, 19 stations with two range forms each) that is
-// ~2100 wave-level instructions per interior-point iteration for two problems, 44 M per 4096 scenes - a third of all the
+// ~2500 wave-level instructions per interior-point iteration for two problems, 44 M per 4096 scenes - a third of all the
 // vector instructions of a planning step, in a step that is bound by FP64 instruction issue over all its kernels together.
 //
-// Here a problem takes a group of GP = 8 lanes (half a DPP row) and every lane owns R CONSECUTIVE stations and R
-// consecutive unknowns (R = 3: up to 26 stations, R = 4: up to 34).  The station / unknown phases are the same arithmetic,
-// R times per lane; the sweeps become GP lane-steps in each of which a lane runs its R rows one after the other from its
-// left neighbour's last KD rows (KD <= R), so a sweep costs about what it cost before - for eight problems instead of two.
-// Same algorithm, stopping rule and failure handling as range_qp_solve_wave_fast (Mehrotra predictor-corrector on the
-// reduced normal equations); sums are associated differently, so results agree to round-off (QP outputs are compared
-// at 1e-6 and certified against the reference-built KKT system).
+// Here a problem takes a group of GP = 8 lanes (half a DPP row; GP = 16, a whole row, for BASELINE configs[4]'s 61
+// stations) and every lane owns R CONSECUTIVE stations and R consecutive unknowns (GP = 8: R = 3 up to 26 stations, R = 4 up
+// to 34; GP = 16, R = 4: up to 66).  The station / unknown phases are the same arithmetic, R times per lane; the sweeps become
+// ceil(N / R) lane-steps in each of which a lane runs its R rows one after the other from its left neighbour's last KD rows
+// (KD <= R), so a sweep costs about what it cost before - for eight problems instead of two.  Same algorithm, stopping rule
+// and failure handling as range_qp_solve_wave_fast (Mehrotra predictor-corrector on the reduced normal equations); sums are
+// associated differently, so results agree to round-off (2e-9 on the benchmark batch; QP outputs are compared at 1e-6 and
+// certified against the reference-built KKT system).  Measured: 15.7 M vector instructions per 4096
+// scenes.
 //
-// The eight problems of a wavefront iterate in lock step until the slowest has converged (finished groups idle through
-// the barriers): mean 10 iterations per wavefront where a pair took 8.7.
+// The problems of a wavefront iterate in lock step until the slowest has converged (finished groups idle through the
+// barriers): mean 10 iterations per wavefront of eight where a pair took 8.7.  Small batches (under 1024 scenes), which
+// cannot fill the chip and are served by latency, keep the two-per-wavefront kernel.
 #pragma once
 
 #include "emp_qp_wave.h"
@@ -278,7 +281,6 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
             out[r] = acc;
         }
     };
-    auto ux_new = [&](int r, double step) { return Q.u[base + r] + step; };
     auto bounds = [&](double (&c_it)[R][F], double (&lo_it)[R][F], double (&hi_it)[R][F]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -551,7 +553,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                             zl[r][f] += alpha * dzl[r][f];
                         }
                     }
-                    if ((mmask >> r) & 1u) Q.u[base + r] = ux_new(r, alpha * du[r]);
+                    if ((mmask >> r) & 1u) Q.u[base + r] = Q.u[base + r] + alpha * du[r];      // (u is re-read, not kept: registers)
                 }
                 ++iters;
             }

@@ -1,11 +1,12 @@
 // emp_smooth_rows.h - the smoothing QP (ref smooth_reference_line, planning_utils.py:262-361) with EIGHT problems per
 // wavefront: the x and the y problem of four polylines (device only).
 //
-// Same idea as emp_qp_rows.h: a problem takes a group of 8 lanes and every lane owns R CONSECUTIVE coordinates (R = 3: up
-// to 24 points, R = 4: up to 32), so a sweep of the pentadiagonal Cholesky factorisation / substitution serves eight
-// problems where the half-wave form of emp_qp_wave.h (box_qp_active_set_lanes<32>) serves two.  Same algorithm - the
-// primal-dual active-set iteration - and the same operation order per coordinate, so the fixed point it stops at is the
-// same KKT point.
+// Same idea as emp_qp_rows.h: a problem takes a group of GP = 8 lanes (16 for polylines of up to 64 points: four problems
+// per wavefront) and every lane owns R CONSECUTIVE coordinates (GP = 8: R = 3 up to 24 points, R = 4 up to 32), so a sweep
+// of the pentadiagonal Cholesky factorisation / substitution serves eight problems where the half-wave form of
+// emp_qp_wave.h (box_qp_active_set_lanes<32>) serves two.  Same algorithm - the primal-dual active-set iteration - and the
+// same operation order per coordinate, so the fixed point it stops at is the same KKT point: the trajectories of the
+// benchmark batch come out bit-identical.
 #pragma once
 
 #include "emp_qp_rows.h"

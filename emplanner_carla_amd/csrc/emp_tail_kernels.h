@@ -687,11 +687,8 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(EMP_CYCLE_QP_PARAMS) 
 }
 // 64 / GP scenes per wavefront on groups of GP lanes, R stations per lane (emp_qp_rows.h): a quarter (GP = 8) of the
 // wavefronts of the two-per-wavefront kernel, each as long as before.
-#ifndef EMP_QP_ROWS_ATTR
-#define EMP_QP_ROWS_ATTR
-#endif
 template <int GP, int R>
-__global__ __launch_bounds__(64) EMP_QP_ROWS_ATTR void cycle_qp_rows_kernel(EMP_CYCLE_QP_PARAMS) {
+__global__ __launch_bounds__(64) void cycle_qp_rows_kernel(EMP_CYCLE_QP_PARAMS) {
     cycle_qp_body<GP, R>(EMP_CYCLE_QP_ARGS);
 }
 #undef EMP_CYCLE_QP_PARAMS
