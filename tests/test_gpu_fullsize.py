@@ -629,3 +629,37 @@ def test_cartesian_tail_kernels_agree_on_the_benchmark_batch(tmp_path):
     assert ok.sum() > 3000
     assert np.array_equal(a["traj"], b["traj"]), "the two kernels perform the same operations: bit-identical"
     assert np.abs(a["traj"][ok] - c["traj"][ok]).max() < 1e-9
+
+
+def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner):
+    """bench.py's timed region brackets the sweep with HIP events, and in staged mode the back stage is released by the
+    event attached to the sweep's own dispatch - the TIMING event then (emp_api.hip: front_attached).  Consecutive calls on
+    DIFFERENT batches with the events on must equal the plain calls bit for bit: a back stage that started early would
+    densify another batch's predecessor table (the bench itself, planning the same batch every step, could not tell)."""
+    import torch
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    dev = torch.device("cuda:0")
+    batches = []
+    for k in range(6):
+        b = S.make_batch(range(5000 + 3000 * k, 5000 + 3000 * k + 2048), cfg)
+        batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+    torch.cuda.synchronize()
+    plain = []
+    for ins in batches:
+        r = planner.plan_cycle(p, q, sp, **ins)
+        planner.synchronize()
+        plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+    planner.set_pipeline("staged")
+    planner.set_timing(True, only="dp_sweep")
+    try:
+        for rep in range(3):
+            with torch.cuda.stream(planner.torch_stream()):
+                res = [planner.plan_cycle(p, q, sp, **ins) for ins in batches]
+            planner.synchronize()
+            for k, r in enumerate(res):
+                _assert_same(plain[k], {kk: getattr(r, kk).cpu().numpy() for kk in OUTPUTS}, f"timed staged call {k}, round {rep}")
+        assert planner.kernel_launches("dp_sweep") == 18 and planner.kernel_ms("dp_sweep") > 0
+    finally:
+        planner.set_timing(False)
+        planner.set_pipeline(False)
