@@ -775,7 +775,8 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     static const bool pair_form = [] { const char* e = getenv("EMP_PATH_QP_PAIR"); return e && e[0] == '1'; }();
     // (small batches keep the two-per-wavefront kernel: a batch that cannot fill the chip is served by latency, and an
     // interior-point iteration of that kernel is 2500 instructions against 3000, for the slower of two scenes instead of eight)
-    const bool few = B < 1024 && cap <= 34;
+    static const int few_below = [] { const char* e = getenv("EMP_PATH_QP_FEW"); return e ? atoi(e) : 1024; }();   // (tests: 0 = never)
+    const bool few = B < few_below && cap <= 34;
     if (cap <= 66 && !pair_form && !few) {                            // 8 (4) scenes per wavefront on groups of 8 (16) lanes
         const int gp = cap <= 34 ? 8 : 16;
         const size_t words = cap <= 26 ? path_qp_words_rows<8, 3>() : cap <= 34 ? path_qp_words_rows<8, 4>() : path_qp_words_rows<16, 4>();

@@ -134,3 +134,19 @@ def test_wide_lattice_edge_tensor_bit_exact_and_layout(planner, row):
     with pytest.raises(Exception):
         planner.dp_plan(dp_params_from_cfg(S.LatticeConfig("too_wide", row=257, col=3, sample_s=5.0, sample_l=0.05, sampling_res=2,
                                                            n_obs=0, n_ref=30)), b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+
+
+def test_eight_per_wavefront_path_qp_on_the_small_batches_of_this_file():
+    """Batches under 1024 scenes take the two-scenes-per-wavefront path QP (latency), so the tests above - 5 to 24 scenes per
+    lattice shape - no longer reach the eight-per-wavefront kernel with its R = 3 and R = 4 instantiations and ragged last
+    wavefronts.  EMP_PATH_QP_FEW=0 lifts the rule: the cycle tests of this file and the golden cycle tests run again in a
+    child process with it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(root, "tests", "test_gpu_fuzz.py"), os.path.join(root, "tests", "test_gpu_cycle.py"),
+                          "-k", "(cycle_vs_port or full_cycle or paired_path_qp or size_limits) and not eight_per_wavefront"],
+                         cwd=root, env=dict(os.environ, EMP_PATH_QP_FEW="0"), capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]
+    assert " passed" in run.stdout
