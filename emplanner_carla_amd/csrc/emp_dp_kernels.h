@@ -73,14 +73,20 @@ __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __r
     if (threadIdx.x == 0) sample_moments(P.sample_s, &tab[kTableFields * rr + kSamples], &tab[kTableFields * rr + kSamples + 1]);
 }
 
-// kSoftGain / d2 for 16 < d2 < 36: the instruction sequence the compiler emits for an IEEE binary64 division
-// (reciprocal seed, Newton steps, quotient, residual, final fma) without its range scaling and special-case fix-up,
-// which do nothing for operands of this size.  EMP_SOFT_NEWTON_STEPS = 2 is the compiler's sequence (the same bits in 8
-// instead of 12 instructions, eight times per obstacle scan); 1 (round 3 experiment, profiles/r03_edge/README.md) drops a
-// step: the seed's 2^-24 or better becomes 2^-48, the residual 5000 - d2 q is exact (fma) and the correction is wrong by
-// q 2^-96 at most, so the final fma misrounds one quotient in 2^43.
+// kSoftGain / d2 for 16 < d2 < 36, correctly rounded: the instruction sequence the compiler emits for an IEEE binary64
+// division (reciprocal seed, Newton steps, quotient, residual, final fma) without its range scaling and special-case fix-up,
+// which do nothing for operands of this size, and (round 3) with ONE Newton step instead of two: six instructions instead
+// of twelve, eight to nine times per obstacle scan.  One step takes the seed (2^-24 or better) to 2^-48 or better; the
+// quotient q = 5000 r then carries that error, the residual 5000 - d2 q is exact (fma), and the correction r (5000 - d2 q)
+// is wrong by q 2^-96 at most - so the final fma rounds to the neighbour of the true quotient only if that lies within
+// 2^-96 q of a rounding boundary: one operand in 2^43.  tools/soft_quotient_test.hip: 8.6e9 operands of the interval, an
+// even sweep and a hashed one, every quotient equal to the compiler's IEEE division bit for bit; every edge tensor of the
+// suite and the rows of a 262144-scene DP sweep (profiles/r03_final_parity_sweep_dp_262144.json) equal the oracle's.
+// EMP_SOFT_NEWTON_STEPS=2 restores the compiler's sequence.  With the shorter block the compiler would drop the wave-level
+// skip branch around it (its threshold is twelve instructions) and execute all ten divisions of a scan under masks - 8 %
+// slower than the long form; obstacle_scan_dense keeps the branch with an empty volatile asm.
 #ifndef EMP_SOFT_NEWTON_STEPS
-#define EMP_SOFT_NEWTON_STEPS 2
+#define EMP_SOFT_NEWTON_STEPS 1
 #endif
 __device__ __forceinline__ double soft_cost_quotient(double d2) {
     double r = __builtin_amdgcn_rcp(d2);
@@ -113,7 +119,12 @@ __device__ __forceinline__ double obstacle_scan_dense(double s0, const double* t
     for (int n = 0; n < kSamples; ++n) {
         const bool near = alive & (d2[n] < kSafe2);
         const bool hard = near & (d2[n] <= kDanger2);
-        if (near & !hard) c = c + soft_cost_quotient(d2[n]);
+        if (near & !hard) {
+#if EMP_SOFT_NEWTON_STEPS == 1
+            asm volatile("");          // keeps the wave-level skip branch around the (now short) division block
+#endif
+            c = c + soft_cost_quotient(d2[n]);
+        }
         alive = alive & !hard;
     }
     if (!alive) c = c + w_coll;

@@ -1,0 +1,48 @@
+// The edge-cost kernel's 5000 / d2 (emp_dp_kernels.h: soft_cost_quotient, one Newton step) against the compiler's IEEE binary64
+// division on 2^33 operands of the range it is used on, 16 < d2 < 36: an even sweep of the interval and a hashed one (all
+// mantissa bits in play).  Prints the number of results that differ in any bit; 0 expected.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I emplanner_carla_amd/csrc tools/soft_quotient_test.hip -o /tmp/sq && /tmp/sq
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "emp_dp_kernels.h"
+
+__global__ void check(unsigned long long per_thread, unsigned long long* bad, double* worst) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long total = (unsigned long long)gridDim.x * blockDim.x * per_thread;
+    unsigned long long mine = 0;
+    for (unsigned long long k = 0; k < per_thread; ++k) {
+        const unsigned long long i = tid * per_thread + k;
+        // even sweep
+        double d2 = 16.0 + ((double)i + 0.5) * (20.0 / (double)total);
+        // hashed: splitmix64 bits into the mantissa of a value in [16, 32) or [32, 36)
+        unsigned long long z = i + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        double h = __longlong_as_double(0x4030000000000000ull | (z & 0x000FFFFFFFFFFFFFull));   // [16, 32)
+        if ((z >> 60) == 0) h = 32.0 + (h - 16.0) * 0.25;                                         // some in [32, 36)
+        for (int v = 0; v < 2; ++v) {
+            const double x = v ? h : d2;
+            if (!(x > 16.0 && x < 36.0)) continue;
+            const double a = emp::soft_cost_quotient(x), b = 5000.0 / x;
+            if (__double_as_longlong(a) != __double_as_longlong(b)) ++mine;
+        }
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+int main() {
+    unsigned long long* bad;
+    double* worst;
+    hipMalloc(&bad, 8);
+    hipMalloc(&worst, 8);
+    hipMemset(bad, 0, 8);
+    const unsigned long long per_thread = 1ull << 12;
+    hipLaunchKernelGGL(check, dim3(1 << 12), dim3(256), 0, 0, per_thread, bad, worst);
+    unsigned long long h = ~0ull;
+    hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
+    printf("operands checked: %llu, results differing from IEEE division: %llu\n", 2ull * (1ull << 12) * 256 * per_thread, h);
+    return h != 0;
+}
