@@ -64,7 +64,46 @@ __device__ __forceinline__ void prefix_min_first(double& d, int& li) {
     prefix_min_step<0x143, 0xC>(d, li);   // row_bcast:31 -> rows 2, 3
 }
 
+// One step of a value-only inclusive prefix minimum (lanes without a source, or outside the row mask, see +inf)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double prefix_fmin_step(double v) {
+    union { double f; int w[2]; } a, r, inf;
+    a.f = v;
+    inf.f = __builtin_inf();
+    r.w[0] = __builtin_amdgcn_update_dpp(inf.w[0], a.w[0], CTRL, ROW_MASK, 0xF, false);
+    r.w[1] = __builtin_amdgcn_update_dpp(inf.w[1], a.w[1], CTRL, ROW_MASK, 0xF, false);
+    return __builtin_fmin(v, r.f);
+}
+
+// The scan for lines of at most 64 nodes (one node per lane; the cycle's 51- and 61-node lines), without carrying the index
+// through the prefix: with pm_i = min(d_0..d_i), the first occurrence L_i of pm_i satisfies i - L_i >= limit exactly when
+// pm_i == pm_{i-limit} (no strict improvement among the last `limit` nodes), so the stopping node i* is the first lane where
+// that holds and the answer is the first lane j <= i* with d_j == pm_{i*} - or, if the scan never stops, the first lane that
+// attains the overall minimum.  Half the instructions of the indexed prefix (round 3).
+__device__ inline int match_scan_wave64(const double* lx, const double* ly, int P, double x, double y, int limit) {
+    const int lane = threadIdx.x & 63;
+    double d = __builtin_inf();
+    if (lane < P) {
+        const double dx = lx[lane] - x, dy = ly[lane] - y;
+        d = sqrt(dx * dx + dy * dy);
+    }
+    double pm = d;
+    pm = prefix_fmin_step<0x111, 0xF>(pm);   // row_shr:1
+    pm = prefix_fmin_step<0x112, 0xF>(pm);   // row_shr:2
+    pm = prefix_fmin_step<0x114, 0xF>(pm);   // row_shr:4
+    pm = prefix_fmin_step<0x118, 0xF>(pm);   // row_shr:8
+    pm = prefix_fmin_step<0x142, 0xA>(pm);   // row_bcast:15 -> rows 1, 3
+    pm = prefix_fmin_step<0x143, 0xC>(pm);   // row_bcast:31 -> rows 2, 3
+    const double back = __shfl(pm, lane >= limit ? lane - limit : 0, 64);
+    const unsigned long long stop = __ballot(lane < P && lane >= limit && pm == back);
+    const int last = stop ? __builtin_ffsll((long long)stop) - 1 : P - 1;          // the node at which the scan ends
+    const double target = __shfl(pm, last, 64);
+    const unsigned long long hit = __ballot(lane <= last && d == target);
+    return hit ? __builtin_ffsll((long long)hit) - 1 : 0;                           // (no finite distance at all: node 0)
+}
+
 __device__ inline int match_scan_wave(const double* lx, const double* ly, int P, double x, double y, int limit) {
+    if (P <= 64 && limit >= 1) return match_scan_wave64(lx, ly, P, x, y, limit);   // uniform
     const int lane = threadIdx.x & 63;
     double cd = __builtin_inf();     // carry: prefix minimum and its first index over the previous chunks
     int ci = 0;
