@@ -740,7 +740,7 @@ static int dev_project(emp_ctx* ctx, int B, int max_ref, int max_obs, const doub
                        double* begin_sl, double* start, int obs_cap = -1, const double* dyn = nullptr,
                        int* n_obs_out = nullptr) {
     if (B == 0) return EMP_OK;
-    const size_t lds = (size_t)5 * max_ref * sizeof(double);
+    const size_t lds = (size_t)7 * max_ref * sizeof(double);
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "reference line too long for the LDS-resident projection kernel");
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)frenet_project_wave_kernel,

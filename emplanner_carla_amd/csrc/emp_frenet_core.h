@@ -49,6 +49,15 @@ EMP_HD Node project_on(const Node& m, double x, double y) {
     return Node{m.x + ds * c, m.y + ds * s, m.theta + m.kappa * ds, m.kappa};
 }
 
+// the same with cos / sin of the node's heading supplied (the projection kernel evaluates them once per node and scene)
+EMP_HD Node project_on_cs(const Node& m, double c, double s, double x, double y) {
+    const double ds = dot2(x - m.x, y - m.y, c, s);
+    return Node{m.x + ds * c, m.y + ds * s, m.theta + m.kappa * ds, m.kappa};
+}
+EMP_HD double projection_s_cs(const Node& m, double c, double s, double s_at_m, double x, double y) {
+    return s_at_m + dot2(x - m.x, y - m.y, c, s);
+}
+
 // ref: cal_projection_s_fun, planning_utils.py:439-443
 EMP_HD double projection_s(const Node& m, double s_at_m, double x, double y) {
     return s_at_m + dot2(x - m.x, y - m.y, cos(m.theta), sin(m.theta));

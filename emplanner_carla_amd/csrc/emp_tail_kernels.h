@@ -132,7 +132,7 @@ __device__ inline int match_scan_wave(const double* lx, const double* ly, int P,
     return ci;
 }
 
-// dynamic LDS (doubles): 5 * max_ref
+// dynamic LDS (doubles): 7 * max_ref
 __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     int B, int max_ref, int max_obs, const double* __restrict__ ref_line, const int* __restrict__ n_ref,
     const double* __restrict__ origin_xy, const double* __restrict__ start_xy, const double* __restrict__ start_v,
@@ -149,7 +149,9 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     double* lth = ly + max_ref;
     double* lk = lth + max_ref;
     double* sm = lk + max_ref;
-    const double* line = ref_line + (size_t)b * max_ref * 4;
+    double* lcos = sm + max_ref;                        // cos / sin of every node's heading: each node one lane, once per
+    double* lsin = lcos + max_ref;                      // scene - the ten projections below read them instead of calling
+    const double* line = ref_line + (size_t)b * max_ref * 4;   // cos / sin again (half of this kernel's instructions were those calls)
     const int P = min(max(n_ref[b], 0), max_ref);       // clamped to the row's capacity
     // Every coordinate the ten match scans below start from is fetched HERE, next to the reference line: one round trip
     // to memory for the whole kernel.  Loaded where they are used - one obstacle per scan, each scan behind the previous
@@ -165,8 +167,11 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     for (int i = lane; i < P; i += 64) {
         lx[i] = line[4 * i];
         ly[i] = line[4 * i + 1];
-        lth[i] = line[4 * i + 2];
+        const double th = line[4 * i + 2];
+        lth[i] = th;
         lk[i] = line[4 * i + 3];
+        lcos[i] = cos(th);
+        lsin[i] = sin(th);
     }
     __syncthreads();
     // cumulative chord length (ref planning_utils.py:461-466).  The chords are computed one per lane, but the
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
     auto node = [&](int i) { return Node{lx[i], ly[i], lth[i], lk[i]}; };
     // origin of the s axis (ref :457-471)
     const int m0 = match_scan_wave(lx, ly, P, ox, oy, 50);
-    const double s0 = projection_s(node(m0), sm[m0], ox, oy);
+    const double s0 = projection_s_cs(node(m0), lcos[m0], lsin[m0], sm[m0], ox, oy);
     __syncthreads();
     for (int i = lane; i < P; i += 64) {
         const double v = sm[i] - s0;
@@ -218,16 +223,16 @@ __global__ __launch_bounds__(64) void frenet_project_wave_kernel(
         if ((j & 63) == 63 || j == k - 1) {                 // flush a full set of lanes
             const int jj = (j & ~63) + lane;
             if (jj <= j) {
-                obs_s[(size_t)b * obs_cap + jj] = projection_s(node(my_match), sm[my_match], obx, oby);
-                obs_l[(size_t)b * obs_cap + jj] = lateral_offset(project_on(node(first_match), obx, oby), obx, oby);
+                obs_s[(size_t)b * obs_cap + jj] = projection_s_cs(node(my_match), lcos[my_match], lsin[my_match], sm[my_match], obx, oby);
+                obs_l[(size_t)b * obs_cap + jj] = lateral_offset(project_on_cs(node(first_match), lcos[first_match], lsin[first_match], obx, oby), obx, oby);
             }
         }
     }
     // planning start (ref test_9.py:134 and :172-177)
     const int ms = match_scan_wave(lx, ly, P, px, py, 50);
     if (lane == 0) {
-        const Node proj = project_on(node(ms), px, py);
-        const double bs = projection_s(node(ms), sm[ms], px, py);
+        const Node proj = project_on_cs(node(ms), lcos[ms], lsin[ms], px, py);
+        const double bs = projection_s_cs(node(ms), lcos[ms], lsin[ms], sm[ms], px, py);
         if (begin_sl) {
             begin_sl[2 * b] = bs;
             begin_sl[2 * b + 1] = lateral_offset(proj, px, py);
