@@ -229,3 +229,21 @@ def test_fused_cycle_equals_two_kernel_cycle(planner):
     r1 = planner.plan_cycle(_params(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), mode=1, **kw)
     for f in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status"):
         assert np.array_equal(getattr(r0, f), getattr(r1, f), equal_nan=True), f
+
+
+def test_soft_cost_quotient_is_ieee_division_on_its_whole_range(tmp_path):
+    """The edge kernel computes 5000 / d2 (16 < d2 < 36) with ONE Newton step and no range fix-up (emp_dp_kernels.h
+    soft_cost_quotient).  tools/soft_quotient_test.hip compares it with the compiler's IEEE division on 8.6e9 operands of the
+    interval, an even sweep and a hashed one: every quotient must be equal bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "soft_quotient_test")
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                            "-I", os.path.join(root, "emplanner_carla_amd", "csrc"),
+                            os.path.join(root, "tools", "soft_quotient_test.hip"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "differing from IEEE division: 0" in run.stdout, run.stdout + run.stderr
