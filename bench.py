@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--records", choices=["full", "trajectory"], default="full",
                     help="what a record carries: everything a cycle returns (179 doubles per scene at 40x9) or status + "
                          "trajectory only (94)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="emp_set_option before the pipeline is set up (include/emplanner.h emp_option; names: "
+                         "emplanner_carla_amd._lib.OPTIONS), e.g. --opt sweep_exclusive=1 --opt back_stream_cus=128; repeatable")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -285,6 +288,11 @@ def main():
     if args.pipeline == "auto":
         args.pipeline = "staged"      # (cfg5 until round 3: 2 lanes - the same 6.4 ms per step now, with the sweep at 0.39 instead of 0.71)
     pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
+    options = {}
+    for kv in args.opt:
+        name, val = kv.split("=")
+        pl.set_option(name, int(val))
+        options[name] = int(val)
     pl.set_pipeline(pmode)
     pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()

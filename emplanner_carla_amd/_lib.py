@@ -39,6 +39,10 @@ EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1
 EMP_DP_FUSED, EMP_DP_TWO_KERNEL = 0, 1
 EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 
+# emp_option (include/emplanner.h): per-context tuning / A-B / test-hook values - the library reads no environment variable
+OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
+           "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9}
+
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2
 ST_BOUND_INDEX = 4
@@ -118,6 +122,9 @@ PROTOTYPES = {
     "emp_result_stream": (_vp, [_vp]),
     "emp_pipeline_depth": (C.c_int, [_vp]),
     "emp_set_fence": (C.c_int, [_vp, C.c_int]),
+    "emp_set_option": (C.c_int, [_vp, _i32, _i32]),
+    "emp_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
+    "emp_sweep_clock_mhz": (_f64, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
@@ -191,7 +198,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 8:
+    if lib.emp_abi_version() != 9:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

@@ -319,6 +319,27 @@ class Planner:
         overlap them (``False``: only for work that does not read a cycle's outputs)."""
         self._check(self._lib.emp_set_fence(self._h, 1 if enabled else 0))
 
+    def set_option(self, name, value: int):
+        """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` ("path_qp_form",
+        "cartesian_form", "smooth_force_fallback", "edge_block", "sweep_variant", "fused_columns", "st_order",
+        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe") or the option's number.  Takes effect at the next call
+        ("back_stream_cus": at the next ``set_pipeline``).  The library reads no environment variable."""
+        key = L.OPTIONS[name] if isinstance(name, str) else int(name)
+        self._check(self._lib.emp_set_option(self._h, key, int(value)))
+
+    def get_option(self, name) -> int:
+        key = L.OPTIONS[name] if isinstance(name, str) else int(name)
+        v = C.c_int32(0)
+        self._check(self._lib.emp_get_option(self._h, key, C.byref(v)))
+        return int(v.value)
+
+    def sweep_clock(self):
+        """With option "sweep_clock_probe" on: (shader clock in MHz, mean and longest wavefront residence in us) of the
+        latest sweep launch, or None when nothing was recorded."""
+        mean_us, max_us = C.c_double(0.0), C.c_double(0.0)
+        mhz = float(self._lib.emp_sweep_clock_mhz(self._h, C.byref(mean_us), C.byref(max_us)))
+        return None if mhz < 0 else (mhz, float(mean_us.value), float(max_us.value))
+
     def torch_result_stream(self):
         """The stream on which the latest cycle's outputs become complete (its lane in pipelined mode)."""
         if not self.pipelined:

@@ -90,8 +90,8 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // moment: beside the previous batch's path-QP wavefronts (staged pipeline) a two-wavefront block of the 40 x 9 lattice
     // (12 KB of LDS: 13 blocks per CU) finds room where a four-wavefront block does not (step 0.322 -> 0.289 ms), while the
     // 120 x 21 lattice's 60 KB table allows two blocks per CU, which therefore carry ten wavefronts each.
-    // EMP_EDGE_BLOCK (development) overrides it.
-    static const int eb_env = [] { const char* e = getenv("EMP_EDGE_BLOCK"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 0; }();
+    // EMP_OPT_EDGE_BLOCK (emp_set_option) overrides it.
+    const int eb_env = ctx->opt[EMP_OPT_EDGE_BLOCK];
     int wpb = 4;
     {
         const int blocks_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
@@ -141,26 +141,43 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
     }
-    static const int variant = getenv("EMP_SWEEP_VARIANT") ? atoi(getenv("EMP_SWEEP_VARIANT")) : 0;
+    const int variant = ctx->opt[EMP_OPT_SWEEP_VARIANT];
+    // EMP_OPT_SWEEP_EXCLUSIVE (staged pipeline): the sweep starts once the previous call's back stage is done
+    if (ctx->sweep_wait) {
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sweep_wait, 0));
+        ctx->sweep_wait = nullptr;
+    }
+    // EMP_OPT_SWEEP_CLOCK_PROBE: four ticks per wavefront (emp_dp_kernels.h), read by emp_sweep_clock_mhz
+    unsigned long long* probe = nullptr;
+    if (ctx->opt[EMP_OPT_SWEEP_CLOCK_PROBE]) {
+        if (ctx->clock_probe_tiles != d.tiles) ctx->probe_launches = 0;       // another batch size: the ring starts over
+        const int grc = grow_buffer(ctx, ctx->clock_probe, (size_t)emp_ctx::kProbeSlots * d.tiles * 4 * sizeof(unsigned long long));
+        if (grc) return grc;
+        probe = (unsigned long long*)ctx->clock_probe.p + (size_t)(ctx->probe_launches % emp_ctx::kProbeSlots) * d.tiles * 4;
+        ctx->clock_probe_tiles = d.tiles;
+        ctx->probe_launches++;
+    }
     KernelTimer t(ctx, "dp_sweep", true);   // the roofline kernel: events stamped by the dispatch itself
 #define EMP_SWEEP(R, PD, WPB) EMP_SWEEP_NT(R, PD, WPB, false)
 #define EMP_SWEEP_NT(R, PD, WPB, NT)                                                                        \
     do {                                                                                                    \
         const size_t lds = (size_t)(WPB) * (d.col * 64 + 64 * sizeof(double));                              \
         EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the predecessor table in LDS");           \
+        const bool defer = (R) > 0 && ctx->bt_pre && ctx->bt_term;                                          \
         if (lds > 48 * 1024)                                                                                \
-            EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_sweep_kernel<R, PD, WPB, NT>,                      \
+            EMP_HIP(ctx, hipFuncSetAttribute(defer ? (const void*)dp_sweep_kernel<R, PD, WPB, NT, false>    \
+                                                   : (const void*)dp_sweep_kernel<R, PD, WPB, NT, true>,    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
         hipEvent_t stop_ev = t.stop ? t.stop : ctx->front_stop;                                             \
-        if ((R) > 0 && ctx->bt_pre && ctx->bt_term) {                                                       \
+        if (defer) {                                                                                        \
             hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT, false>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
                                   ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status, \
-                                  ctx->bt_pre, ctx->bt_term);                                               \
+                                  ctx->bt_pre, ctx->bt_term, probe);                                        \
             ctx->bt_deferred = true;                                                                        \
         } else {                                                                                            \
             hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
                                   ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status, \
-                                  (unsigned char*)nullptr, (int*)nullptr);                                  \
+                                  (unsigned char*)nullptr, (int*)nullptr, probe);                           \
         }                                                                                                   \
         ctx->front_attached = stop_ev;                                                                      \
     } while (0)
@@ -196,6 +213,10 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
 #undef EMP_SWEEP
 #undef EMP_SWEEP_NT
     EMP_LAUNCH_CHECK(ctx);
+    if (probe) {
+        if (!ctx->clock_probe_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->clock_probe_done, hipEventDisableTiming));
+        EMP_HIP(ctx, hipEventRecord(ctx->clock_probe_done, ctx->stream));
+    }
     return EMP_OK;
 }
 
@@ -204,8 +225,11 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
                          const unsigned char* pre = nullptr, const int* term = nullptr, const int* n_obs = nullptr,
                          double* rows_out = nullptr) {
     if (d.B == 0) return EMP_OK;
-    KernelTimer t(ctx, "dp_enrich");
     const size_t lds = pre ? (size_t)d.col * sizeof(double) + (size_t)d.col * d.row : 0;
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the densification kernel's predecessor table in LDS");
+    if (lds > 48 * 1024)
+        EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_enrich_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KernelTimer t(ctx, "dp_enrich");
     hipLaunchKernelGGL(dp_enrich_wave_kernel, dim3(d.B), dim3(64), lds, ctx->stream, d, rows, start, max_pts, path_s, path_l,
                        path_len, status, or_status, pre, term, n_obs, rows_out);
     EMP_LAUNCH_CHECK(ctx);
@@ -235,7 +259,7 @@ static int dev_dp_fused(emp_ctx* ctx, const DpDev& d, const double* obs_s, const
     if (rc) return rc;
     // columns per chunk: 4 (one per wavefront) while two buffers of them leave room for three blocks per CU, fewer on wide
     // lattices whose pair table fills the LDS
-    static const int nc_env = getenv("EMP_FUSED_NC") ? atoi(getenv("EMP_FUSED_NC")) : 0;   // development
+    const int nc_env = ctx->opt[EMP_OPT_FUSED_COLUMNS];                                   // emp_set_option
     int nc = nc_env > 0 ? nc_env : 4;
     while (nc > 1 && fused_lds(d.row, d.col, d.S, d.max_obs, nc).total > 53 * 1024 && nc_env <= 0) nc /= 2;
     const size_t lds = (size_t)fused_lds(d.row, d.col, d.S, d.max_obs, nc).total;
@@ -367,6 +391,8 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
+    if (ctx->clock_probe.p) (void)hipFree(ctx->clock_probe.p);
+    if (ctx->clock_probe_done) (void)hipEventDestroy(ctx->clock_probe_done);
     for (auto& kv : ctx->pair_tables)
         if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
     for (auto& kv : ctx->named)
@@ -513,13 +539,29 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         if (!ln.ev_tail) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
         if (!ln.ev_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
     }
+    const int want_cus = ctx->opt[EMP_OPT_BACK_STREAM_CUS] > 0 && ctx->opt[EMP_OPT_BACK_STREAM_CUS] < ctx->cu_count
+                             ? ctx->opt[EMP_OPT_BACK_STREAM_CUS] : 0;
+    if (m == EMP_PIPELINE_STAGED && ctx->back_stream && ctx->back_stream_cus != want_cus) {   // the option changed: new stream
+        EMP_HIP(ctx, hipStreamDestroy(ctx->back_stream));
+        ctx->back_stream = nullptr;
+    }
     if (m == EMP_PIPELINE_STAGED && !ctx->back_stream) {
-        // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
-        // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
-        // stage's bulk work they overlap with
-        int prio_low = 0, prio_high = 0;
-        EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->back_stream, hipStreamNonBlocking, prio_high));
+        if (want_cus > 0) {
+            // EMP_OPT_BACK_STREAM_CUS: the back stage confined to `want_cus` compute units.  The driver deals the mask's
+            // bits out to the XCDs round robin and to the shader engines within an XCD, so the lowest n bits are n CUs
+            // spread evenly over the chip.  (A masked stream has the default queue priority.)
+            uint32_t mask[16] = {0};
+            for (int i = 0; i < want_cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+            EMP_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->back_stream, (uint32_t)((ctx->cu_count + 31) / 32), mask));
+        } else {
+            // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
+            // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
+            // stage's bulk work they overlap with
+            int prio_low = 0, prio_high = 0;
+            EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->back_stream, hipStreamNonBlocking, prio_high));
+        }
+        ctx->back_stream_cus = want_cus;
     }
     for (auto& ln : ctx->lanes) ln.done_valid = false;       // everything was drained above
     ctx->pipe_mode = m;
@@ -536,6 +578,56 @@ int emp_set_fence(emp_ctx* ctx, int enabled) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     ctx->fence = enabled != 0;
     return EMP_OK;
+}
+
+int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, option >= 0 && option < EMP_OPT_COUNT, "unknown option");
+    bool ok = false;
+    switch (option) {
+        case EMP_OPT_PATH_QP_FORM:
+        case EMP_OPT_CARTESIAN_FORM:
+        case EMP_OPT_SMOOTH_FORCE_FALLBACK:
+        case EMP_OPT_ST_ORDER:
+        case EMP_OPT_SWEEP_EXCLUSIVE:
+        case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
+        case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
+        case EMP_OPT_SWEEP_VARIANT: ok = value >= 0 && value <= 5; break;
+        case EMP_OPT_FUSED_COLUMNS: ok = value >= 0 && value <= 64; break;
+        case EMP_OPT_BACK_STREAM_CUS: ok = value >= 0 && value <= 512; break;
+    }
+    EMP_REQUIRE(ctx, ok, "option value out of range (include/emplanner.h, emp_option)");
+    ctx->opt[option] = value;
+    if (option == EMP_OPT_SWEEP_CLOCK_PROBE) ctx->probe_launches = 0;      // the statistics start over
+    return EMP_OK;
+}
+
+int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, option >= 0 && option < EMP_OPT_COUNT && value, "unknown option or NULL value");
+    *value = ctx->opt[option];
+    return EMP_OK;
+}
+
+double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_us) {
+    if (!ctx || !ctx->clock_probe.p || !ctx->clock_probe_done || ctx->clock_probe_tiles <= 0 || ctx->probe_launches <= 0) return -1.0;
+    if (hipEventSynchronize(ctx->clock_probe_done) != hipSuccess) return -1.0;
+    const long slots = ctx->probe_launches < emp_ctx::kProbeSlots ? ctx->probe_launches : emp_ctx::kProbeSlots;
+    const size_t waves = (size_t)slots * ctx->clock_probe_tiles;
+    std::vector<unsigned long long> h(waves * 4);
+    if (hipMemcpy(h.data(), ctx->clock_probe.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1.0;
+    double ticks_c = 0.0, ticks_r = 0.0, longest = 0.0;
+    for (size_t t = 0; t < waves; ++t) {
+        const double dc = (double)(h[4 * t + 1] - h[4 * t + 0]), dr = (double)(h[4 * t + 3] - h[4 * t + 2]);
+        ticks_c += dc;
+        ticks_r += dr;
+        if (dr > longest) longest = dr;
+    }
+    if (ticks_r <= 0.0) return -1.0;
+    if (mean_wave_us) *mean_wave_us = ticks_r / (double)waves / 100.0;      // 100 MHz reference
+    if (max_wave_us) *max_wave_us = longest / 100.0;
+    return ticks_c / ticks_r * 100.0;
 }
 
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
@@ -720,6 +812,11 @@ int emp_dp_enrich(emp_ctx* ctx, const emp_dp_params* p, int32_t B, const double*
 // =============================================================================================
 namespace emp {
 
+// emp_qp_params.reserved: 0 in every build that ships.  A development build (-DEMP_DEV_HOOKS) reads it as the QP kernels'
+// debug stage (cut the solve short / cap its iterations for timing experiments, tools/qp_sensitivity_probe.py); a product
+// build refuses it, so that an uninitialised struct can never mask a failed solve.
+static bool qp_reserved_ok(const emp_qp_params* q) { return EMP_DEV_HOOKS || q->reserved == 0; }
+
 static QpDev make_qp_dev(const emp_qp_params* q) {
     QpDev d;
     d.qp = PathQpParams{q->ds, q->w_l, q->w_ddl, q->w_dddl, q->w_centre, q->host_d1, q->host_d2, q->host_w};
@@ -728,7 +825,7 @@ static QpDev make_qp_dev(const emp_qp_params* q) {
     d.decimate = q->decimate > 0 ? q->decimate : 1;
     d.midpoint = q->midpoint;
     d.use_qp = q->use_qp;
-    d.debug_stage = q->reserved;
+    d.debug_stage = EMP_DEV_HOOKS ? q->reserved : 0;
     return d;
 }
 
@@ -770,14 +867,14 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     const size_t per_group = ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words(cap)) * sizeof(double);
     int rc;
     KernelTimer t(ctx, "path_qp");
-    // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations, four up to 66; EMP_PATH_QP_PAIR=1 (development, A/B runs)
-    // keeps the kernels of rounds 1-2 (two scenes per wavefront up to 34 stations, one beyond).
-    static const bool pair_form = [] { const char* e = getenv("EMP_PATH_QP_PAIR"); return e && e[0] == '1'; }();
-    // (small batches keep the two-per-wavefront kernel: a batch that cannot fill the chip is served by latency, and an
-    // interior-point iteration of that kernel is 2500 instructions against 3000, for the slower of two scenes instead of eight)
-    static const int few_below = [] { const char* e = getenv("EMP_PATH_QP_FEW"); return e ? atoi(e) : 1024; }();   // (tests: 0 = never)
-    const bool few = B < few_below && cap <= 34;
-    if (cap <= 66 && !pair_form && !few) {                            // 8 (4) scenes per wavefront on groups of 8 (16) lanes
+    // Eight scenes per wavefront (emp_qp_rows.h) up to 34 stations, four up to 66.  EMP_OPT_PATH_QP_FORM = 1 (emp_set_option)
+    // selects the kernels of rounds 1-2 (two scenes per wavefront up to 34 stations, one beyond): an interior-point iteration
+    // of that kernel is 2500 instructions against 3000, for the slower of two scenes instead of eight - the form for a caller
+    // who plans a handful of scenes and counts microseconds.  The two associate their sums differently (~2e-9) and only the
+    // rows solver restores its last acceptable iterate on a fallback exit, so the choice is the CALLER's and never follows
+    // the batch size (round 3 switched below 1024 scenes: a 512-scene shard then differed from its slice of a 4096-scene call).
+    const bool pair_form = ctx->opt[EMP_OPT_PATH_QP_FORM] == 1;
+    if (cap <= 66 && !pair_form) {                                    // 8 (4) scenes per wavefront on groups of 8 (16) lanes
         const int gp = cap <= 34 ? 8 : 16;
         const size_t words = cap <= 26 ? path_qp_words_rows<8, 3>() : cap <= 34 ? path_qp_words_rows<8, 4>() : path_qp_words_rows<16, 4>();
         const size_t per_wave = (size_t)(64 / gp) * ((size_t)5 * cap + 4 * (size_t)max_obs + words) * sizeof(double);
@@ -811,8 +908,8 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
     const int cap = path_cap + 1;                                        // trajectory = planning start + path points
     const size_t lds = ((size_t)max_ref + 3 * (size_t)cap + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
     // Four scenes per wavefront up to 32 trajectory points, two up to 64 (emp_tail_kernels.h, cycle_cartesian_rows_kernel);
-    // EMP_CARTESIAN_WAVE=1 (development, A/B runs) keeps the one-scene-per-wavefront kernels of rounds 1-2.
-    static const bool wave_form = [] { const char* e = getenv("EMP_CARTESIAN_WAVE"); return e && e[0] == '1'; }();
+    // EMP_OPT_CARTESIAN_FORM = 1 (A/B runs) keeps the one-scene-per-wavefront kernels of rounds 1-2 (bit-identical results).
+    const bool wave_form = ctx->opt[EMP_OPT_CARTESIAN_FORM] == 1;
     if (cap <= 64 && !wave_form) {
         const int spw = cap <= 32 ? 4 : 2;
         const size_t lds4 = ((size_t)spw * ((size_t)max_ref + 5 * (size_t)cap) + 2 * (size_t)BoxRangeQp::words(cap, cap)) * sizeof(double);
@@ -820,7 +917,7 @@ static int dev_cycle_cartesian(emp_ctx* ctx, int B, int max_ref, int max_pts, in
         int rc4 = set_lds(ctx, k4, lds4);
         if (rc4) return rc4;
         KernelTimer t4(ctx, "to_cartesian");
-        static const int force_fb = [] { const char* e = getenv("EMP_SMOOTH_FORCE_FALLBACK"); return (e && e[0] == '1') ? 1 : 0; }();   // tests
+        const int force_fb = ctx->opt[EMP_OPT_SMOOTH_FORCE_FALLBACK] ? 1 : 0;                        // test hook
         hipLaunchKernelGGL(k4, dim3((B + spw - 1) / spw), dim3(64), lds4, ctx->stream, B, max_ref, max_pts, cap, sx, sy, ref_line, s_map,
                            n_ref, begin_sl, path_s, path_l, path_len, traj, traj_len, status, force_fb);
         EMP_LAUNCH_CHECK(ctx);
@@ -975,6 +1072,7 @@ int emp_path_qp(emp_ctx* ctx, const emp_qp_params* q, int32_t B, int32_t max_pts
                 double* qp_ddl, int32_t* iters, int32_t* status, emp_mem where) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_REQUIRE(ctx, q && B >= 0 && max_pts >= 1 && max_pts <= 256, "bad sizes (max_pts must be in [1, 256])");
+    EMP_REQUIRE(ctx, qp_reserved_ok(q), "emp_qp_params.reserved must be 0 (start from emp_qp_params_default)");
     EMP_REQUIRE(ctx, l_min && l_max && n_pts && start_l3 && qp_l && qp_dl && qp_ddl && status, "NULL argument");
     EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
@@ -1114,6 +1212,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
                    emp_mem where) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
     EMP_REQUIRE(ctx, p && q && sp && io, "NULL parameter struct");
+    EMP_REQUIRE(ctx, qp_reserved_ok(q), "emp_qp_params.reserved must be 0 (start from emp_qp_params_default)");
     // with a dynamic obstacle per scene (test_9.py:137-169) up to three virtual obstacles join the projected ones
     const bool has_dyn = io->dyn_dis_speed != nullptr;
     const int obs_cap = max_obs + (has_dyn ? 3 : 0);
@@ -1231,11 +1330,17 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     }
     ctx->front_stop = staged ? lane.ln->ev_front : nullptr;
     ctx->front_attached = nullptr;
+    ctx->sweep_wait = nullptr;
+    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE]) {       // the previous call's back stage: its lane is the one before ours
+        emp_ctx::Lane& prev = ctx->lanes[(ctx->lane + ctx->lanes_in_use() - 1) % ctx->lanes_in_use()];
+        if (prev.done_valid) ctx->sweep_wait = prev.ev_done;
+    }
     ctx->bt_pre = d_pre;
     ctx->bt_term = d_term;
     ctx->bt_deferred = false;
     rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st);
     ctx->front_stop = nullptr;
+    ctx->sweep_wait = nullptr;
     ctx->bt_pre = nullptr;
     ctx->bt_term = nullptr;
     const bool deferred = ctx->bt_deferred;
@@ -1597,7 +1702,7 @@ int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t 
     if ((rc = stg.out(speed_t, (size_t)B * st::kCols, &d_tt, false))) return rc;
     // heaviest scenes first (emp_st_kernels.h: st_count_kernel); pointless when every block is resident at once
     int* d_order = nullptr;
-    static const bool no_order = getenv("EMP_ST_NO_ORDER") != nullptr;   // development A/B switch
+    const bool no_order = ctx->opt[EMP_OPT_ST_ORDER] == 0;               // emp_set_option (A/B)
     if (B > 512 && !no_order) {
         unsigned char* d_key;
         int* d_hist;

@@ -79,6 +79,18 @@ struct emp_ctx {
     int lane = 0;                       // lane of the latest pipelined cycle call
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
+    // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0};
+    int back_stream_cus = -1;           // the CU count back_stream was created with (-1: no back stream yet)
+    // EMP_OPT_SWEEP_EXCLUSIVE: the event the next sweep launch waits for on its own stream (the previous call's back stage)
+    hipEvent_t sweep_wait = nullptr;
+    // EMP_OPT_SWEEP_CLOCK_PROBE: a ring of kProbeSlots launches x [tiles][4] ticks (shader-clock begin / end, reference
+    // begin / end); probe_launches counts the launches recorded since the option was last switched on
+    static constexpr int kProbeSlots = 32;
+    Buf clock_probe;
+    int clock_probe_tiles = 0;
+    long probe_launches = 0;
+    hipEvent_t clock_probe_done = nullptr;
     bool pipelined() const { return pipe_mode != 0; }
     // STAGED rotates kStagedPools pools of temporaries although only two calls overlap on the GPU: call k reuses the pool
     // of call k - 4 and the HOST waits for that call's back stage (long finished unless the host runs more than four

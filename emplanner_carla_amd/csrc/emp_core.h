@@ -18,6 +18,10 @@
 #define EMP_HD inline
 #endif
 
+// Development hooks (emp_qp_params.reserved read as the QP kernels' debug stage): compiled in only with -DEMP_DEV_HOOKS=1.
+#ifndef EMP_DEV_HOOKS
+#define EMP_DEV_HOOKS 0
+#endif
 // Wavefront priorities (s_setprio, 0..3) of the kernels that share the SIMDs when two batches are in flight.
 #ifndef EMP_PRIO_BACK
 #define EMP_PRIO_BACK 3      // path QP, Cartesian tail

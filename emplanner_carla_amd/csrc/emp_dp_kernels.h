@@ -285,8 +285,26 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
                                                        double* __restrict__ min_cost_out,
                                                        int* __restrict__ status_out,
                                                        unsigned char* __restrict__ pre_out = nullptr,
-                                                       int* __restrict__ term_out = nullptr) {
+                                                       int* __restrict__ term_out = nullptr,
+                                                       unsigned long long* __restrict__ clock_probe = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pre_lds[];   // [WPB][64] doubles, then [WPB][col][64] bytes
+    // EMP_OPT_SWEEP_CLOCK_PROBE (measurement; a scalar branch when off): the shader-clock counter and the constant 100 MHz
+    // reference counter at the wavefront's first and last instruction - their ratio is the clock this wavefront ran at,
+    // whatever runs beside it (a counter pass of rocprofv3 would serialise the kernels of the staged step).
+    unsigned long long probe_c0 = 0, probe_r0 = 0;
+    if (clock_probe) {
+        probe_c0 = clock64();
+        probe_r0 = wall_clock64();
+    }
+    auto probe_end = [&](int tile_, int lane_) {
+        if (clock_probe && lane_ == 0) {
+            unsigned long long* o = clock_probe + (size_t)tile_ * 4;
+            o[0] = probe_c0;
+            o[1] = clock64();
+            o[2] = probe_r0;
+            o[3] = wall_clock64();
+        }
+    };
     // One wavefront per tile, ~75 instructions per column between two waits for HBM: with two batches in flight it shares
     // its SIMD with the previous batch's path-QP / Cartesian wavefronts, which raise their priority to 3; at priority 0
     // every one of its short bursts queued behind them and the stream slowed from 20.5 to 22.5-25 us.
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
         const uint4* src = reinterpret_cast<const uint4*>(pre);
         uint4* dst = reinterpret_cast<uint4*>(pre_out + (size_t)tile * P.col * 64);
         for (int w = lane; w < P.col * 4; w += 64) dst[w] = src[w];
+        probe_end(tile, lane);
         return;
     }
     if (live && i == 0) {
@@ -463,6 +482,7 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
             status_out[b] = (best > P.w_coll) ? 1 : 0;    // ref :351 (EMP_ST_DP_INFEASIBLE)
         }
     }
+    probe_end(tile, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

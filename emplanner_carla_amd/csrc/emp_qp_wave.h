@@ -1095,7 +1095,7 @@ __device__ inline int path_qp_group(double* lds, const double* l_min, const doub
     else rs = range_qp_solve_wave<G>(Q, gl, ok && Q.N > 0, cap_it);
     if (ok && Q.N > 0) {
         *iters_out = Q.iters;
-        if (rs && debug_stage < 10) rc = rs;          // (development: a capped solve hands its last iterate on, for timing)
+        if (rs && (debug_stage < 10 || !EMP_DEV_HOOKS)) rc = rs;   // (-DEMP_DEV_HOOKS only: a capped solve hands its last iterate on, for timing)
     }
     ok = rc == 0;
     if (ok && Q.N == 0) {                                // nothing free: only check the constant forms

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 8
+#define EMP_ABI_VERSION 9
 
 typedef struct emp_ctx emp_ctx;
 
@@ -77,7 +77,9 @@ typedef struct emp_qp_params {
     int32_t decimate;       /* 2 (test_9.py:187) or 1 (test_7.py) */
     int32_t midpoint;       /* 1: re-interleave midpoints (test_9.py:204-210); 0: none (test_7.py) */
     int32_t use_qp;         /* 1; 0 skips the QP (test_5.py / test_6.py form) */
-    int32_t reserved;
+    int32_t reserved;       /* MUST be 0 (emp_qp_params_default sets it): every entry point that takes the struct refuses
+                             * anything else with EMP_ERR_INVALID, so that a caller who did not initialise the struct finds
+                             * out at once */
 } emp_qp_params;
 
 /* ref: keyword arguments of smooth_reference_line, planning_utils.py:262-264 */
@@ -160,6 +162,61 @@ int emp_pipeline_depth(emp_ctx* ctx);
  * the same scenes: bench.py --config cfg5); what must be ordered, the caller orders with emp_result_stream().  Their
  * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
 int emp_set_fence(emp_ctx* ctx, int enabled);
+
+/* ---- options (ABI version 9) ---------------------------------------------------------------------------------------
+ * The library reads NO environment variable.  Everything that used to be an EMP_* environment switch of the development
+ * builds is a per-context option here, set by the host program before the calls it should affect (a change takes effect
+ * at the next call; EMP_OPT_BACK_STREAM_CUS at the next emp_set_pipeline).  Unknown options and values out of range are
+ * EMP_ERR_INVALID.  "result-affecting" options change WHICH kernel computes a stage: the two forms of a stage solve the
+ * same problem with the same stopping rule but associate sums differently (path QP: ~2e-9 relative; Cartesian tail: bit
+ * identical) - so they are never chosen from the batch size: a scene's result does not depend on how many scenes share
+ * its call or its GPU (a rank's shard equals its slice of the one-GPU result, emplanner_carla_amd/dist.py).
+ *
+ *   option                          default  kind             meaning
+ *   EMP_OPT_PATH_QP_FORM            0        result-affecting 0: eight scenes per wavefront (emp_qp_rows.h; up to 66 stations,
+ *                                                             beyond that the one-per-wavefront kernel whatever is set);
+ *                                                             1: the two-scenes-per-wavefront kernel of rounds 1-2
+ *                                                             (emp_qp_wave.h: ~17 % fewer instructions on a scene's own
+ *                                                             critical path - for a caller that plans a handful of scenes
+ *                                                             and wants the last 10 us of latency)
+ *   EMP_OPT_CARTESIAN_FORM          0        A/B (bit-ident.) 0: four scenes per wavefront; 1: one scene per wavefront
+ *   EMP_OPT_SMOOTH_FORCE_FALLBACK   0        test hook        1: every smoothing QP of the Cartesian tail takes its
+ *                                                             projected-gradient fallback (tests/test_gpu_fullsize.py)
+ *   EMP_OPT_EDGE_BLOCK              0        tuning           threads per block of the edge-cost kernel (multiple of 64 up
+ *                                                             to 1024); 0: from the lattice's LDS footprint
+ *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto; 1/2/3: register ring 3/4/8 columns deep;
+ *                                                             4/5: nontemporal / plain loads whatever the tensor's size
+ *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
+ *   EMP_OPT_ST_ORDER                1        tuning           speed DP: 1 heaviest scenes first, 0 input order (same results)
+ *   EMP_OPT_SWEEP_EXCLUSIVE         0        tuning           staged pipeline: 1 = the sweep of call k waits (stream-side) for
+ *                                                             the back stage of call k-1, so that the HBM-bound kernel runs
+ *                                                             beside nothing
+ *   EMP_OPT_BACK_STREAM_CUS         0        tuning           staged pipeline: n > 0 confines the back stage's stream to n
+ *                                                             compute units (hipExtStreamCreateWithCUMask, the lowest n bits
+ *                                                             of the mask: spread evenly over the XCDs); 0: no mask
+ *   EMP_OPT_SWEEP_CLOCK_PROBE       0        measurement      1: every sweep launch also records, per wavefront, the shader
+ *                                                             clock ticks and the 100 MHz reference ticks it ran for
+ *                                                             (emp_sweep_clock_mhz reads their ratio)                       */
+typedef enum emp_option {
+    EMP_OPT_PATH_QP_FORM = 0,
+    EMP_OPT_CARTESIAN_FORM = 1,
+    EMP_OPT_SMOOTH_FORCE_FALLBACK = 2,
+    EMP_OPT_EDGE_BLOCK = 3,
+    EMP_OPT_SWEEP_VARIANT = 4,
+    EMP_OPT_FUSED_COLUMNS = 5,
+    EMP_OPT_ST_ORDER = 6,
+    EMP_OPT_SWEEP_EXCLUSIVE = 7,
+    EMP_OPT_BACK_STREAM_CUS = 8,
+    EMP_OPT_SWEEP_CLOCK_PROBE = 9,
+    EMP_OPT_COUNT = 10
+} emp_option;
+int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
+int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
+/* With EMP_OPT_SWEEP_CLOCK_PROBE on: the shader clock the sweep launches ran at since the option was last switched on (the
+ * latest 32 of them), in MHz: the ratio of shader-clock ticks to 100 MHz reference ticks between a wavefront's first and
+ * last instruction, summed over all their wavefronts (synchronises on the latest launch); optionally (may be NULL) the mean
+ * and the longest time a wavefront was resident, in microseconds.  Negative when nothing was recorded. */
+double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_us);
 
 /* One fixed-stride record per scene for the multi-GPU gather (no reference counterpart: the reference plans one scene
  * per process; this is the result exchange of the batched form, emplanner_carla_amd/dist.py):

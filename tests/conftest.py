@@ -69,3 +69,15 @@ def assert_rel(a, b, rtol, what="", scale=None):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def make_planner(device_id=0):
+    """The GPU suites' context.  EMP_TEST_PATH_QP_FORM (an environment variable of the TEST HARNESS - the library reads
+    none) selects the path-QP kernel form through emp_set_option, so that a child pytest can rerun whole test files on the
+    two-scenes-per-wavefront kernel (tests/test_gpu_fuzz.py)."""
+    from emplanner_carla_amd.api import Planner
+    pl = Planner(device_id)
+    form = os.environ.get("EMP_TEST_PATH_QP_FORM")
+    if form:
+        pl.set_option("path_qp_form", int(form))
+    return pl

@@ -25,8 +25,8 @@ GOLD = {"cfg1": (S.CFG1, "cycle_cfg1_20x5_0obs.npz", {}),
 
 @pytest.fixture(scope="module")
 def planner():
-    from emplanner_carla_amd.api import Planner
-    p = Planner(0)
+    from conftest import make_planner
+    p = make_planner(0)
     yield p
     p.close()
 
@@ -768,11 +768,12 @@ def test_full_cycle_on_the_wide_lattice_stage_by_stage(planner):
 
 
 @pytest.mark.parametrize("col,max_pts,stations", [(33, None, 33), (34, 68, 34), (34, None, 34)])
-def test_paired_path_qp_at_its_size_limits(planner, col, max_pts, stations):
-    """The cycle's path QP packs two scenes into a wavefront while a scene has at most 34 stations (32 free
-    coefficients, 32 constrained stations: every lane of both half-waves busy) and its LDS arrays are addressed with
-    fixed strides and unclamped neighbour indices.  33 and 34 stations through that kernel, 34 through the
-    one-scene-per-wavefront kernel (the output capacity decides), each against oracle/ref_port.plan_cycle."""
+def test_path_qp_at_its_size_limits(planner, col, max_pts, stations):
+    """The cycle's path QP packs eight scenes into a wavefront while a scene has at most 34 stations (R = 4 stations per lane
+    of an 8-lane group: every lane busy), four up to 66 (16-lane groups); the two-scenes-per-wavefront form
+    (EMP_OPT_PATH_QP_FORM = 1, the child run of tests/test_gpu_fuzz.py) holds 34 stations per half-wave, with LDS arrays
+    addressed by fixed strides and unclamped neighbour indices.  33 and 34 stations through the narrow kernel, 34 through the
+    wide one (the output capacity decides), each against oracle/ref_port.plan_cycle."""
     from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params
     cfg = S.LatticeConfig(f"limits_{col}x5", row=5, col=col, sample_s=2.0, sample_l=1.0, sampling_res=1, n_obs=4)
     seeds = list(range(300, 316))

@@ -577,58 +577,66 @@ def test_unfenced_calls_overlap_the_cycles_in_flight(planner, pipe):
         planner.set_pipeline(False)
 
 
-def test_both_path_qp_kernels_agree_on_the_benchmark_batch(tmp_path):
+def _benchmark_batch_under(planner, option, value):
+    """The 4096 benchmark scenes through the whole cycle with one emp_set_option value in force (restored afterwards)."""
+    cfg = S.CFG2
+    host = _host_inputs(S.make_batch(range(4096), cfg))
+    old = planner.get_option(option)
+    planner.set_option(option, value)
+    try:
+        return _plan_resident(planner, cfg, host)
+    finally:
+        planner.set_option(option, old)
+
+
+def test_both_path_qp_kernels_agree_on_the_benchmark_batch(planner):
     """The cycle's path QP runs eight scenes per wavefront (emp_qp_rows.h: R stations per lane); the two-scenes-per-wavefront
-    kernel of rounds 1-2 (emp_qp_wave.h) stays behind EMP_PATH_QP_PAIR=1.  Same algorithm and stopping rule, sums associated
+    kernel of rounds 1-2 (emp_qp_wave.h) is EMP_OPT_PATH_QP_FORM = 1.  Same algorithm and stopping rule, sums associated
     differently: on all 4096 benchmark scenes the two must classify every scene alike and agree on path and trajectory far
     inside the 1e-6 bar (measured: 2e-9).  Scene 446 is the one that found the stopping rule's weak spot: its dual residual
     sits at the threshold when the complementarity has converged, one more iteration destroys the iterate."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tool = os.path.join(root, "tools", "qp_form_compare.py")
-    outs = []
-    for name, pair in (("rows", ""), ("pair", "1")):
-        out = str(tmp_path / f"{name}.npz")
-        env = dict(os.environ, EMP_PATH_QP_PAIR=pair)
-        run = subprocess.run([sys.executable, tool, out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-        assert run.returncode == 0, run.stderr[-2000:]
-        outs.append(np.load(out))
-    a, b = outs
+    a = _benchmark_batch_under(planner, "path_qp_form", 0)
+    b = _benchmark_batch_under(planner, "path_qp_form", 1)
     assert np.array_equal(a["status"], b["status"])
     ok = (a["status"] & ~1) == 0
     assert ok.sum() > 3000
     assert np.array_equal(a["traj_len"], b["traj_len"])
     assert np.abs(a["path_l"][ok] - b["path_l"][ok]).max() < 1e-7
     assert np.abs(a["traj"][ok] - b["traj"][ok]).max() < 1e-7
+    assert not np.array_equal(a["path_l"][ok], b["path_l"][ok]), "the option must reach a different kernel"
 
 
-def test_cartesian_tail_kernels_agree_on_the_benchmark_batch(tmp_path):
+def test_cartesian_tail_kernels_agree_on_the_benchmark_batch(planner):
     """The cycle's Cartesian tail runs four scenes per wavefront (cycle_cartesian_rows_kernel); the one-scene-per-wavefront
-    kernel of rounds 1-2 stays behind EMP_CARTESIAN_WAVE=1.  Same operations per coordinate in the same order: the
-    trajectories of the 4096 benchmark scenes must be BIT-identical.  Third run: EMP_SMOOTH_FORCE_FALLBACK=1 sends every
+    kernel of rounds 1-2 is EMP_OPT_CARTESIAN_FORM = 1.  Same operations per coordinate in the same order: the
+    trajectories of the 4096 benchmark scenes must be BIT-identical.  Third run: EMP_OPT_SMOOTH_FORCE_FALLBACK = 1 sends every
     scene of the new kernel through its fall-back (the half-wave interior-point / active-set solvers, the whole wavefront
     on one scene at a time) - a path no test or benchmark scene takes by itself; it must classify alike and agree to 1e-9."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tool = os.path.join(root, "tools", "qp_form_compare.py")
-    outs = {}
-    for name, env_extra in (("rows", {}), ("wave", {"EMP_CARTESIAN_WAVE": "1"}), ("fallback", {"EMP_SMOOTH_FORCE_FALLBACK": "1"})):
-        out = str(tmp_path / f"{name}.npz")
-        run = subprocess.run([sys.executable, tool, out], cwd=root, env=dict(os.environ, **env_extra), capture_output=True,
-                             text=True, timeout=600)
-        assert run.returncode == 0, run.stderr[-2000:]
-        outs[name] = np.load(out)
-    a, b, c = outs["rows"], outs["wave"], outs["fallback"]
+    a = _benchmark_batch_under(planner, "cartesian_form", 0)
+    b = _benchmark_batch_under(planner, "cartesian_form", 1)
+    c = _benchmark_batch_under(planner, "smooth_force_fallback", 1)
     for other in (b, c):
         assert np.array_equal(a["status"], other["status"]) and np.array_equal(a["traj_len"], other["traj_len"])
     ok = (a["status"] & ~1) == 0
     assert ok.sum() > 3000
     assert np.array_equal(a["traj"], b["traj"]), "the two kernels perform the same operations: bit-identical"
     assert np.abs(a["traj"][ok] - c["traj"][ok]).max() < 1e-9
+    assert not np.array_equal(a["traj"][ok], c["traj"][ok]), "the hook must reach the fall-back"
+
+
+def test_small_shards_equal_their_slice_of_the_full_batch(planner):
+    """What rank r of an N-GPU run computes must be its slice of the one-GPU result whatever the shard size - also when a
+    shard is far smaller than the batch (4096 scenes on 8 ranks: 512 each; 16 ranks' worth: 256; a 7-scene tail).  Round 3
+    chose the path-QP kernel from the batch size (two scenes per wavefront below 1024), which broke exactly this; the form is
+    now an option of the caller (include/emplanner.h) and every kernel of the cycle treats a scene independently of its
+    neighbours in the batch."""
+    cfg = S.CFG2
+    B = 4096
+    host = _host_inputs(S.make_batch(range(B), cfg))
+    out = _plan_resident(planner, cfg, host)
+    for a, n in ((0, 512), (3584, 512), (1024, 256), (777, 100), (4089, 7), (5, 1)):
+        sl = slice(a, a + n)
+        _assert_same({k: v[sl] for k, v in out.items()}, _plan_resident(planner, cfg, host, sl), f"shard {a}+{n}")
 
 
 def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner):

@@ -1,5 +1,6 @@
-"""Development aid: the benchmark batch through the whole cycle, outputs saved to an .npz - run once with EMP_PATH_QP_PAIR=1 and
-once without, then `python tools/qp_form_compare.py diff a.npz b.npz`."""
+"""Development aid: the benchmark batch through the whole cycle, outputs saved to an .npz - run once with `path_qp_form=1` (any
+`name=value` of emplanner_carla_amd._lib.OPTIONS after the output file) and once without, then
+`python tools/qp_form_compare.py diff a.npz b.npz`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +20,9 @@ cfg, B = S.CFG2, int(os.environ.get("SCENES", "4096"))
 batch = S.make_batch(range(B), cfg); P = batch.ref.shape[1]
 p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
 pl = Planner(0)
+for kv in sys.argv[2:]:
+    k, v = kv.split("=")
+    pl.set_option(k, int(v))
 r = pl.plan_cycle(p, q, sp, max_pts=max_path_points(p), ref_line=batch.ref, n_ref=np.full(B, P, np.int32), origin_xy=batch.origin_xy,
                   start_xy=batch.start_xy, start_v=batch.start_v, start_a=batch.start_a, obs_xy=batch.obs_xy, n_obs=batch.n_obs)
 np.savez(sys.argv[1], status=r.status, path_l=r.path_l, path_s=r.path_s, traj=r.traj, traj_len=r.traj_len)
