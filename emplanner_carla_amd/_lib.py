@@ -166,6 +166,7 @@ PROTOTYPES = {
     "emp_speed_dp": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32] + [_vp] * 11 + [C.c_int]),
     "emp_st_edge_costs": (C.c_int, [_vp, C.POINTER(SpeedDpParams), _i32, _i32, _i32] + [_vp] * 7 + [C.c_int]),
     "emp_st_collision_cost": (C.c_int, [_vp, _i32, _f64, _vp, _vp, C.c_int]),
+    "emp_speed_start_condition": (C.c_int, [_vp, _i32] + [_vp] * 7 + [C.c_int]),
     "emp_speed_qp_params_default": (None, [C.POINTER(SpeedQpParams)]),
     "emp_speed_convex_space": (C.c_int, [_vp, _i32, _i32, _i32, _f64] + [_vp] * 14 + [C.c_int]),
     "emp_speed_qp": (C.c_int, [_vp, C.POINTER(SpeedQpParams), _i32] + [_vp] * 14 + [C.c_int]),

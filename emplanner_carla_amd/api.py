@@ -669,6 +669,18 @@ class Planner:
                                                     a.where))
         return c
 
+    def speed_start_condition(self, vx, vy, ax, ay, heading):
+        """ref calc_speed_planning_start_condition (:23-35): Cartesian velocity / acceleration and heading of the planning
+        start, (n,) each -> plan_start_s_dot, plan_start_s_dot2 (n,)."""
+        a = self._args(vx, vy, ax, ay, heading)
+        n = int(vx.shape[0])
+        s1, p1 = a.out((n,), np.float64)
+        s2, p2 = a.out((n,), np.float64)
+        self._check(self._lib.emp_speed_start_condition(
+            self._h, n, a.inp(vx, np.float64, (n,)), a.inp(vy, np.float64, (n,)), a.inp(ax, np.float64, (n,)),
+            a.inp(ay, np.float64, (n,)), a.inp(heading, np.float64, (n,)), p1, p2, a.where))
+        return s1, s2
+
     # ---- S-T speed planning back end (reference speed_planning_test.py:308-620) ---------------------
     def speed_convex_space(self, dp_speed_s, dp_speed_t, path_index2s, path_kappa, path_len, s_in, s_out, t_in, t_out,
                            max_lateral_accel=0.2 * 9.8):

@@ -1778,6 +1778,30 @@ int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const doub
     return stg.finish();
 }
 
+int emp_speed_start_condition(emp_ctx* ctx, int32_t n, const double* vx, const double* vy, const double* ax, const double* ay,
+                              const double* heading, double* s_dot, double* s_dot2, emp_mem where) {
+    using namespace emp;
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && vx && vy && ax && ay && heading && s_dot && s_dot2, "bad argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    Stage stg(ctx, where);
+    int rc;
+    const double *d_vx, *d_vy, *d_ax, *d_ay, *d_h;
+    double *d_s1, *d_s2;
+    if ((rc = stg.in(vx, (size_t)n, &d_vx))) return rc;
+    if ((rc = stg.in(vy, (size_t)n, &d_vy))) return rc;
+    if ((rc = stg.in(ax, (size_t)n, &d_ax))) return rc;
+    if ((rc = stg.in(ay, (size_t)n, &d_ay))) return rc;
+    if ((rc = stg.in(heading, (size_t)n, &d_h))) return rc;
+    if ((rc = stg.out(s_dot, (size_t)n, &d_s1, false))) return rc;
+    if ((rc = stg.out(s_dot2, (size_t)n, &d_s2, false))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(st_start_condition_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, d_vx, d_vy, d_ax, d_ay, d_h, d_s1, d_s2);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return stg.finish();
+}
+
 // ---- S-T speed planning back end (reference speed_planning_test.py:308-620) ---------------------
 void emp_speed_qp_params_default(emp_speed_qp_params* p) {
     if (!p) return;

@@ -73,18 +73,22 @@ __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __r
     if (threadIdx.x == 0) sample_moments(P.sample_s, &tab[kTableFields * rr + kSamples], &tab[kTableFields * rr + kSamples + 1]);
 }
 
-// kSoftGain / d2 for 16 < d2 < 36, correctly rounded: the instruction sequence the compiler emits for an IEEE binary64
-// division (reciprocal seed, Newton steps, quotient, residual, final fma) without its range scaling and special-case fix-up,
-// which do nothing for operands of this size, and (round 3) with ONE Newton step instead of two: six instructions instead
-// of twelve, eight to nine times per obstacle scan.  One step takes the seed (2^-24 or better) to 2^-48 or better; the
-// quotient q = 5000 r then carries that error, the residual 5000 - d2 q is exact (fma), and the correction r (5000 - d2 q)
-// is wrong by q 2^-96 at most - so the final fma rounds to the neighbour of the true quotient only if that lies within
-// 2^-96 q of a rounding boundary: one operand in 2^43.  tools/soft_quotient_test.hip: 8.6e9 operands of the interval, an
-// even sweep and a hashed one, every quotient equal to the compiler's IEEE division bit for bit; every edge tensor of the
-// suite and the rows of a 262144-scene DP sweep (profiles/r03_final_parity_sweep_dp_262144.json) equal the oracle's.
-// EMP_SOFT_NEWTON_STEPS=2 restores the compiler's sequence.  With the shorter block the compiler would drop the wave-level
-// skip branch around it (its threshold is twelve instructions) and execute all ten divisions of a scan under masks - 8 %
-// slower than the long form; obstacle_scan_dense keeps the branch with an empty volatile asm.
+// kSoftGain / d2 for 16 < d2 < 36, equal to the IEEE binary64 quotient except with probability ~2^-43 per operand (NOT a
+// proof of correct rounding): the instruction sequence the compiler emits for an IEEE division (reciprocal seed, Newton
+// steps, quotient, residual, final fma) without its range scaling and special-case fix-up, which do nothing for operands
+// of this size, and (round 3) with ONE Newton step instead of two: six instructions instead of twelve, eight to nine
+// times per obstacle scan.  One step takes the seed (2^-24 or better) to 2^-48 or better; the quotient q = 5000 r then
+// carries that error, the residual 5000 - d2 q is exact to 2^-53 of itself (fma), and the correction r (5000 - d2 q) is
+// wrong by q 2^-96 at most - so the final fma returns the NEIGHBOUR of the correctly rounded quotient only if the true
+// quotient lies within 2^-96 q of a rounding boundary: one operand in 2^43, i.e. about one soft term in 10^4 batches of
+// 4096 scenes (1e9 divisions each), and then by one unit in the last place (1.1e-16 relative against the 1e-6 bar; an
+// argmin moves only if two path costs tie to that unit).  Evidence, not proof: tools/soft_quotient_test.hip checks 8.6e9
+// operands of the interval (an even sweep and a hashed one) against the compiler's IEEE division bit for bit, as a test
+// of the GPU suite; every edge tensor of the suite and the rows of a 262144-scene DP sweep
+// (profiles/r03_final_parity_sweep_dp_262144.json) equal the oracle's.  Building with -DEMP_SOFT_NEWTON_STEPS=2 restores
+// the compiler's own (proven) sequence at +4 % of the edge kernel.  With the shorter block the compiler would drop the
+// wave-level skip branch around it (its threshold is twelve instructions) and execute all ten divisions of a scan under
+// masks - 8 % slower than the long form; obstacle_scan_dense keeps the branch with an empty volatile asm.
 #ifndef EMP_SOFT_NEWTON_STEPS
 #define EMP_SOFT_NEWTON_STEPS 1
 #endif

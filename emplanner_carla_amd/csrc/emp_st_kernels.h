@@ -469,4 +469,15 @@ __global__ void st_collision_cost_kernel(int n, st::PowBase w, const double* __r
     if (i < n) cost[i] = st::collision_cost(w, dist[i]);
 }
 
+// ref :23-35: tangential speed and acceleration of the planning start (one lane per scene)
+__global__ void st_start_condition_kernel(int n, const double* __restrict__ vx, const double* __restrict__ vy, const double* __restrict__ ax,
+                                          const double* __restrict__ ay, const double* __restrict__ heading, double* __restrict__ s_dot,
+                                          double* __restrict__ s_dot2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double c = cos(heading[i]), s = sin(heading[i]);
+    s_dot[i] = c * vx[i] + s * vy[i];
+    s_dot2[i] = c * ax[i] + s * ay[i];
+}
+
 }  // namespace emp

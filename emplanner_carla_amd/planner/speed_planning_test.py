@@ -1,4 +1,4 @@
-"""Drop-in for the S-T speed-DP part of reference planner/speed_planning_test.py (:38-305): same function
+"""Drop-in for the S-T speed-DP part of reference planner/speed_planning_test.py (:23-305): same function
 names, argument order, keyword names and defaults; results from the HIP kernels (batch of one scene).
 Line numbers cite the reference file.  The back end (:308-620: ``generate_convex_space``, ``speed_QP``,
 ``increase_points``, ``path_speed_merge``) is at the bottom of this module.
@@ -28,6 +28,14 @@ def _sets(*arrays):
         row[0, :k] = [float(v) for v in a]
         out.append(row)
     return out, k
+
+
+def calc_speed_planning_start_condition(plan_start_vx, plan_start_vy, plan_start_ax, plan_start_ay, plan_start_heading):
+    """ref :23-35 (called by the driver at test_10.py:249) -> plan_start_s_dot, plan_start_s_dot2."""
+    one = lambda v: np.array([float(v)])
+    s_dot, s_dot2 = planner().speed_start_condition(one(plan_start_vx), one(plan_start_vy), one(plan_start_ax),
+                                                    one(plan_start_ay), one(plan_start_heading))
+    return np.float64(s_dot[0]), np.float64(s_dot2[0])
 
 
 def generate_st_graph(dynamic_obs_s_set, dynamic_obs_l_set, dynamic_obs_s_dot_set, dynamic_obs_l_dot_set):

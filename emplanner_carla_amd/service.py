@@ -16,9 +16,18 @@ static obstacles count only if the nearest is within 30 m (test_9.py:117), only 
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 
 from .api import Planner, dp_params, max_path_points, qp_params, smooth_params
+
+log = logging.getLogger("emplanner_carla_amd.service")
+
+#: how many requests in a row may be answered with the previous trajectory before the loop gives up (ValueError): at the
+#: reference's planning period (test_9.py:356: one request per 0.5 s of simulated time at most) ten repeats are five seconds
+#: of driving on a trajectory that was planned for an older scene
+MAX_CONSECUTIVE_REPEATS = 10
 
 INFEASIBLE_BANNER = "********************     can't find a feasible path      ********************"
 
@@ -105,23 +114,50 @@ def answer_refused(reply, status, match_index, previous, on_infeasible):
     raise ValueError("path or smoothing QP infeasible" + ("" if on_infeasible == "raise" else " and no previous trajectory to repeat"))
 
 
-def motion_planning(conn, device_id: int = 0, dp=None, on_infeasible: str = "previous", strict: bool = False):
+class RefusalPolicy:
+    """The state of ``answer_refused`` across the requests of one planning loop: the last valid reply, and how many
+    requests in a row it has been repeated for.  Every repeat is logged (WARNING, logger emplanner_carla_amd.service) with
+    its status bits and its count; after ``max_repeats`` consecutive repeats the next refused request raises ValueError -
+    a driver is never left following an arbitrarily stale trajectory without anyone being told."""
+
+    def __init__(self, on_infeasible: str = "previous", max_repeats: int = MAX_CONSECUTIVE_REPEATS):
+        self.on_infeasible, self.max_repeats = on_infeasible, int(max_repeats)
+        self.previous, self.repeats = None, 0
+
+    def answer(self, reply, status, match_index):
+        if reply is not None:
+            self.previous, self.repeats = reply, 0
+            return reply
+        out = answer_refused(reply, status, match_index, self.previous, self.on_infeasible)     # raises for the other policies
+        if self.on_infeasible == "previous":
+            self.repeats += 1
+            if self.repeats > self.max_repeats:
+                raise ValueError(f"path or smoothing QP infeasible for {self.repeats} requests in a row (status {status}): "
+                                 f"not repeating a trajectory that old (max_repeats = {self.max_repeats})")
+            log.warning("request refused (status %d: path or smoothing QP infeasible): previous trajectory sent again, "
+                        "repeat %d of at most %d", status, self.repeats, self.max_repeats)
+        else:
+            log.warning("request refused (status %d): sentinel reply sent", status)
+        return out
+
+
+def motion_planning(conn, device_id: int = 0, dp=None, on_infeasible: str = "previous", strict: bool = False,
+                    max_repeats: int = MAX_CONSECUTIVE_REPEATS):
     """Drop-in for the reference's planning process (test_9.py:92-220): ``multiprocessing.Process(target=
     motion_planning, args=(conn,))``.  Blocks on ``conn.recv()`` like the reference and creates its device context here,
     in the child.  A request on which the reference raises IndexError raises IndexError here too - the child ends, as the
     reference's does.  A request whose path or smoothing QP is infeasible: see ``answer_refused`` (default: the previous
-    valid trajectory again, so that an UNMODIFIED driver keeps running; ``strict=True`` is ``on_infeasible="raise"``).
+    valid trajectory again, so that an UNMODIFIED driver keeps running - logged every time and at most ``max_repeats``
+    times in a row, ``RefusalPolicy``; ``strict=True`` is ``on_infeasible="raise"``).
     ``dp`` overrides the lattice (default: the reference's keyword defaults, path_planning.py:277-279)."""
     planner = Planner(device_id)                                            # created in the child process
-    previous = None
     if strict:
         on_infeasible = "raise"
+    policy = RefusalPolicy(on_infeasible, max_repeats)
     while 1:
         request = conn.recv()
         stages = {}
         reply, status = plan_requests(planner, [request], dp=dp, stages=stages)[0]
         if status & 1:
             print(INFEASIBLE_BANNER)                                        # path_planning.py:351
-        if reply is not None:
-            previous = reply
-        conn.send(answer_refused(reply, status, stages["match"][0], previous, on_infeasible))
+        conn.send(policy.answer(reply, status, stages["match"][0]))

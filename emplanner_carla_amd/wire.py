@@ -337,7 +337,11 @@ class PlannerClient:
             raise WireError(payload.decode())
         if ftype != T_REPLY or count != len(requests):
             raise WireError(f"expected {len(requests)} replies, got frame type {ftype} with {count}")
-        return [(reply, status) for reply, status, _ in self.layout.decode_replies(payload, count)]
+        replies = self.layout.decode_replies(payload, count)
+        # the match index the SERVER computed for every request of this call, refused ones included (the reply record
+        # carries it whether or not a trajectory follows)
+        self.last_match = [int(m) for m in np.frombuffer(payload, self.layout.reply_dtype, count)["match"]]
+        return [(reply, status) for reply, status, _ in replies]
 
     def close(self):
         try:
@@ -347,19 +351,18 @@ class PlannerClient:
         self.sock.close()
 
 
-def motion_planning_remote(conn, host: str, port: int, dp=None, on_infeasible: str = "previous"):
+def motion_planning_remote(conn, host: str, port: int, dp=None, on_infeasible: str = "previous", max_repeats=None):
     """Drop-in body of the reference's planning process (test_9.py:92-220) that plans on a remote server: requests come in
     over the driver's Pipe, go out over the socket, the reply tuple goes back over the Pipe.  Failure handling as in
-    ``service.motion_planning`` (``service.answer_refused``)."""
-    from .service import answer_refused
+    ``service.motion_planning`` (``service.RefusalPolicy``: a refused request is answered with the previous trajectory and
+    the match index the SERVER computed for this request, logged, at most ``max_repeats`` times in a row)."""
+    from .service import MAX_CONSECUTIVE_REPEATS, RefusalPolicy
     client = PlannerClient(host, port, dp=dp)
-    previous = None
+    policy = RefusalPolicy(on_infeasible, MAX_CONSECUTIVE_REPEATS if max_repeats is None else max_repeats)
     while 1:
         request = conn.recv()
         reply, status = client.plan([request])[0]
-        if reply is not None:
-            previous = reply
-        conn.send(answer_refused(reply, status, request[7][0], previous, on_infeasible))
+        conn.send(policy.answer(reply, status, client.last_match[0]))
 
 
 if __name__ == "__main__":

@@ -507,6 +507,11 @@ int emp_st_edge_costs(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int
 /* ref: CalcCollisionCost (:274-284): n distances -> n costs */
 int emp_st_collision_cost(emp_ctx* ctx, int32_t n, double w_cost_obs, const double* min_dis, double* cost, emp_mem where);
 
+/* ref: calc_speed_planning_start_condition (:23-35), called by the driver at test_10.py:249: the planning start's velocity and
+ * acceleration (Cartesian) projected on the path tangent at the start's heading, n scenes -> s_dot [n], s_dot2 [n] */
+int emp_speed_start_condition(emp_ctx* ctx, int32_t n, const double* vx, const double* vy, const double* ax, const double* ay,
+                              const double* heading, double* s_dot, double* s_dot2, emp_mem where);
+
 /* ---- S-T speed planning back end (reference planner/speed_planning_test.py:308-620) ----
  * Status bits of these four entry points (per scene; the arrays of a flagged scene are NaN): */
 #define EMP_STB_RANGE 2       /* scipy interp1d bounds error / np.interp on an empty path (ValueError in the reference) */

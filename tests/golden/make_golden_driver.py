@@ -20,6 +20,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+#: where the .npz files go: this directory, or a scratch one for tests/test_reference_live.py (regenerate and compare)
+OUT = os.environ.get("EMP_GOLDEN_OUT", HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
@@ -138,8 +140,8 @@ def _run(t9, pu, fname):
         recs.append(rec)
         print("case", c, "kind", case, "reply" if ok else "no reply", "traj points", rec["n_traj"])
     out = {k: np.stack([np.asarray(r[k]) for r in recs]) for k in recs[0]}
-    np.savez_compressed(os.path.join(HERE, fname), **out)
-    print(fname, os.path.getsize(os.path.join(HERE, fname)), "bytes")
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, os.path.getsize(os.path.join(OUT, fname)), "bytes")
 
 
 def main():

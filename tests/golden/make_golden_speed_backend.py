@@ -22,6 +22,8 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+#: where the .npz files go: this directory, or a scratch one for tests/test_reference_live.py (regenerate and compare)
+OUT = os.environ.get("EMP_GOLDEN_OUT", HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
@@ -181,7 +183,7 @@ def main():
     g.update(merge_now=now, merge_path_s=ps, merge_x=px, merge_y=py, merge_heading=ph, merge_kappa=pk, merge_n=n_path,
              merge_out=merged, merge_raise=merge_raise)
     print("path_speed_merge: raises", {int(c): int((merge_raise == c).sum()) for c in np.unique(merge_raise)})
-    path = os.path.join(HERE, "speed_backend.npz")
+    path = os.path.join(OUT, "speed_backend.npz")
     np.savez_compressed(path, **g)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

@@ -1,7 +1,7 @@
 """Import the *actual reference* (read-only tree at /root/reference) in this container.
 
-Used only by ``make_golden.py`` (fixture generation) and by the optional live
-cross-check test that is skipped when /root/reference is absent (it never exists on the
+Used only by the ``make_golden*.py`` scripts (fixture generation) and by the live
+cross-check (tests/test_reference_live.py), which is skipped when /root/reference is absent (it never exists on the
 GPU box).  Nothing here is copied from the reference: we only register two stub modules
 so that its ``import carla`` / ``import cvxopt`` lines succeed:
 

@@ -309,3 +309,112 @@ def test_planning_loop_policy_for_refused_requests():
         answer_refused(None, 8, 11, None, "previous")
     with pytest.raises(ValueError, match="on_infeasible"):
         answer_refused(None, 8, 11, prev, "whatever")
+
+
+def test_repeated_trajectories_are_logged_and_bounded(caplog):
+    """service.RefusalPolicy: every repeat of the previous trajectory is a WARNING with its count, a valid reply resets the
+    count, and the request after max_repeats consecutive repeats raises instead of sending a stale trajectory again."""
+    import logging
+    from emplanner_carla_amd.service import RefusalPolicy
+    good = ([(1.0, 1.0, 0.0, 0.0)], [9], [2.0], [0.25])
+    pol = RefusalPolicy("previous", max_repeats=3)
+    assert pol.answer(good, 0, 9) is good
+    with caplog.at_level(logging.WARNING, logger="emplanner_carla_amd.service"):
+        for k in range(3):
+            assert pol.answer(None, 8, 20 + k) == (good[0], [20 + k], good[2], good[3])
+        assert [r.getMessage().count(f"repeat {k + 1} of at most 3") for k, r in enumerate(caplog.records)] == [1, 1, 1]
+        with pytest.raises(ValueError, match="4 requests in a row"):
+            pol.answer(None, 8, 30)
+    assert pol.answer(good, 0, 31) is good and pol.repeats == 0
+    assert pol.answer(None, 16, 32)[1] == [32] and pol.repeats == 1
+    with pytest.raises(ValueError):
+        RefusalPolicy("raise").answer(None, 8, 1)
+
+
+def _callable_args(fn):
+    """[name, default] pairs of a Python callable in the fixture's form (defaults as VALUES here)."""
+    import inspect
+    out = []
+    for name, p in inspect.signature(fn).parameters.items():
+        if p.kind is p.VAR_POSITIONAL:
+            name = "*" + name
+        elif p.kind is p.VAR_KEYWORD:
+            name = "**" + name
+        out.append((name, p.default))
+    return out
+
+
+def _same_default(got, want_src):
+    import inspect
+    if want_src is None:
+        return got is inspect.Parameter.empty
+    if got is inspect.Parameter.empty:
+        return False
+    want = eval(want_src, {"np": np, "math": __import__("math")})      # literals and arithmetic of literals only
+    if isinstance(want, float) or isinstance(got, float):
+        return float(got) == float(want)
+    return got == want and type(got) is type(want)
+
+
+def test_dropin_surface_matches_the_reference_signature_fixture():
+    """tests/golden/signatures.json (written from the reference's source by tests/golden/make_signatures.py): every function
+    and every class method the reference's planner / controller modules define exists in the drop-in module under the same
+    name, with the same argument names in the same order and the same defaults.  A drop-in may ADD trailing keyword
+    arguments with defaults (speed_DP's reference_behaviour); it may not rename, reorder or drop anything.  The controller
+    module is scope "input_side" (out of scope; section 8f row 3 mirrors the lateral controllers'
+    constructor, cal_vehicle_info and _control): there, whatever the drop-in defines must be the reference's."""
+    import importlib
+    import json
+    sig = json.load(open(os.path.join(ROOT, "tests", "golden", "signatures.json")))
+    assert set(sig) == {"planner/path_planning.py", "planner/planning_utils.py", "planner/speed_planning_test.py",
+                        "controller/controller.py"}
+    problems, checked = [], 0
+
+    def compare(where, fn, want):
+        got = _callable_args(fn)
+        if len(got) < len(want):
+            problems.append(f"{where}: {len(got)} arguments, the reference has {len(want)}")
+            return
+        for (gn, gd), (wn, wd) in zip(got, want):
+            if gn != wn:
+                problems.append(f"{where}: argument {gn!r} where the reference has {wn!r}")
+            elif not _same_default(gd, wd):
+                problems.append(f"{where}: default of {gn!r} is {gd!r}, the reference's is {wd}")
+        import inspect
+        for gn, gd in got[len(want):]:
+            if gd is inspect.Parameter.empty and not gn.startswith("*"):
+                problems.append(f"{where}: extra argument {gn!r} without a default")
+
+    import inspect
+    for rel, entry in sig.items():
+        mod = importlib.import_module(entry["dropin"])
+        full = entry["scope"] == "full"
+        for name, want in entry["functions"].items():
+            fn = getattr(mod, name, None)
+            if fn is None:
+                problems.append(f"{rel}: {name} is missing")
+                continue
+            compare(f"{rel}:{name}", fn, want)
+            checked += 1
+        for cname, methods in entry["classes"].items():
+            cls = getattr(mod, cname, None)
+            if cls is None:
+                if full:
+                    problems.append(f"{rel}: class {cname} is missing")
+                continue
+            for mname, want in methods.items():
+                m = getattr(cls, mname, None)
+                if m is None or (not full and mname not in vars(cls)):
+                    if full:
+                        problems.append(f"{rel}: {cname}.{mname} is missing")
+                    continue
+                compare(f"{rel}:{cname}.{mname}", m, want)
+                checked += 1
+        if not full:      # nothing public in the drop-in that the reference does not have
+            for cname, cls in vars(mod).items():
+                if inspect.isclass(cls) and cls.__module__ == mod.__name__:
+                    assert cname in entry["classes"], f"{rel}: the drop-in defines a class {cname} the reference lacks"
+                    extra = [m for m in vars(cls) if callable(vars(cls)[m]) and m not in entry["classes"][cname]]
+                    assert not extra, f"{rel}: {cname} defines {extra}, which the reference lacks"
+    assert not problems, "\n".join(problems)
+    assert checked >= 45

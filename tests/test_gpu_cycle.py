@@ -25,7 +25,7 @@ GOLD = {"cfg1": (S.CFG1, "cycle_cfg1_20x5_0obs.npz", {}),
 
 @pytest.fixture(scope="module")
 def planner():
-    from conftest import make_planner
+    from tests.conftest import make_planner
     p = make_planner(0)
     yield p
     p.close()

@@ -33,7 +33,7 @@ SHAPES = [  # row, col, sample_s, sample_l, res, n_obs
 
 @pytest.fixture(scope="module")
 def planner():
-    from conftest import make_planner
+    from tests.conftest import make_planner
     p = make_planner(0)
     yield p
     p.close()

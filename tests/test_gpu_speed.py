@@ -32,6 +32,24 @@ def test_st_graph_bit_exact_vs_reference(pl):
         np.testing.assert_array_equal(out[i][0], g["graph_mid_out"][i])
 
 
+def test_start_condition_vs_reference(pl):
+    """calc_speed_planning_start_condition (:23-35): the batched entry point and the drop-in function against the imported
+    reference's outputs.  The projection of a velocity ACROSS the heading cancels to ~1e-16 in the reference, so the bar
+    is relative to the operands (|v|), which is what 1e-6 of a sum of two products can mean."""
+    g = load_golden("speed.npz")
+    x, want = g["start_in"], g["start_out"]
+    s1, s2 = pl.speed_start_condition(*[np.ascontiguousarray(x[:, i]) for i in range(5)])
+    assert_rel(s1, want[:, 0], 1e-13, scale=float(np.abs(x[:, :2]).max()))
+    assert_rel(s2, want[:, 1], 1e-13, scale=float(np.abs(x[:, 2:4]).max()))
+    assert s1[0] == 7.5 and s2[0] == 0.3 and s1[1] == 0.0 and s2[1] == 0.0
+    from emplanner_carla_amd.planner import speed_planning_test as sp
+    for k in (0, 2, 3, 17):
+        a, b = sp.calc_speed_planning_start_condition(*x[k])
+        assert a == s1[k] and b == s2[k]
+    e1, e2 = pl.speed_start_condition(*[np.zeros(0)] * 5)
+    assert e1.shape == (0,) and e2.shape == (0,)
+
+
 def test_collision_cost_vs_reference(pl):
     g = load_golden("speed.npz")
     got = pl.st_collision_cost(10000000, g["coll_d"])

@@ -8,7 +8,7 @@
 
 #include "emp_dp_kernels.h"
 
-__global__ void check(unsigned long long per_thread, unsigned long long* bad, double* worst) {
+__global__ void check(unsigned long long per_thread, unsigned long long* bad, unsigned long long* done) {
     const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long total = (unsigned long long)gridDim.x * blockDim.x * per_thread;
     unsigned long long mine = 0;
@@ -31,18 +31,36 @@ __global__ void check(unsigned long long per_thread, unsigned long long* bad, do
         }
     }
     if (mine) atomicAdd(bad, mine);
+    if (threadIdx.x == 0) atomicAdd(done, 1ull);      // the host checks that every block ran to its end
 }
 
+#define CHECK(call)                                                                        \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            printf("%s failed: %s\n", #call, hipGetErrorString(e_));                       \
+            return 2;                                                                      \
+        }                                                                                  \
+    } while (0)
+
 int main() {
-    unsigned long long* bad;
-    double* worst;
-    hipMalloc(&bad, 8);
-    hipMalloc(&worst, 8);
-    hipMemset(bad, 0, 8);
+    unsigned long long *bad, *done;
+    CHECK(hipMalloc(&bad, 8));
+    CHECK(hipMalloc(&done, 8));
+    CHECK(hipMemset(bad, 0, 8));
+    CHECK(hipMemset(done, 0, 8));         // a kernel that never ran cannot read as "0 differences": `done` counts its blocks
     const unsigned long long per_thread = 1ull << 12;
-    hipLaunchKernelGGL(check, dim3(1 << 12), dim3(256), 0, 0, per_thread, bad, worst);
-    unsigned long long h = ~0ull;
-    hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
-    printf("operands checked: %llu, results differing from IEEE division: %llu\n", 2ull * (1ull << 12) * 256 * per_thread, h);
+    const unsigned blocks = 1u << 12;
+    hipLaunchKernelGGL(check, dim3(blocks), dim3(256), 0, 0, per_thread, bad, done);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    unsigned long long h = ~0ull, d = 0;
+    CHECK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(&d, done, 8, hipMemcpyDeviceToHost));
+    if (d != blocks) {
+        printf("only %llu of %u blocks ran\n", d, blocks);
+        return 2;
+    }
+    printf("operands checked: %llu, results differing from IEEE division: %llu\n", 2ull * blocks * 256 * per_thread, h);
     return h != 0;
 }
