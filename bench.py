@@ -31,8 +31,13 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 with every kernel bracketed by events, one batch in flight
   roofline_dp_edge, dp_only   the FP64-issue-bound edge kernel (algorithmic flops of SURVEY.md 8d AND the executed
                 wave-level instruction / active-lane counts of the committed SQ counter profile), and the DP alone
-  fully_planned_cycles_per_s  value x the fraction of scenes whose cycle ran to the end (the rest are refused: walls,
-                blocked corridors, infeasible QPs - they were computed too, and are part of `value`)
+  value / all_scenes_cycles_per_s   `value` counts the scenes whose cycle ran to the end (scenes_fully_planned_frac of the batch;
+                the rest are refused at the end of the cycle: walls, blocked corridors, infeasible QPs - they were computed
+                too and cost the same time); all_scenes_cycles_per_s = scenes per step / ms_per_step
+  overlapped_sweep_leg, dram_leg, cfg5_leg, latency_leg   (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them)
+                short secondary measurements after the headline: the rounds 1-3 pipeline with the sweep free to overlap the
+                back stage; 32768 scenes (the edge tensor streams from HBM instead of the Infinity Cache); BASELINE
+                configs[4] (120x21 lattice + S-T speed DP) on 4096 scenes; configs[1] (one scene per synchronous call)
 """
 from __future__ import annotations
 
@@ -194,6 +199,129 @@ def latency_main(args):
     pl.close()
 
 
+def _device_inputs(torch, S, cfg, seeds, device, dist_name="corridor"):
+    batch = S.make_batch(seeds, cfg, dist=dist_name)
+    P = batch.ref.shape[1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return dict(ref_line=t(batch.ref), n_ref=t(np.full(len(batch.seeds), P, np.int32)), origin_xy=t(batch.origin_xy),
+                start_xy=t(batch.start_xy), start_v=t(batch.start_v), start_a=t(batch.start_a),
+                obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
+
+
+def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, dist_name="corridor", speed=False):
+    """A short, separately reported measurement of ANOTHER workload inside the default run (the driver's one command then
+    observes it too): `untimed` steps, a fence, `steps` timed steps with the sweep bracketed by events, a fence - the
+    headline's own procedure - then three steps with every kernel bracketed, one batch in flight, for the kernel table.
+    Staged pipeline with the library's default options.  Never raises: a failure is reported in the leg."""
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params, speed_dp_params
+    t_leg = time.perf_counter()
+    try:
+        inputs = _device_inputs(torch, S, cfg, range(scenes), device, dist_name)
+        st_inputs = None
+        if speed:
+            dyn = S.make_dynamic_batch(range(scenes), 16)
+            st_inputs = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in dyn[:4]], torch.from_numpy(np.ascontiguousarray(dyn[4])).to(device)
+        p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+        sdp, M = speed_dp_params(), max_path_points(p)
+        pl.set_timing(False)
+        pl.set_pipeline(1)
+        ts = pl.torch_stream()
+
+        def step():
+            with torch.cuda.stream(ts):
+                res = pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
+                if speed:
+                    pl.set_fence(False)
+                    sets = pl.st_graph(*st_inputs[0])
+                    pl.speed_dp(sdp, *sets, st_inputs[1], tables=False)
+                    pl.set_fence(True)
+            return res
+
+        def fence():
+            pl.synchronize()
+            torch.cuda.synchronize()
+
+        for _ in range(untimed):
+            step()
+        fence()
+        pl.set_timing(True, only="dp_sweep")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        fence()
+        el = time.perf_counter() - t0
+        sweep_ms = pl.kernel_ms("dp_sweep")
+        pl.set_timing(False)
+        pl.set_pipeline(0)
+        step()
+        fence()
+        pl.set_timing(True)
+        for _ in range(3):
+            step()
+        fence()
+        kernels = {n: round(pl.kernel_ms(n), 6) for n in ("project", "dp_edge", "dp_sweep", "dp_enrich", "path_qp", "to_cartesian",
+                                                          "st_graph", "speed_dp") if pl.kernel_ms(n) >= 0}
+        pl.set_timing(False)
+        ok = float(((res.status.cpu().numpy() & ~1) == 0).mean())
+        E = cfg.row + (cfg.col - 1) * cfg.row ** 2
+        bytes_dp = (8 * E + 4 * cfg.row * cfg.col + 4 * cfg.col) * scenes
+        rate = scenes * steps / el
+        out = {"workload": f"{scenes} scenes, lattice col={cfg.col} x row={cfg.row}, {cfg.n_obs} obstacles"
+                           + (", + generate_st_graph and the S-T speed DP (40x16 grid, 16 dynamic-obstacle slots)" if speed else "")
+                           + "; full planning cycle, inputs resident in HBM, staged pipeline",
+               "steps": steps, "untimed_steps": untimed, "ms_per_step": round(el / steps * 1e3, 4),
+               "fully_planned_cycles_per_s": round(rate * ok, 1), "all_scenes_cycles_per_s": round(rate, 1),
+               "scenes_fully_planned_frac": round(ok, 4),
+               "sweep": {"mean_launch_us": round(sweep_ms * 1e3, 2), "algorithmic_bytes_per_launch": bytes_dp,
+                         "achieved_gbs": round(bytes_dp / (sweep_ms * 1e-3) / 1e9, 1),
+                         "frac": round(bytes_dp / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_alone": (round(bytes_dp / (kernels["dp_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if "dp_sweep" in kernels else None)},
+               "kernels_ms_one_batch_in_flight": kernels}
+        if speed and "speed_dp" in kernels:
+            out["speed_dp_us"] = round(kernels["speed_dp"] * 1e3, 1)
+        out["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
+        return out
+    except Exception as exc:                                    # a secondary leg never costs the headline
+        try:
+            pl.set_timing(False)
+            pl.set_pipeline(0)
+        except Exception:
+            pass
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
+def latency_leg(pl, torch, device, calls=50, dist_name="corridor"):
+    """BASELINE configs[1] inside the default run: ONE scene on the 40x9 lattice, one synchronous call per cycle."""
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params
+    t_leg = time.perf_counter()
+    try:
+        cfg = S.CFG2
+        dev = _device_inputs(torch, S, cfg, [7], device, dist_name)
+        p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+        M = max_path_points(p)
+        pl.set_timing(False)
+        pl.set_pipeline(0)
+        for _ in range(10):
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **dev)
+            pl.synchronize()
+        lat = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **dev)
+            pl.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.sort(np.asarray(lat))
+        return {"workload": "BASELINE configs[1]: one scene, 40x9 lattice, 8 obstacles, one synchronous call per cycle, inputs resident in HBM",
+                "calls": calls, "ms_per_cycle_mean": round(float(lat.mean()), 4), "ms_per_cycle_median": round(float(np.median(lat)), 4),
+                "ms_per_cycle_p95": round(float(lat[int(0.95 * (calls - 1))]), 4), "scene_status": int(r.status.cpu().numpy()[0]),
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +353,11 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="emp_set_option before the pipeline is set up (include/emplanner.h emp_option; names: "
                          "emplanner_carla_amd._lib.OPTIONS), e.g. --opt sweep_exclusive=1 --opt back_stream_cus=128; repeatable")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the secondary legs of the default run (N = 1, config cfg2, default batch): overlapped_sweep_leg "
+                         "(the same steps with the sweep left to overlap the back stage, --opt sweep_exclusive=0), dram_leg "
+                         "(32768 scenes: the edge tensor streams from HBM), cfg5_leg (BASELINE configs[4], 4096 scenes), "
+                         "latency_leg (configs[1], one scene per call)")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -352,6 +485,7 @@ def main():
         elapsed = float(el.item())
 
     sweep_ms, sweep_launches = pl.kernel_ms("dp_sweep"), pl.kernel_launches("dp_sweep")
+    sweep_samples = pl.kernel_samples("dp_sweep") * 1e3 if sweep_launches > 0 else None
     # ---- what a first multi-GPU run needs to explain itself (N > 1, or the N > 1 code forced onto one GPU) -------------
     diag = None
     if gather_path:
@@ -410,7 +544,7 @@ def main():
         a_el = time.perf_counter() - a0
         a_sweep = pl.kernel_ms("dp_sweep")
         alt = {"pipeline": "off" if amode == 0 else "staged" if amode == 1 else f"{amode} lanes", "batches_in_flight": pl.in_flight,
-               "value": round(total * args.steps / a_el, 1), "unit": "planning cycles/s",
+               "all_scenes_cycles_per_s": round(total * args.steps / a_el, 1), "unit": "planning cycles/s",
                "ms_per_step": round(a_el / args.steps * 1e3, 4), "sweep_mean_launch_us": round(a_sweep * 1e3, 2)}
         pl.set_timing(False)
     # Per-kernel breakdown: a separate diagnostic pass AFTER the timed region, every kernel bracketed, one batch in
@@ -431,6 +565,46 @@ def main():
         if ms >= 0:
             kernels[name] = round(ms, 6)
     pl.set_timing(False)
+
+    # ---- secondary legs (N = 1, the default workload only): other workloads, observed by the same command, after the headline
+    # and its diagnostic pass; each is a short measurement of its own and never touches the headline's numbers
+    legs = {}
+    if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096)
+            and args.dp_mode == "two_kernel" and pmode == 1 and args.scene_dist == "corridor"):
+        # (a) the headline's steps with the sweep free to overlap the previous batch's back stage (rounds 1-3)
+        if "sweep_exclusive" not in options:
+            try:
+                fence()
+                pl.set_timing(False)
+                old_excl = pl.get_option("sweep_exclusive")
+                pl.set_option("sweep_exclusive", 0)
+                pl.set_pipeline(1)
+                for _ in range(60):
+                    step()
+                fence()
+                pl.set_timing(True, only="dp_sweep")
+                o0 = time.perf_counter()
+                for _ in range(args.steps):
+                    o_out, o_res = step()
+                fence()
+                o_el = time.perf_counter() - o0
+                o_sweep = pl.kernel_ms("dp_sweep")
+                pl.set_timing(False)
+                pl.set_option("sweep_exclusive", old_excl)
+                pl.set_pipeline(0)
+                o_bytes = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * count
+                legs["overlapped_sweep_leg"] = {
+                    "options": {"sweep_exclusive": 0}, "steps": args.steps, "ms_per_step": round(o_el / args.steps * 1e3, 4),
+                    "all_scenes_cycles_per_s": round(total * args.steps / o_el, 1),
+                    "sweep_mean_launch_us": round(o_sweep * 1e3, 2),
+                    "sweep_frac": round(o_bytes / (o_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "the sweep of step k is not held back and overlaps the densification and path QP of step k-1 (the "
+                            "pipeline of rounds 1-3): a faster step, a slower sweep"}
+            except Exception as exc:
+                legs["overlapped_sweep_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
+        legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device)
+        legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, speed=True)
+        legs["latency_leg"] = latency_leg(pl, torch, device)
 
     # outcome statistics of the last step (sanity: the work was really done); every rank looks at its own shard and the
     # fractions are averaged over the ranks
@@ -459,7 +633,12 @@ def main():
                     "traffic": prof["hbm_bytes_per_launch"] if prof else None,
                     "traffic_source": prof["source"] if prof else None,
                     "algorithmic_bytes_per_launch": bytes_dp, "launches_timed": sweep_launches,
-                    "mean_launch_us": round(sweep_ms * 1e3, 2)}
+                    "mean_launch_us": round(sweep_ms * 1e3, 2),
+                    "launch_us_min_median_max": [round(float(v), 2) for v in (sweep_samples.min(), np.median(sweep_samples), sweep_samples.max())]
+                    if sweep_samples is not None and len(sweep_samples) else None,
+                    # the same kernel with nothing beside it: the diagnostic pass after the timed region, one batch in flight
+                    "frac_alone": (round(bytes_dp / (kernels["dp_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if "dp_sweep" in kernels else None),
+                    "alone_mean_launch_us": (round(kernels["dp_sweep"] * 1e3, 2) if "dp_sweep" in kernels else None)}
         if alt and alt["sweep_mean_launch_us"] > 0:
             alt["sweep_roofline_frac"] = round(bytes_dp / (alt["sweep_mean_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         # Secondary figures from the diagnostic pass (event-bracketed kernels; not part of the timed region):
@@ -477,7 +656,7 @@ def main():
             # as a secondary key, it is not a roofline.
             e = {"kernel": "dp_edge_kernel", "bound": "fp64_valu_issue", "frac": None, "unit": "fraction of the FP64 issue slots doing work",
                  "mean_launch_us": round(kernels["dp_edge"] * 1e3, 2), "source": "diagnostic pass after the timed region",
-                 "algorithmic_tflops": round(tf, 2), "algorithmic_frac_of_vector_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                 "algorithmic_tflops": round(tf, 2), "algorithmic_tflops_over_vector_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
                  "algorithmic_flops_per_launch": flops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
             if cprof:
                 busy = cprof.get("valu_issue_busy_frac")
@@ -500,9 +679,15 @@ def main():
             e_st = 40 + 15 * 40 * 40
             flops = e_st * (30 + 5 * 16 * 45) * count
             tf = flops / (kernels["speed_dp"] * 1e-3) / 1e12
-            e = {"kernel": "speed_dp_kernel", "bound": "fp64_valu_issue", "achieved": round(tf, 2),
-                 "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s (ALGORITHMIC flops with all 16 slots present; far fewer are executed)",
-                 "frac": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), "algorithmic_flops_per_launch": flops,
+            # `frac` is the counter-backed useful-issue fraction (null without a committed SQ pass of this workload); the
+            # algorithmic count reads MORE than the vector peak because the kernel prunes most of what it prices - a
+            # secondary key, never a fraction of anything
+            e = {"kernel": "speed_dp_kernel", "bound": "fp64_valu_issue", "frac": None,
+                 "unit": "fraction of the FP64 issue slots doing work", "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                 "algorithmic_tflops": round(tf, 2), "algorithmic_tflops_over_vector_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+                 "algorithmic_note": "SURVEY 8(d)'s flop count with all 16 obstacle slots present; the kernel skips the 92 % of "
+                                     "(sample, obstacle) pairs out of reach, so this is not a roofline",
+                 "algorithmic_flops_per_launch": flops,
                  "mean_launch_us": round(kernels["speed_dp"] * 1e3, 1), "speed_dps_per_s": round(count / (kernels["speed_dp"] * 1e-3), 1),
                  "edges_per_dp": e_st, "hbm_bytes_per_scene": 16 * 4 * 8 + 8 + 2 * 16 * 8 + 8,
                  "source": "diagnostic pass after the timed region (one batch in flight); tables stay in LDS (emp_st_kernels.h)"}
@@ -511,21 +696,25 @@ def main():
                 e.update(executed_wave_instructions_valu=cprof["insts_valu"], active_lane_frac=cprof["lanes_active_frac"],
                          executed_lane_ops=int(cprof["insts_valu"] * 64 * cprof["lanes_active_frac"]),
                          valu_issue_busy_frac=cprof["valu_issue_busy_frac"],
+                         frac=round(cprof["valu_issue_busy_frac"] * cprof["lanes_active_frac"], 3),
                          useful_issue_frac=round(cprof["valu_issue_busy_frac"] * cprof["lanes_active_frac"], 3),
                          mean_waves_per_simd=cprof["mean_waves_per_simd"], counters_source=cprof["source"])
             extra["roofline_speed_dp"] = e
-        value = total * args.steps / elapsed
+        all_scenes_rate = total * args.steps / elapsed
+        value = all_scenes_rate * ok_frac                  # what "planning cycles/sec" means: cycles planned to the end
         gather_note = ""
         if world > 1:
             gather_note = f"; + RCCL {'gather to rank 0' if args.gather == 'rank0' else 'all_gather'} of {args.records} result records"
         line = {
             "metric": ("planning cycles/sec (DP+QP, 40x9 S-L lattice, 8 obs)" if not wide else
                        "planning cycles/sec (DP+QP on the 120x21 S-L lattice, 16 obs, + S-T speed DP 40x16, 16 dynamic obstacles)"),
-            "metric_note": "value counts every scene of the batch: each one runs the whole cycle, and the scenes whose path QP "
-                           "turns out infeasible (walls and blocked corridors the generator puts there on purpose; "
-                           "scenes_fully_planned_frac) are refused with a status bit at the end of it.  "
-                           "fully_planned_cycles_per_s counts only the scenes planned to the end",
+            "metric_note": "value counts the scenes PLANNED TO THE END: scenes per step x scenes_fully_planned_frac / ms_per_step.  "
+                           "Every scene of the batch runs the whole cycle; those whose path QP turns out infeasible (walls and "
+                           "blocked corridors the generator puts there on purpose) are refused with a status bit at the end of "
+                           "it and are not counted, although they cost the same time: all_scenes_cycles_per_s = scenes per "
+                           "step / ms_per_step is the rate at which scenes go through the pipeline",
             "value": round(value, 1),
+            "all_scenes_cycles_per_s": round(all_scenes_rate, 1),
             "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "rccl_world_size": (dist.get_world_size() if world > 1 else None),     # what the process group itself reports
             "process_group_backend": (dist.get_backend() if world > 1 else None),
@@ -546,7 +735,8 @@ def main():
             "kernels_ms": kernels,
             "alt_pipeline": alt,
             "scenes_fully_planned_frac": round(ok_frac, 4),
-            "fully_planned_cycles_per_s": round(value * ok_frac, 1),
+            "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "enrich_on_front", "path_qp_form")}, **options},
+            **legs,
         }
         if gather_path:
             line["gather"] = {"mode": args.gather, "records": args.records, "doubles_per_scene": sg.width,

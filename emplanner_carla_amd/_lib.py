@@ -41,7 +41,10 @@ EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 
 # emp_option (include/emplanner.h): per-context tuning / A-B / test-hook values - the library reads no environment variable
 OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
-           "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9}
+           "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9,
+           "enrich_on_front": 10}
+#: the values a fresh context holds (everything else is 0)
+OPTION_DEFAULTS = {"st_order": 1, "sweep_exclusive": 2}
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2
@@ -125,10 +128,12 @@ PROTOTYPES = {
     "emp_set_option": (C.c_int, [_vp, _i32, _i32]),
     "emp_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
     "emp_sweep_clock_mhz": (_f64, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
+    "emp_sweep_probe_spans": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
     "emp_kernel_ms": (_f64, [_vp, C.c_char_p]),
     "emp_kernel_launches": (C.c_int, [_vp, C.c_char_p]),
+    "emp_kernel_samples": (C.c_int, [_vp, C.c_char_p, _vp, _i32]),
     "emp_edge_tensor_elems": (_u64, [C.POINTER(DpParams), _i32, C.c_int]),
     "emp_dp_edge_costs": (C.c_int, [_vp, C.POINTER(DpParams), _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                     C.c_int]),

@@ -289,6 +289,15 @@ class Planner:
     def kernel_launches(self, name: str) -> int:
         return int(self._lib.emp_kernel_launches(self._h, name.encode()))
 
+    def kernel_samples(self, name: str) -> np.ndarray:
+        """The individual durations (ms) behind ``kernel_ms``, in launch order."""
+        n = self.kernel_launches(name)
+        out = np.zeros(max(n, 1), np.float64)
+        got = int(self._lib.emp_kernel_samples(self._h, name.encode(), out.ctypes.data, n))
+        if got < 0:
+            raise RuntimeError("emp_kernel_samples failed")
+        return out[:min(n, got)]
+
     @property
     def stream(self):
         """Raw hipStream_t of the context."""
@@ -322,7 +331,7 @@ class Planner:
     def set_option(self, name, value: int):
         """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` ("path_qp_form",
         "cartesian_form", "smooth_force_fallback", "edge_block", "sweep_variant", "fused_columns", "st_order",
-        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe") or the option's number.  Takes effect at the next call
+        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe", "enrich_on_front") or the option's number.  Takes effect at the next call
         ("back_stream_cus": at the next ``set_pipeline``).  The library reads no environment variable."""
         key = L.OPTIONS[name] if isinstance(name, str) else int(name)
         self._check(self._lib.emp_set_option(self._h, key, int(value)))
@@ -339,6 +348,14 @@ class Planner:
         mean_us, max_us = C.c_double(0.0), C.c_double(0.0)
         mhz = float(self._lib.emp_sweep_clock_mhz(self._h, C.byref(mean_us), C.byref(max_us)))
         return None if mhz < 0 else (mhz, float(mean_us.value), float(max_us.value))
+
+    def sweep_probe_spans(self):
+        """With option "sweep_clock_probe" on: (us between the first and the last wavefront START of a sweep launch, us from
+        the first wavefront's start to the last wavefront's end), averaged over the recorded launches; None when nothing
+        was recorded."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        rc = int(self._lib.emp_sweep_probe_spans(self._h, C.byref(a), C.byref(b)))
+        return None if rc != 0 else (float(a.value), float(b.value))
 
     def torch_result_stream(self):
         """The stream on which the latest cycle's outputs become complete (its lane in pipelined mode)."""

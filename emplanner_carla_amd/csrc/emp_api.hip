@@ -388,11 +388,13 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
         if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
         if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
+        if (ln.ev_qp) (void)hipEventDestroy(ln.ev_qp);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
     if (ctx->clock_probe.p) (void)hipFree(ctx->clock_probe.p);
     if (ctx->clock_probe_done) (void)hipEventDestroy(ctx->clock_probe_done);
+    if (ctx->sweep_marker) (void)hipEventDestroy(ctx->sweep_marker);
     for (auto& kv : ctx->pair_tables)
         if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
     for (auto& kv : ctx->named)
@@ -538,6 +540,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         if (!ln.ev_front) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_front, hipEventDisableTiming));
         if (!ln.ev_tail) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
         if (!ln.ev_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+        if (!ln.ev_qp) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_qp, hipEventDisableTiming));
     }
     const int want_cus = ctx->opt[EMP_OPT_BACK_STREAM_CUS] > 0 && ctx->opt[EMP_OPT_BACK_STREAM_CUS] < ctx->cu_count
                              ? ctx->opt[EMP_OPT_BACK_STREAM_CUS] : 0;
@@ -563,7 +566,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         }
         ctx->back_stream_cus = want_cus;
     }
-    for (auto& ln : ctx->lanes) ln.done_valid = false;       // everything was drained above
+    for (auto& ln : ctx->lanes) ln.done_valid = ln.qp_valid = false;       // everything was drained above
     ctx->pipe_mode = m;
     ctx->lane = 0;
     return EMP_OK;
@@ -589,8 +592,9 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_CARTESIAN_FORM:
         case EMP_OPT_SMOOTH_FORCE_FALLBACK:
         case EMP_OPT_ST_ORDER:
-        case EMP_OPT_SWEEP_EXCLUSIVE:
+        case EMP_OPT_ENRICH_ON_FRONT:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
+        case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
         case EMP_OPT_SWEEP_VARIANT: ok = value >= 0 && value <= 5; break;
         case EMP_OPT_FUSED_COLUMNS: ok = value >= 0 && value <= 64; break;
@@ -628,6 +632,30 @@ double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_
     if (mean_wave_us) *mean_wave_us = ticks_r / (double)waves / 100.0;      // 100 MHz reference
     if (max_wave_us) *max_wave_us = longest / 100.0;
     return ticks_c / ticks_r * 100.0;
+}
+
+int emp_sweep_probe_spans(emp_ctx* ctx, double* start_spread_us, double* first_start_to_last_end_us) {
+    if (!ctx || !ctx->clock_probe.p || !ctx->clock_probe_done || ctx->clock_probe_tiles <= 0 || ctx->probe_launches <= 0) return EMP_ERR_INVALID;
+    if (hipEventSynchronize(ctx->clock_probe_done) != hipSuccess) return EMP_ERR_HIP;
+    const long slots = ctx->probe_launches < emp_ctx::kProbeSlots ? ctx->probe_launches : emp_ctx::kProbeSlots;
+    const size_t tiles = (size_t)ctx->clock_probe_tiles;
+    std::vector<unsigned long long> h((size_t)slots * tiles * 4);
+    if (hipMemcpy(h.data(), ctx->clock_probe.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return EMP_ERR_HIP;
+    double spread = 0.0, span = 0.0;
+    for (long sl = 0; sl < slots; ++sl) {
+        unsigned long long first = ~0ull, last_start = 0, last_end = 0;
+        for (size_t t = 0; t < tiles; ++t) {
+            const unsigned long long* o = &h[((size_t)sl * tiles + t) * 4];
+            if (o[2] < first) first = o[2];
+            if (o[2] > last_start) last_start = o[2];
+            if (o[3] > last_end) last_end = o[3];
+        }
+        spread += (double)(last_start - first);
+        span += (double)(last_end - first);
+    }
+    if (start_spread_us) *start_spread_us = spread / (double)slots / 100.0;
+    if (first_start_to_last_end_us) *first_start_to_last_end_us = span / (double)slots / 100.0;
+    return EMP_OK;
 }
 
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
@@ -688,6 +716,20 @@ double emp_kernel_ms(emp_ctx* ctx, const char* kernel) {
         total += (double)ms;
     }
     return total / (double)it->second.used;
+}
+
+int emp_kernel_samples(emp_ctx* ctx, const char* kernel, double* ms, int32_t cap) {
+    if (!ctx || !kernel || (cap > 0 && !ms) || cap < 0) return -1;
+    auto it = ctx->events.find(kernel);
+    if (it == ctx->events.end()) return 0;
+    const size_t n = it->second.used;
+    for (size_t i = 0; i < n && i < (size_t)cap; ++i) {
+        auto& pr = it->second.pairs[i];
+        float v = 0.f;
+        if (hipEventSynchronize(pr.second) != hipSuccess || hipEventElapsedTime(&v, pr.first, pr.second) != hipSuccess) return -1;
+        ms[i] = (double)v;
+    }
+    return (int)n;
 }
 
 // ---- DP ----------------------------------------------------------------------------------
@@ -1333,7 +1375,11 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     ctx->sweep_wait = nullptr;
     if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE]) {       // the previous call's back stage: its lane is the one before ours
         emp_ctx::Lane& prev = ctx->lanes[(ctx->lane + ctx->lanes_in_use() - 1) % ctx->lanes_in_use()];
-        if (prev.done_valid) ctx->sweep_wait = prev.ev_done;
+        if (ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE] == 2) {        // ... only its densification and path QP: the sweep runs beside the Cartesian tail
+            if (prev.qp_valid) ctx->sweep_wait = prev.ev_qp;
+        } else if (prev.done_valid) {
+            ctx->sweep_wait = prev.ev_done;
+        }
     }
     ctx->bt_pre = d_pre;
     ctx->bt_term = d_term;
@@ -1347,6 +1393,24 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     ctx->bt_deferred = false;
     if (rc) return rc;
     const QpDev Q = make_qp_dev(q);
+    // EMP_OPT_SWEEP_EXCLUSIVE: a marker behind the sweep on the front stream.  Measured, not understood: which of two
+    // regimes the two queues settle in depends on it.  With it the kernels keep the durations of the overlapped step (edge
+    // 198 us, path QP 140, Cartesian 70, sweep 19) and the step takes 0.264 ms (mode 2) / 0.277 (mode 1); without it the
+    // edge kernel runs at its stand-alone 147 us, starves the path QP beside it (250 us) and the step takes 0.32 - 0.35 ms
+    // (profiles/r04_sweep/README.md).  The clock probe's event did the same by accident, which is how this was found.
+    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE]) {
+        if (!ctx->sweep_marker) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->sweep_marker, hipEventDisableTiming));
+        EMP_HIP(ctx, hipEventRecord(ctx->sweep_marker, ctx->stream));
+    }
+    // EMP_OPT_ENRICH_ON_FRONT: the densification kernel stays on the front stream, behind the sweep it depends on; the back
+    // stage then begins with the path QP
+    const bool enrich_front = staged && ctx->opt[EMP_OPT_ENRICH_ON_FRONT] != 0;
+    if (enrich_front) {
+        if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
+                                deferred ? d_term : nullptr, d_no, d_rows)))
+            return rc;
+        ctx->front_attached = nullptr;         // the event to wait for is the one recorded behind the densification
+    }
     if (staged) {      // the back stage (short kernels that last as long as their slowest scene) goes to the back stream
         // behind the sweep's own completion event where the launch attached one (a marker packet behind the sweep costs the
         // front queue ~5 us per step), else behind an event recorded here
@@ -1358,12 +1422,17 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, front_done, 0));
         ctx->stream = ctx->back_stream;        // ~LaneSwap puts the main stream back
     }
-    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
+    if (!enrich_front &&
+        (rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
                             deferred ? d_term : nullptr, d_no, d_rows)))
         return rc;
     if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
                            d_st)))
         return rc;
+    if (staged) {
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_qp, ctx->stream));
+        lane.ln->qp_valid = true;
+    }
     const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);
     if ((rc = dev_cycle_cartesian(ctx, B, max_ref, max_pts, path_cap, sp, d_ref, d_sm, d_nr, d_bsl, d_ps, d_pl, d_plen,
                                   d_traj, d_tlen, d_st)))

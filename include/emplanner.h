@@ -188,9 +188,15 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             4/5: nontemporal / plain loads whatever the tensor's size
  *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
  *   EMP_OPT_ST_ORDER                1        tuning           speed DP: 1 heaviest scenes first, 0 input order (same results)
- *   EMP_OPT_SWEEP_EXCLUSIVE         0        tuning           staged pipeline: 1 = the sweep of call k waits (stream-side) for
- *                                                             the back stage of call k-1, so that the HBM-bound kernel runs
- *                                                             beside nothing
+ *   EMP_OPT_SWEEP_EXCLUSIVE         2        tuning           staged pipeline, what the HBM-bound sweep of call k may run beside:
+ *                                                             2 (default) = it waits (stream-side) for call k-1's densification
+ *                                                             and path QP and overlaps only the tail of its Cartesian kernel -
+ *                                                             the sweep then streams as fast as alone (0.70 of the HBM peak at
+ *                                                             4096 scenes instead of 0.60-0.65) for ~6 % of the step;
+ *                                                             1 = it waits for the whole back stage of call k-1 (+11 %);
+ *                                                             0 = no wait, rounds 1-3 (the fastest step)
+ *   EMP_OPT_ENRICH_ON_FRONT         0        tuning           staged pipeline: 1 = the densification kernel runs on the front
+ *                                                             stream behind the sweep, the back stage begins with the path QP
  *   EMP_OPT_BACK_STREAM_CUS         0        tuning           staged pipeline: n > 0 confines the back stage's stream to n
  *                                                             compute units (hipExtStreamCreateWithCUMask, the lowest n bits
  *                                                             of the mask: spread evenly over the XCDs); 0: no mask
@@ -208,7 +214,8 @@ typedef enum emp_option {
     EMP_OPT_SWEEP_EXCLUSIVE = 7,
     EMP_OPT_BACK_STREAM_CUS = 8,
     EMP_OPT_SWEEP_CLOCK_PROBE = 9,
-    EMP_OPT_COUNT = 10
+    EMP_OPT_ENRICH_ON_FRONT = 10,
+    EMP_OPT_COUNT = 11
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
@@ -217,6 +224,11 @@ int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
  * last instruction, summed over all their wavefronts (synchronises on the latest launch); optionally (may be NULL) the mean
  * and the longest time a wavefront was resident, in microseconds.  Negative when nothing was recorded. */
 double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_us);
+/* The same probe, per launch and averaged over the recorded launches (100 MHz reference ticks, which all wavefronts share):
+ * how long after the launch's first wavefront its last wavefront started, and the time from the first wavefront's first
+ * instruction to the last wavefront's last - what is left of the launch's event-measured duration is dispatch and
+ * completion overhead outside any wavefront. */
+int emp_sweep_probe_spans(emp_ctx* ctx, double* start_spread_us, double* first_start_to_last_end_us);
 
 /* One fixed-stride record per scene for the multi-GPU gather (no reference counterpart: the reference plans one scene
  * per process; this is the result exchange of the batched form, emplanner_carla_amd/dist.py):
@@ -235,6 +247,9 @@ int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_
                                 emp_mem where);
 double emp_kernel_ms(emp_ctx* ctx, const char* kernel);
 int emp_kernel_launches(emp_ctx* ctx, const char* kernel);
+/* The individual durations behind emp_kernel_ms, in launch order: writes min(recorded, cap) values (milliseconds) to `ms`
+ * and returns how many were recorded (negative on error). */
+int emp_kernel_samples(emp_ctx* ctx, const char* kernel, double* ms, int32_t cap);
 
 /* ---- S-L lattice DP ------------------------------------------------------------------ */
 /* Layout of the materialised edge-cost tensor (two-kernel DP mode):

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", *extra]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+           *(() if "--legs" in extra else ("--no-legs",)), *[e for e in extra if e != "--legs"]]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -30,11 +31,15 @@ def test_bench_line(extra):
     # (lane mode overlaps the sweep with other batches' edge kernels: it takes two to three times as long there)
     assert d["value"] > 1e6 and (0.05 if lanes else 0.3) < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
+    # `value` is the fully planned rate: scenes per step x planned fraction / step time
+    assert abs(d["value"] - d["all_scenes_cycles_per_s"] * d["scenes_fully_planned_frac"]) <= 1e-3 * d["value"]
+    assert abs(d["all_scenes_cycles_per_s"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 2e-3 * d["all_scenes_cycles_per_s"]
+    assert d["roofline"]["frac_alone"] > 0.3 and len(d["roofline"]["launch_us_min_median_max"]) == 3
     assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else lanes or 2)
     assert d["config"]["pipeline"] == ("off" if "--no-pipeline" in extra else f"{lanes} lanes" if lanes else "staged")
     if "--alt-pipeline" in extra:      # the second timed region, in lane mode
         alt = d["alt_pipeline"]
-        assert alt["pipeline"] == "3 lanes" and alt["value"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
+        assert alt["pipeline"] == "3 lanes" and alt["all_scenes_cycles_per_s"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
     else:
         assert d["alt_pipeline"] is None
 
@@ -58,7 +63,7 @@ def test_other_bench_lines(extra, metric_part):
     if "--latency" in extra:
         assert d["higher_is_better"] is False and d["roofline"] is None and 0.05 < d["value"] < 5.0
         return
-    assert d["higher_is_better"] is True and "fully_planned_cycles_per_s" in d
+    assert d["higher_is_better"] is True and "all_scenes_cycles_per_s" in d and d["value"] <= d["all_scenes_cycles_per_s"]
     if "fused" in extra:
         assert d["roofline"] is None and "dp_fused" in d["kernels_ms"]
     else:
@@ -69,6 +74,25 @@ def test_other_bench_lines(extra, metric_part):
         assert d["scenes_fully_planned_frac"] > 0.9
     if "--gather" in extra:
         assert d["gather"]["mode"] == "all" and d["gather"]["doubles_per_scene"] == 94 and d["gather"]["records_complete_on_rank0"]
+
+
+def test_default_run_carries_the_secondary_legs():
+    """The driver's one command (no flags beyond steps / warm-up) also observes the other workloads: the rounds 1-3 pipeline
+    with the sweep overlapping the back stage, 32768 scenes (edge tensor from HBM), BASELINE configs[4] on 4096 scenes and
+    configs[1] - each a short leg behind the headline, none of which may fail or change the headline's keys."""
+    d = _run("--legs")
+    assert d["options"]["sweep_exclusive"] == 2
+    o = d["overlapped_sweep_leg"]
+    assert "error" not in o and o["options"] == {"sweep_exclusive": 0} and o["all_scenes_cycles_per_s"] > 1e6 and 0.3 < o["sweep_frac"] < 1.0
+    g = d["dram_leg"]
+    assert "error" not in g, g
+    assert g["ms_per_step"] > 4 * d["ms_per_step"] and 0.4 < g["sweep"]["frac"] < 1.0 and g["sweep"]["algorithmic_bytes_per_launch"] == 26944 * 32768
+    assert 0.8 < g["scenes_fully_planned_frac"] < 0.95
+    c = d["cfg5_leg"]
+    assert "error" not in c, c
+    assert c["speed_dp_us"] > 100 and 0.3 < c["sweep"]["frac"] < 1.0 and c["all_scenes_cycles_per_s"] > 1e5
+    lat = d["latency_leg"]
+    assert "error" not in lat and 0.05 < lat["ms_per_cycle_median"] < 5.0 and lat["calls"] == 50
 
 
 def test_bench_two_ranks_without_gather_separates_compute_scaling():

@@ -577,14 +577,21 @@ def test_unfenced_calls_overlap_the_cycles_in_flight(planner, pipe):
         planner.set_pipeline(False)
 
 
-def _benchmark_batch_under(planner, option, value):
-    """The 4096 benchmark scenes through the whole cycle with one emp_set_option value in force (restored afterwards)."""
+def _benchmark_batch_under(planner, option, value, time_kernel=None):
+    """The 4096 benchmark scenes through the whole cycle with one emp_set_option value in force (restored afterwards).
+    ``time_kernel``: also return the mean duration (ms) of that kernel over the call."""
     cfg = S.CFG2
     host = _host_inputs(S.make_batch(range(4096), cfg))
     old = planner.get_option(option)
     planner.set_option(option, value)
     try:
-        return _plan_resident(planner, cfg, host)
+        if time_kernel is None:
+            return _plan_resident(planner, cfg, host)
+        planner.set_timing(True, only=time_kernel)
+        out = _plan_resident(planner, cfg, host)
+        ms = planner.kernel_ms(time_kernel)
+        planner.set_timing(False)
+        return out, ms
     finally:
         planner.set_option(option, old)
 
@@ -611,17 +618,20 @@ def test_cartesian_tail_kernels_agree_on_the_benchmark_batch(planner):
     kernel of rounds 1-2 is EMP_OPT_CARTESIAN_FORM = 1.  Same operations per coordinate in the same order: the
     trajectories of the 4096 benchmark scenes must be BIT-identical.  Third run: EMP_OPT_SMOOTH_FORCE_FALLBACK = 1 sends every
     scene of the new kernel through its fall-back (the half-wave interior-point / active-set solvers, the whole wavefront
-    on one scene at a time) - a path no test or benchmark scene takes by itself; it must classify alike and agree to 1e-9."""
-    a = _benchmark_batch_under(planner, "cartesian_form", 0)
+    on one scene at a time) - a path no test or benchmark scene takes by itself; it must classify alike and agree to 1e-9
+    (measured on the GPU box: the fall-back converges to the same active set and its final solve performs the same
+    operations, so the trajectories come out bit-identical - which is why the proof that the hook reaches it is the kernel's
+    duration: four scenes one after the other on the whole wavefront instead of side by side)."""
+    a, ms_a = _benchmark_batch_under(planner, "cartesian_form", 0, time_kernel="to_cartesian")
     b = _benchmark_batch_under(planner, "cartesian_form", 1)
-    c = _benchmark_batch_under(planner, "smooth_force_fallback", 1)
+    c, ms_c = _benchmark_batch_under(planner, "smooth_force_fallback", 1, time_kernel="to_cartesian")
     for other in (b, c):
         assert np.array_equal(a["status"], other["status"]) and np.array_equal(a["traj_len"], other["traj_len"])
     ok = (a["status"] & ~1) == 0
     assert ok.sum() > 3000
     assert np.array_equal(a["traj"], b["traj"]), "the two kernels perform the same operations: bit-identical"
     assert np.abs(a["traj"][ok] - c["traj"][ok]).max() < 1e-9
-    assert not np.array_equal(a["traj"][ok], c["traj"][ok]), "the hook must reach the fall-back"
+    assert ms_a > 0 and ms_c > 1.3 * ms_a, f"the hook must reach the fall-back: {ms_c:.3f} ms against {ms_a:.3f} ms"
 
 
 def test_small_shards_equal_their_slice_of_the_full_batch(planner):
@@ -639,11 +649,16 @@ def test_small_shards_equal_their_slice_of_the_full_batch(planner):
         _assert_same({k: v[sl] for k, v in out.items()}, _plan_resident(planner, cfg, host, sl), f"shard {a}+{n}")
 
 
-def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner):
+@pytest.mark.parametrize("options", [{}, {"sweep_exclusive": 0}, {"sweep_exclusive": 1}, {"sweep_exclusive": 0, "enrich_on_front": 1},
+                                     {"sweep_exclusive": 2, "enrich_on_front": 1}],
+                         ids=["default", "overlapped_sweep", "exclusive_sweep", "enrich_on_front", "exclusive2_enrich_on_front"])
+def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner, options):
     """bench.py's timed region brackets the sweep with HIP events, and in staged mode the back stage is released by the
     event attached to the sweep's own dispatch - the TIMING event then (emp_api.hip: front_attached).  Consecutive calls on
     DIFFERENT batches with the events on must equal the plain calls bit for bit: a back stage that started early would
-    densify another batch's predecessor table (the bench itself, planning the same batch every step, could not tell)."""
+    densify another batch's predecessor table (the bench itself, planning the same batch every step, could not tell).
+    Every ordering option of the staged pipeline (include/emplanner.h: EMP_OPT_SWEEP_EXCLUSIVE 0 / 1 / 2 - the default is 2 -
+    and EMP_OPT_ENRICH_ON_FRONT) moves waits and kernels between the two queues: each one is held to the same bar."""
     import torch
     cfg = S.CFG2
     p, q, sp = _params(cfg)
@@ -658,6 +673,9 @@ def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner):
         r = planner.plan_cycle(p, q, sp, **ins)
         planner.synchronize()
         plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+    old = {k: planner.get_option(k) for k in options}
+    for k, v in options.items():
+        planner.set_option(k, v)
     planner.set_pipeline("staged")
     planner.set_timing(True, only="dp_sweep")
     try:
@@ -671,3 +689,5 @@ def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner):
     finally:
         planner.set_timing(False)
         planner.set_pipeline(False)
+        for k, v in old.items():
+            planner.set_option(k, v)

@@ -14,7 +14,10 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(B, P, np.int32)), origin_xy=t(batch.origin_xy), start_xy=t(batch.start_xy),
               start_v=t(batch.start_v), start_a=t(batch.start_a), obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
 p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
-M = max_path_points(p); pl = Planner(0); pl.set_pipeline(1); ts = pl.torch_stream()
+M = max_path_points(p); pl = Planner(0)
+for kv in sys.argv[1:]:                      # name=value options (emp_set_option) before the pipeline is set up
+    k, v = kv.split("="); pl.set_option(k, int(v))
+pl.set_pipeline(1); ts = pl.torch_stream()
 def step():
     with torch.cuda.stream(ts):
         return pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)

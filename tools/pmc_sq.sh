@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/sq_$TAG
 mkdir -p $OUT
-ARGS="bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-3} --no-cpu-baseline --no-pipeline --settle-steps 0 $*"
+ARGS="bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-3} --no-cpu-baseline --no-legs --no-pipeline --settle-steps 0 $*"
 [ -f $OUT/counters_available.txt ] || rocprofv3 -L > $OUT/counters_available.txt 2>&1
 P1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS"

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 STEPS=${STEPS:-100}; WARMUP=${WARMUP:-10}   # bench.py's defaults
-ARGS="bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline ${BENCH_ARGS:-}"   # BENCH_ARGS: e.g. "--scenes-per-gpu 32768", "--config cfg5"
+ARGS="bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-legs ${BENCH_ARGS:-}"   # BENCH_ARGS: e.g. "--scenes-per-gpu 32768", "--config cfg5"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o $TAG -- python $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o $TAG -- python $ARGS --settle-steps 0 > $OUT/bench_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/pmc_write -o $TAG -- python $ARGS --settle-steps 0 > $OUT/bench_pmc_write.log 2>&1

@@ -15,6 +15,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--scenes", type=int, default=4096)
 ap.add_argument("--repeat", type=int, default=2)
 ap.add_argument("--json", default="")
+ap.add_argument("--no-probe", action="store_true", help="leave the in-kernel clock probe off")
 ap.add_argument("variants", nargs="*", default=["default"])
 a = ap.parse_args()
 dev = torch.device("cuda", 0); cfg, B = S.CFG2, a.scenes
@@ -31,32 +32,39 @@ def step():
         return pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
 def fence(): pl.synchronize(); torch.cuda.synchronize()
 results = []
+pl.set_pipeline(0)
+ref = step(); fence()
+ref_traj, ref_status = ref.traj.clone(), ref.status.clone()
 for rep in range(a.repeat):
     for var in a.variants:
         for k in L.OPTIONS:                       # back to the defaults
-            pl.set_option(k, 1 if k == "st_order" else 0)
+            pl.set_option(k, L.OPTION_DEFAULTS.get(k, 0))
         mode = 1
         if var == "off": mode = 0
         elif var != "default":
             for kv in var.split(","):
                 k, v = kv.split("="); pl.set_option(k, int(v))
-        pl.set_option("sweep_clock_probe", 1)
+        pl.set_option("sweep_clock_probe", 0 if a.no_probe else 1)
         pl.set_pipeline(mode)
         for _ in range(150): step()
         fence()
-        pl.set_option("sweep_clock_probe", 1)     # restart the probe's statistics
+        pl.set_option("sweep_clock_probe", 0 if a.no_probe else 1)     # restart the probe's statistics
         pl.set_timing(True, only="dp_sweep")
         t0 = time.perf_counter()
-        for _ in range(a.steps): step()
+        for _ in range(a.steps): last = step()
         fence()
         ms = (time.perf_counter() - t0) / a.steps * 1e3
+        same = bool(torch.equal(last.status, ref_status)) and bool(torch.equal(torch.nan_to_num(last.traj), torch.nan_to_num(ref_traj)))
         sw = pl.kernel_ms("dp_sweep") * 1e3
         pl.set_timing(False)
         clk = pl.sweep_clock()
+        spans = None if a.no_probe else pl.sweep_probe_spans()
         r = {"variant": var, "rep": rep, "ms_per_step": round(ms, 4), "sweep_us": round(sw, 2),
-             "sweep_frac": round(bytes_dp / (sw * 1e-6) / 8e12, 4),
+             "sweep_frac": round(bytes_dp / (sw * 1e-6) / 8e12, 4), "same_as_unpipelined": same,
              "sweep_clock_mhz": None if clk is None else round(clk[0], 1),
-             "wave_resident_us_mean_max": None if clk is None else [round(clk[1], 2), round(clk[2], 2)]}
+             "wave_resident_us_mean_max": None if clk is None else [round(clk[1], 2), round(clk[2], 2)],
+             "wave_start_spread_us": None if spans is None else round(spans[0], 2),
+             "first_start_to_last_end_us": None if spans is None else round(spans[1], 2)}
         results.append(r)
         print(json.dumps(r), flush=True)
 if a.json:

@@ -44,12 +44,43 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         pmc[k][counter] = sum(v) / len(v)
         pmc[k]["launches"] = len(v)
 
+# The sweep inside the timed region, from the kernel trace of the same command: its launches in start order are
+# [untimed steps][the K timed steps][2 + min(K, 5) of the diagnostic pass, one batch in flight] (bench.py --no-legs).
+region = None
+trace_csv = os.path.join(src, "trace", f"{tag}_kernel_trace.csv")
+if os.path.exists(trace_csv):
+    sw = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(trace_csv))
+                 if short(r["Kernel_Name"]).startswith("dp_sweep_kernel")))
+    untimed = None
+    try:
+        line = [ln for ln in open(os.path.join(src, "bench_trace.log")) if ln.startswith("{")][-1]
+        untimed = int(json.loads(line)["untimed_steps_before_the_timed_region"])
+    except Exception:
+        pass
+    diag = 2 + min(steps, 5)
+    if untimed is not None and len(sw) == untimed + steps + diag:
+        dur = [(e - b) / 1e3 for b, e in sw]
+        timed, alone = dur[untimed:untimed + steps], dur[-min(steps, 5):]
+        region = {"launches_in_trace": len(sw), "untimed": untimed, "timed_mean_us": sum(timed) / len(timed),
+                  "timed_min_us": min(timed), "timed_max_us": max(timed), "alone_mean_us": sum(alone) / len(alone),
+                  "all_mean_us": sum(dur) / len(dur)}
+    else:
+        region = {"launches_in_trace": len(sw), "untimed": untimed, "note": "launch count does not match untimed + steps + diagnostic pass"}
+
 stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
 lines = [f"# rocprofv3 summary `{tag}` - `python bench.py --steps {steps} --warmup {warmup}` on one MI355X ({scenes} scenes/GPU)", "",
          f"`rocprofv3 --kernel-trace --stats` (all launches: {warmup} warm-up steps and the untimed settling steps, {steps} timed, the per-kernel diagnostic pass):", "",
          "| kernel | calls | mean us | % of GPU time |", "|---|---|---|---|"]
 for r in stats:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+if region and "timed_mean_us" in region:
+    E_bytes = None
+    lines += ["", f"dp_sweep launches of the same trace by region (start order: {region['untimed']} untimed, {steps} timed, the diagnostic pass): "
+                  f"timed region mean {region['timed_mean_us']:.2f} us (min {region['timed_min_us']:.2f}, max {region['timed_max_us']:.2f}); "
+                  f"diagnostic pass, one batch in flight: {region['alone_mean_us']:.2f} us; all launches {region['all_mean_us']:.2f} us"]
+    json.dump(region, open(os.path.join(dst, f"{tag}_sweep_regions.json"), "w"), indent=1)
+elif region:
+    lines += ["", f"dp_sweep launches by region: {region}"]
 lines += ["", "PMC passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate runs), per-launch means:", "",
           "| kernel | FETCH_SIZE KiB | read MB (x2 gfx950 correction) | WRITE_SIZE KiB | write MB |", "|---|---|---|---|---|"]
 with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
