@@ -735,7 +735,7 @@ def main():
             "kernels_ms": kernels,
             "alt_pipeline": alt,
             "scenes_fully_planned_frac": round(ok_frac, 4),
-            "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "enrich_on_front", "path_qp_form")}, **options},
+            "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "edge_after_enrich", "enrich_on_front", "path_qp_form")}, **options},
             **legs,
         }
         if gather_path:

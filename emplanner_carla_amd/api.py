@@ -331,7 +331,7 @@ class Planner:
     def set_option(self, name, value: int):
         """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` ("path_qp_form",
         "cartesian_form", "smooth_force_fallback", "edge_block", "sweep_variant", "fused_columns", "st_order",
-        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe", "enrich_on_front") or the option's number.  Takes effect at the next call
+        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe", "enrich_on_front", "edge_after_enrich") or the option's number.  Takes effect at the next call
         ("back_stream_cus": at the next ``set_pipeline``).  The library reads no environment variable."""
         key = L.OPTIONS[name] if isinstance(name, str) else int(name)
         self._check(self._lib.emp_set_option(self._h, key, int(value)))

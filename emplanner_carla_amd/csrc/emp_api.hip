@@ -121,6 +121,13 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // EMP_OPT_EDGE_AFTER_ENRICH (staged pipeline): the edge kernel starts behind the previous call's densification kernel,
+    // so that the path QP that follows it on the back queue is dispatched BEFORE this kernel's sixteen-wavefront blocks
+    // take the compute units (emp_plan_cycle)
+    if (ctx->edge_wait) {
+        EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->edge_wait, 0));
+        ctx->edge_wait = nullptr;
+    }
     KernelTimer t(ctx, "dp_edge");
     hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
                        cols_per_chunk);
@@ -389,6 +396,7 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
         if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.ev_qp) (void)hipEventDestroy(ln.ev_qp);
+        if (ln.ev_enrich) (void)hipEventDestroy(ln.ev_enrich);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
@@ -541,6 +549,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         if (!ln.ev_tail) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_tail, hipEventDisableTiming));
         if (!ln.ev_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
         if (!ln.ev_qp) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_qp, hipEventDisableTiming));
+        if (!ln.ev_enrich) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_enrich, hipEventDisableTiming));
     }
     const int want_cus = ctx->opt[EMP_OPT_BACK_STREAM_CUS] > 0 && ctx->opt[EMP_OPT_BACK_STREAM_CUS] < ctx->cu_count
                              ? ctx->opt[EMP_OPT_BACK_STREAM_CUS] : 0;
@@ -566,7 +575,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         }
         ctx->back_stream_cus = want_cus;
     }
-    for (auto& ln : ctx->lanes) ln.done_valid = ln.qp_valid = false;       // everything was drained above
+    for (auto& ln : ctx->lanes) ln.done_valid = ln.qp_valid = ln.enrich_valid = false;       // everything was drained above
     ctx->pipe_mode = m;
     ctx->lane = 0;
     return EMP_OK;
@@ -593,6 +602,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_SMOOTH_FORCE_FALLBACK:
         case EMP_OPT_ST_ORDER:
         case EMP_OPT_ENRICH_ON_FRONT:
+        case EMP_OPT_EDGE_AFTER_ENRICH:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
@@ -1381,12 +1391,18 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
             ctx->sweep_wait = prev.ev_done;
         }
     }
+    ctx->edge_wait = nullptr;
+    if (staged && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH] && mode == EMP_DP_TWO_KERNEL && !wide(d)) {
+        emp_ctx::Lane& prev = ctx->lanes[(ctx->lane + ctx->lanes_in_use() - 1) % ctx->lanes_in_use()];
+        if (prev.enrich_valid) ctx->edge_wait = prev.ev_enrich;
+    }
     ctx->bt_pre = d_pre;
     ctx->bt_term = d_term;
     ctx->bt_deferred = false;
     rc = dev_dp_plan(ctx, d, d_os, d_ol, d_no, d_start, mode, d_rows, nullptr, d_st);
     ctx->front_stop = nullptr;
     ctx->sweep_wait = nullptr;
+    ctx->edge_wait = nullptr;
     ctx->bt_pre = nullptr;
     ctx->bt_term = nullptr;
     const bool deferred = ctx->bt_deferred;
@@ -1426,6 +1442,12 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         (rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
                             deferred ? d_term : nullptr, d_no, d_rows)))
         return rc;
+    if (staged && !enrich_front && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH]) {
+        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_enrich, ctx->stream));
+        lane.ln->enrich_valid = true;
+    } else if (staged) {
+        lane.ln->enrich_valid = false;
+    }
     if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
                            d_st)))
         return rc;

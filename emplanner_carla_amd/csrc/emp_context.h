@@ -62,7 +62,8 @@ struct emp_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr, ev_tail = nullptr;
         hipEvent_t ev_qp = nullptr;     // STAGED: end of the cycle's path QP on the back stream (EMP_OPT_SWEEP_EXCLUSIVE = 2)
-        bool done_valid = false, qp_valid = false;
+        hipEvent_t ev_enrich = nullptr; // STAGED: end of the cycle's densification kernel on the back stream (EMP_OPT_EDGE_AFTER_ENRICH)
+        bool done_valid = false, qp_valid = false, enrich_valid = false;
         std::vector<Buf> pool;
     };
     std::vector<Lane> lanes;            // created on demand, kept until emp_destroy
@@ -81,7 +82,8 @@ struct emp_ctx {
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
-    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 0};
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 0, 1};
+    hipEvent_t edge_wait = nullptr;     // EMP_OPT_EDGE_AFTER_ENRICH: what the next edge-cost launch waits for on its stream
     hipEvent_t sweep_marker = nullptr;  // EMP_OPT_SWEEP_EXCLUSIVE: recorded on the front stream behind the sweep (emp_api.hip)
     int back_stream_cus = -1;           // the CU count back_stream was created with (-1: no back stream yet)
     // EMP_OPT_SWEEP_EXCLUSIVE: the event the next sweep launch waits for on its own stream (the previous call's back stage)

@@ -195,6 +195,15 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             4096 scenes instead of 0.60-0.65) for ~6 % of the step;
  *                                                             1 = it waits for the whole back stage of call k-1 (+11 %);
  *                                                             0 = no wait, rounds 1-3 (the fastest step)
+ *   EMP_OPT_EDGE_AFTER_ENRICH       1        tuning           staged pipeline: 1 (default) = the edge-cost kernel of call k waits
+ *                                                             (stream-side) for the densification kernel of call k-1, so that
+ *                                                             the path QP behind it is dispatched BEFORE the edge kernel's
+ *                                                             sixteen-wavefront blocks take the compute units.  Whichever of
+ *                                                             the two starts first keeps the chip: QP first = edge 195 us, QP
+ *                                                             140 us side by side; edge first = edge 147 us with the QP starved
+ *                                                             to 255 us behind it, a 0.32-0.34 ms step.  Without the wait the
+ *                                                             order is a race that the N > 1 step (record packing on the back
+ *                                                             queue) loses: 0.305 -> 0.270 ms there, +1 % on the plain step
  *   EMP_OPT_ENRICH_ON_FRONT         0        tuning           staged pipeline: 1 = the densification kernel runs on the front
  *                                                             stream behind the sweep, the back stage begins with the path QP
  *   EMP_OPT_BACK_STREAM_CUS         0        tuning           staged pipeline: n > 0 confines the back stage's stream to n
@@ -215,7 +224,8 @@ typedef enum emp_option {
     EMP_OPT_BACK_STREAM_CUS = 8,
     EMP_OPT_SWEEP_CLOCK_PROBE = 9,
     EMP_OPT_ENRICH_ON_FRONT = 10,
-    EMP_OPT_COUNT = 11
+    EMP_OPT_EDGE_AFTER_ENRICH = 11,
+    EMP_OPT_COUNT = 12
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);

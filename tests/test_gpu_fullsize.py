@@ -650,15 +650,18 @@ def test_small_shards_equal_their_slice_of_the_full_batch(planner):
 
 
 @pytest.mark.parametrize("options", [{}, {"sweep_exclusive": 0}, {"sweep_exclusive": 1}, {"sweep_exclusive": 0, "enrich_on_front": 1},
-                                     {"sweep_exclusive": 2, "enrich_on_front": 1}],
-                         ids=["default", "overlapped_sweep", "exclusive_sweep", "enrich_on_front", "exclusive2_enrich_on_front"])
+                                     {"sweep_exclusive": 2, "enrich_on_front": 1}, {"edge_after_enrich": 0},
+                                     {"sweep_exclusive": 0, "edge_after_enrich": 0}],
+                         ids=["default", "overlapped_sweep", "exclusive_sweep", "enrich_on_front", "exclusive2_enrich_on_front",
+                              "edge_not_held", "rounds_1_to_3_pipeline"])
 def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner, options):
     """bench.py's timed region brackets the sweep with HIP events, and in staged mode the back stage is released by the
     event attached to the sweep's own dispatch - the TIMING event then (emp_api.hip: front_attached).  Consecutive calls on
     DIFFERENT batches with the events on must equal the plain calls bit for bit: a back stage that started early would
     densify another batch's predecessor table (the bench itself, planning the same batch every step, could not tell).
     Every ordering option of the staged pipeline (include/emplanner.h: EMP_OPT_SWEEP_EXCLUSIVE 0 / 1 / 2 - the default is 2 -
-    and EMP_OPT_ENRICH_ON_FRONT) moves waits and kernels between the two queues: each one is held to the same bar."""
+    EMP_OPT_EDGE_AFTER_ENRICH - default 1 - and EMP_OPT_ENRICH_ON_FRONT) moves waits and kernels between the two queues: each
+    one is held to the same bar."""
     import torch
     cfg = S.CFG2
     p, q, sp = _params(cfg)

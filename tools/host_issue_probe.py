@@ -18,6 +18,10 @@ p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=5, obs_width=5), smooth
 M = max_path_points(p)
 pl.set_pipeline(True)
 ts = pl.torch_stream()
+sg = None
+if "--gather" in sys.argv:        # the N > 1 per-step code on one GPU: pack on the result stream, gather stream, events
+    from emplanner_carla_amd import dist as emp_dist
+    sg = emp_dist.StepGather(p.col, M, B, planner=pl, fields="full", device=dev, dst=0, timing="--timing" in sys.argv)
 for _ in range(10):
     with torch.cuda.stream(ts):
         r = pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
@@ -27,6 +31,8 @@ t0 = time.perf_counter()
 for _ in range(N):
     with torch.cuda.stream(ts):
         r = pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
+    if sg is not None:
+        sg.submit(r)
 t1 = time.perf_counter()
 pl.synchronize(); torch.cuda.synchronize()
 t2 = time.perf_counter()
