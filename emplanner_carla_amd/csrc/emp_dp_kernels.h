@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void dp_sweep_wide_kernel(DpDev P, const doubl
 // buffer.  Same arithmetic as dp_edge_kernel + dp_sweep_kernel (dp_edge_column, the v_min tree with the
 // lowest-k predecessor, first-minimum terminal), so rows, min_cost and status are bit-identical to the two-kernel
 // path.  Trade: no 8 E bytes per scene written and read back, against one block per tile - 586 blocks at 4096
-// scenes 40x9, two or three per CU instead of the edge kernel's sixteen wavefronts per CU.
+// scenes 40x9, two or three per CU instead of the edge kernel's sixteen wavefronts per CU (HISTORY.md section 3.2).
 struct FusedLds {
     int off_smp, off_obs_s, off_obs_l, off_buf, off_front, off_pre, off_ctr, total;   // bytes
 };

@@ -13,8 +13,8 @@
 // (KD <= R), so a sweep costs about what it cost before - for eight problems instead of two.  Same algorithm, stopping rule
 // and failure handling as range_qp_solve_wave_fast (Mehrotra predictor-corrector on the reduced normal equations); sums are
 // associated differently, so results agree to round-off (2e-9 on the benchmark batch; QP outputs are compared at 1e-6 and
-// certified against the reference-built KKT system, DESIGN.md section 4).  Measured: 15.7 M vector instructions per 4096
-// scenes.
+// certified against the reference-built KKT system, DESIGN.md section 5).  Measured: 15.7 M vector instructions per 4096
+// scenes (HISTORY.md section 3.3).
 //
 // The problems of a wavefront iterate in lock step until the slowest has converged (finished groups idle through the
 // barriers): mean 10 iterations per wavefront of eight where a pair took 8.7.  Small batches (under 1024 scenes), which

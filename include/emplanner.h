@@ -194,7 +194,7 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             the sweep then streams as fast as alone (0.70 of the HBM peak at
  *                                                             4096 scenes instead of 0.60-0.65) for ~6 % of the step;
  *                                                             1 = it waits for the whole back stage of call k-1 (+11 %);
- *                                                             0 = no wait, rounds 1-3 (the fastest step; DESIGN.md 5)
+ *                                                             0 = no wait, rounds 1-3 (the fastest step; DESIGN.md 4)
  *   EMP_OPT_EDGE_AFTER_ENRICH       1        tuning           staged pipeline: 1 (default) = the edge-cost kernel of call k waits
  *                                                             (stream-side) for the densification kernel of call k-1, so that
  *                                                             the path QP behind it is dispatched BEFORE the edge kernel's
@@ -270,7 +270,12 @@ int emp_kernel_samples(emp_ctx* ctx, const char* kernel, double* ms, int32_t cap
  * `row` may be anything in [1, 256] (ref path_planning.py:276-279 takes any; :301-346).  Up to 32 rows the DP runs on the
  * tiled kernels; wider lattices take a generic pair of kernels (one block per scene, pair table in device memory) whose
  * tensor is the CANONICAL one whichever layout is asked for (emp_edge_tensor_elems says so), and EMP_DP_FUSED falls back
- * to the two-kernel form there.  Same arithmetic, bit for bit; built for correctness, not measured for speed.           */
+ * to the two-kernel form there.  Same arithmetic, bit for bit.  Measured (profiles/r04_wide_lattice.json, 1024 scenes, 40
+ * columns): the wide edge kernel costs 0.014-0.021 ns per lattice edge against 0.013 on the 21-row tiled lattice, the wide
+ * sweep 0.003-0.007 against 0.0016 (2.0-2.6 TB/s of algorithmic bytes; 0.6 TB/s at exactly 33 rows) - a 48-row lattice is
+ * 1.3x the per-edge cost of the 21-row one, so the wide pair stays generic.
+ * THE CAP: row > 256 is refused with EMP_ERR_INVALID (a predecessor index is one byte in every kernel; the reference itself
+ * takes any row count - at 256 rows x 40 columns one scene is already 2.6 M edges and 70 us of GPU time).                */
 typedef enum emp_edge_layout { EMP_EDGE_CANONICAL = 0, EMP_EDGE_TILED = 1 } emp_edge_layout;
 uint64_t emp_edge_tensor_elems(const emp_dp_params* p, int32_t B, emp_edge_layout layout);
 

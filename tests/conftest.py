@@ -29,7 +29,7 @@ ATOL_SURVEY = 1e-9     # "within 1e-6 relative (abs floo
 def tolerance(b, rtol, scale=None):
     """The suite's closeness rule.  For the 1e-6 bar it is SURVEY.md 8(d)'s, to the letter:
     |a - b| <= max(rtol |b|, 1e-9 (rtol / 1e-6)) - no magnitude floor (until round 3 the floor was max(|b|, 1.0), i.e.
-    1e-6 m absolute near l = 0: a thousand times looser than what the whole GPU suite measures).
+    1e-6 m absolute near l = 0: a thousand times looser than what the whole GPU suite measures, see HISTORY.md section 4).
     For the tight comparisons (rtol < 1e-7: S-T cost tables, MPC error model ...) `scale` is an explicit magnitude
     floor, rtol max(|b|, scale), because there an absolute 1e-9 would be the LOOSER rule."""
     b = np.abs(np.asarray(b, dtype=np.float64))

@@ -557,7 +557,7 @@ def test_motion_planning_process_loop(planner):
     """The Pipe-protocol loop (drop-in for the reference's child process) answers a request and blocks for the next."""
     from emplanner_carla_amd import service
     from emplanner_carla_amd.api import dp_params
-    g = load_golden("driver_s147.npz")        # non-integer sample_s: no int() truncation flips (DESIGN.md)
+    g = load_golden("driver_s147.npz")        # non-integer sample_s: no int() truncation flips (HISTORY.md 7)
 
     class Done(Exception):
         pass

@@ -601,7 +601,7 @@ def test_both_path_qp_kernels_agree_on_the_benchmark_batch(planner):
     kernel of rounds 1-2 (emp_qp_wave.h) is EMP_OPT_PATH_QP_FORM = 1.  Same algorithm and stopping rule, sums associated
     differently: on all 4096 benchmark scenes the two must classify every scene alike and agree on path and trajectory far
     inside the 1e-6 bar (measured: 2e-9).  Scene 446 is the one that found the stopping rule's weak spot: its dual residual
-    sits at the threshold when the complementarity has converged, one more iteration destroys the iterate."""
+    sits at the threshold when the complementarity has converged, one more iteration destroys the iterate (HISTORY 3.3)."""
     a = _benchmark_batch_under(planner, "path_qp_form", 0)
     b = _benchmark_batch_under(planner, "path_qp_form", 1)
     assert np.array_equal(a["status"], b["status"])

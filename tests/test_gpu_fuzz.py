@@ -20,7 +20,7 @@ SCALE = int(os.environ.get("EMP_FUZZ_SCALE", "1"))       # the same tests on SCA
 # sample_s is kept off the integers: the reference sizes its output with int(end_s - start_s)
 # (path_planning.py:398), which for an integer sample_s sits on the edge of a truncation and follows the last bit of
 # the projected start s - and that bit comes out of ndarray.dot, i.e. out of the BLAS the reference runs on
-# (DESIGN.md "Known sensitivity"); the integer cases live in the golden fixtures.
+# (HISTORY.md "Known sensitivity"); the integer cases live in the golden fixtures.
 SHAPES = [  # row, col, sample_s, sample_l, res, n_obs
     (3, 12, 7.5, 1.5, 2, 2), (4, 20, 4.5, 1.0, 1, 4), (6, 16, 5.2, 1.2, 2, 3), (7, 30, 3.2, 1.0, 1, 6),
     (9, 24, 2.5, 1.5, 2, 8), (11, 14, 6.3, 0.8, 2, 5), (15, 18, 4.2, 0.6, 2, 7), (5, 10, 9.3, 1.5, 1, 0),

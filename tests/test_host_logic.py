@@ -378,7 +378,7 @@ def test_projection_dot_product_rounds_like_numpy(hc):
     whose OpenBLAS accumulates with fused multiply-adds (the reference evaluates every projection with np.dot,
     planning_utils.py:107, :443, :507, :546-578).  The fused form itself is checked against libm's fma on any host; numpy
     only where its dot is of that form (another BLAS may round the plain way - that is the reference's host dependence,
-    DESIGN.md section 4)."""
+    HISTORY.md section 4)."""
     import ctypes
     rng = np.random.default_rng(11)
     n = 20000

@@ -130,7 +130,7 @@ def test_edge_costs_vs_reference():
             # matrix in absolute s has cond ~ s^10/T^5, and the measured deviation from the exact
             # quintic grows ~ s^6 (1e-11 at 10 m, 1e-7 at 70 m, 1.4e-6 at 100 m on the generating
             # machine).  1e-6 is enforced where the reference is that accurate; the last columns
-            # get 4e-6 (documented in DESIGN.md "Reference noise floor").
+            # get 4e-6 (documented in HISTORY.md "Reference noise floor").
             s0 = g["start"][sd, 0] + np.arange(1, cfg.col) * cfg.sample_s
             near = s0 <= 90.0
             assert_rel(ed[0][near], red[near], RTOL, "neighbour edge costs (s0 <= 90 m)")

@@ -1,5 +1,5 @@
 """Lane statistics of the edge-cost kernel's obstacle scans on the benchmark scenes, on the CPU (development aid; the numbers
-quoted in DESIGN.md 3.1 and profiles/r02_edge/README.md): scans per edge, soft samples per scan, wave-level scans of the
+quoted in HISTORY.md 3.1 and profiles/r02_edge/README.md): scans per edge, soft samples per scan, wave-level scans of the
 kernel's lane mapping against a one-scene-per-wavefront mapping, the exact box test.  Usage: python tools/edge_lane_sim.py [scenes]"""
 import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))

@@ -4,7 +4,7 @@
   cycle   seeds 0..N_CYCLE-1: the whole cycle against the faithful port oracle/ref_port.py (reference-structured NumPy,
           QP by oracle/qp_dense.py) - per-scene outcome equal, trajectory within 1e-6.  Scenes whose planning start
           projects onto a reference-line node to the last bits are listed separately when they differ: there the
-          reference's own result follows the rounding of its host's libm / BLAS ("Known sensitivity")
+          reference's own result follows the rounding of its host's libm / BLAS (HISTORY.md, "Known sensitivity")
 
 The oracles run in a process pool on the host cores; prints one summary line per part and writes gpurun_out/parity_sweep.json.
   S-T     seeds 0..N_ST-1: generate_st_graph bit for bit, speed-DP cost tables within 1e-12, predecessor tables (a node may differ

@@ -1,5 +1,5 @@
 """Staged steps of the benchmark batch under emp_set_option variants, in one process (development A/B; the numbers behind
-DESIGN.md section 5 "what slows the sweep in the step").  For every variant: ms per step, the sweep's mean launch duration
+profiles/r04_sweep/README.md and DESIGN.md section 4).  For every variant: ms per step, the sweep's mean launch duration
 (HIP events attached to its dispatch), the shader clock its wavefronts ran at and how long they were resident (the
 in-kernel clock probe).  Usage: python tools/step_variants.py [--steps N] [--json out.json] name=value,name=value ...
 ("default" = no option; "off" = one batch in flight)"""
