@@ -603,6 +603,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_ST_ORDER:
         case EMP_OPT_ENRICH_ON_FRONT:
         case EMP_OPT_EDGE_AFTER_ENRICH:
+        case EMP_OPT_SWEEP_MARKER:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
@@ -1414,7 +1415,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     // 198 us, path QP 140, Cartesian 70, sweep 19) and the step takes 0.264 ms (mode 2) / 0.277 (mode 1); without it the
     // edge kernel runs at its stand-alone 147 us, starves the path QP beside it (250 us) and the step takes 0.32 - 0.35 ms
     // (profiles/r04_sweep/README.md).  The clock probe's event did the same by accident, which is how this was found.
-    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE]) {
+    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE] && ctx->opt[EMP_OPT_SWEEP_MARKER]) {
         if (!ctx->sweep_marker) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->sweep_marker, hipEventDisableTiming));
         EMP_HIP(ctx, hipEventRecord(ctx->sweep_marker, ctx->stream));
     }

@@ -204,6 +204,8 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             to 255 us behind it, a 0.32-0.34 ms step.  Without the wait the
  *                                                             order is a race that the N > 1 step (record packing on the back
  *                                                             queue) loses: 0.305 -> 0.270 ms there, +1 % on the plain step
+ *   EMP_OPT_SWEEP_MARKER            1        tuning           staged pipeline with EMP_OPT_SWEEP_EXCLUSIVE != 0: an event record on
+ *                                                             the front stream behind the sweep (0: none; profiles/r04_sweep)
  *   EMP_OPT_ENRICH_ON_FRONT         0        tuning           staged pipeline: 1 = the densification kernel runs on the front
  *                                                             stream behind the sweep, the back stage begins with the path QP
  *   EMP_OPT_BACK_STREAM_CUS         0        tuning           staged pipeline: n > 0 confines the back stage's stream to n
@@ -225,7 +227,8 @@ typedef enum emp_option {
     EMP_OPT_SWEEP_CLOCK_PROBE = 9,
     EMP_OPT_ENRICH_ON_FRONT = 10,
     EMP_OPT_EDGE_AFTER_ENRICH = 11,
-    EMP_OPT_COUNT = 12
+    EMP_OPT_SWEEP_MARKER = 12,
+    EMP_OPT_COUNT = 13
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
