@@ -145,3 +145,21 @@ def test_bench_two_ranks_on_one_gpu(extra):
     assert g["ms_per_step_without_pack_and_gather"] > 0 and g["gather_ms_on_its_stream"]["count"] == 6
     assert g["gather_ms_on_its_stream"]["mean"] > 0 and 0.0 <= g["gather_hidden_behind_compute_frac"] <= 1.0
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
+
+
+def test_rccl_calls_of_the_multi_gpu_path_with_one_rank():
+    """The only RCCL run a one-GPU box allows: tools/rccl_smoke.py under torch.distributed.run with ONE rank and the real
+    "nccl" (= RCCL) backend issues the torch.distributed calls of bench.py's N > 1 path in the same forms - init with device_id,
+    barrier, all_reduce MAX, all_gather, dist.gather into views of one tensor on a side stream behind the record-packing
+    kernel of a staged planning step, all_gather_into_tensor - and checks the gathered records.  It cannot show scaling; it
+    shows that RCCL / ProcessGroupNCCL on this stack accept the calls, their argument forms and the stream usage."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "rccl_smoke.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(port))
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "backend nccl world 1" in out.stdout and "rccl smoke ok" in out.stdout
