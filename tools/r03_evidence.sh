@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-3 evidence run on the GPU box (final build of the round): every bench line and the rocprofv3 passes behind profiles/r03*.
+# Round-3 evidence run on the GPU box (final build of round 3; kept as the record of how profiles/r03* were made - the EMP_* environment
+# switches below were development switches of THAT build; since round 4 they are `bench.py --opt name=value`, tools/r04_evidence.sh).
 # Afterwards, here: tools/r03_file_evidence.sh copies the results under profiles/ and refreshes profiles/counters.json.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/r03
