@@ -118,7 +118,12 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     dim3 grid(d.tiles, chunks), block(eb);
     const double* pair_tab = nullptr;
     { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
-    auto kern = tiled ? dp_edge_kernel<true> : dp_edge_kernel<false>;
+    // the benchmark lattices' row counts are compiled in (emp_dp_kernels.h: dp_edge_column<ROW>), as in the sweep; any other takes
+    // the generic instantiation - the same operations either way
+    auto kern = tiled ? (d.row == 9 ? dp_edge_kernel<true, 9> : d.row == 21 ? dp_edge_kernel<true, 21> : d.row == 12 ? dp_edge_kernel<true, 12>
+                         : d.row == 5 ? dp_edge_kernel<true, 5> : dp_edge_kernel<true, 0>)
+                      : (d.row == 9 ? dp_edge_kernel<false, 9> : d.row == 21 ? dp_edge_kernel<false, 21> : d.row == 12 ? dp_edge_kernel<false, 12>
+                         : d.row == 5 ? dp_edge_kernel<false, 5> : dp_edge_kernel<false, 0>);
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // EMP_OPT_EDGE_AFTER_ENRICH (staged pipeline): the edge kernel starts behind the previous call's densification kernel,

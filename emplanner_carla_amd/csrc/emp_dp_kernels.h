@@ -150,11 +150,14 @@ __device__ __forceinline__ bool obstacle_box_in_reach(double os, double ol, doub
 // column) only - the sample abscissae and which obstacles are within longitudinal reach - is set up once and reused
 // for the source rows.  tab / t_smp: the pair table and the sample offsets in LDS; my_obs_s / my_obs_l: the scene's
 // obstacles in LDS; ps = plan_start_s; nob = the scene's obstacle count (clamped to the row's capacity).
-template <typename Store>
+// ROW > 0: the lattice's row count at compile time (round 4: every offset into the pair table - (field) row^2 + k row + i, and the ten
+// lateral samples of a scan row^2 doubles apart - is then an immediate of the LDS instruction instead of vector arithmetic in
+// front of it); ROW == 0: any row count (the generic, fused and wide kernels).
+template <int ROW = 0, typename Store>
 __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, double ps, int nob, const double* tab,
                                                const double* t_smp, const double* my_obs_s, const double* my_obs_l,
                                                Store&& store) {
-    const int row = P.row, rr = P.row * P.row;
+    const int row = ROW > 0 ? ROW : P.row, rr = row * row;
     const int nmask = min(nob, 64);
     const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
     const double s9 = s0 + t_smp[kSamples - 1];
@@ -195,7 +198,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
 #ifndef EMP_EDGE_WAVES
 #define EMP_EDGE_WAVES 5
 #endif
-template <bool TILED>
+template <bool TILED, int ROW = 0>
 // Five wavefronts per SIMD (at most 102 registers; 94 used, nothing spilled - the sample abscissae are rebuilt from
 // s0 + t_n where they are needed instead of living in twenty registers): alone the kernel takes the same 158 us as with
 // four, with a second batch's path-QP wavefronts on the SIMDs it gets a slot more (0.348 -> 0.340 ms per step).
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
                                                       double* __restrict__ edge, int cols_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __builtin_amdgcn_s_setprio(EMP_PRIO_FRONT);
-    const int row = P.row, rr = P.row * P.row;
+    const int row = ROW > 0 ? ROW : P.row, rr = row * row;
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
     double* t_obs_l = t_obs_s + P.S * P.max_obs;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     const double* my_obs_s = t_obs_s + s * P.max_obs;
     const double* my_obs_l = t_obs_l + s * P.max_obs;
     for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
-        dp_edge_column(P, j, i, ps, nob, tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) {
+        dp_edge_column<ROW>(P, j, i, ps, nob, tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) {
             if (TILED) {
                 edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
             } else {
