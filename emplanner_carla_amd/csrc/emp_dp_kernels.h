@@ -263,7 +263,9 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     const double* my_obs_s = t_obs_s + s * P.max_obs;
     const double* my_obs_l = t_obs_l + s * P.max_obs;
     for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
-        dp_edge_column<ROW>(P, j, i, ps, nob, tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) {
+        // (the sample offsets t_n are the same for every lane: read through the kernel argument they come back in scalar
+        // registers, where the LDS copy costs a vector move and an LDS read per pair of them in every scan)
+        dp_edge_column<ROW>(P, j, i, ps, nob, tab, pair_tab + kTableFields * rr, my_obs_s, my_obs_l, [&](int k, double cost) {
             if (TILED) {
                 edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
             } else {
