@@ -120,10 +120,17 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
     // the benchmark lattices' row counts are compiled in (emp_dp_kernels.h: dp_edge_column<ROW>), as in the sweep; any other takes
     // the generic instantiation - the same operations either way
-    auto kern = tiled ? (d.row == 9 ? dp_edge_kernel<true, 9> : d.row == 21 ? dp_edge_kernel<true, 21> : d.row == 12 ? dp_edge_kernel<true, 12>
-                         : d.row == 5 ? dp_edge_kernel<true, 5> : dp_edge_kernel<true, 0>)
-                      : (d.row == 9 ? dp_edge_kernel<false, 9> : d.row == 21 ? dp_edge_kernel<false, 21> : d.row == 12 ? dp_edge_kernel<false, 12>
-                         : d.row == 5 ? dp_edge_kernel<false, 5> : dp_edge_kernel<false, 0>);
+    using M32 = unsigned int;
+    using M64 = unsigned long long;
+    const bool m32 = d.max_obs <= 32;          // every obstacle of a row fits a 32-bit reach mask
+#define EMP_EDGE_PICK(T)                                                                                              \
+    (d.row == 9 ? (m32 ? dp_edge_kernel<T, 9, M32> : dp_edge_kernel<T, 9, M64>)                                       \
+     : d.row == 21 ? (m32 ? dp_edge_kernel<T, 21, M32> : dp_edge_kernel<T, 21, M64>)                                  \
+     : d.row == 12 ? (m32 ? dp_edge_kernel<T, 12, M32> : dp_edge_kernel<T, 12, M64>)                                  \
+     : d.row == 5 ? (m32 ? dp_edge_kernel<T, 5, M32> : dp_edge_kernel<T, 5, M64>)                                     \
+                  : (m32 ? dp_edge_kernel<T, 0, M32> : dp_edge_kernel<T, 0, M64>))
+    auto kern = tiled ? EMP_EDGE_PICK(true) : EMP_EDGE_PICK(false);
+#undef EMP_EDGE_PICK
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // EMP_OPT_EDGE_AFTER_ENRICH (staged pipeline): the edge kernel starts behind the previous call's densification kernel,

@@ -153,20 +153,24 @@ __device__ __forceinline__ bool obstacle_box_in_reach(double os, double ol, doub
 // ROW > 0: the lattice's row count at compile time (round 4: every offset into the pair table - (field) row^2 + k row + i, and the ten
 // lateral samples of a scan row^2 doubles apart - is then an immediate of the LDS instruction instead of vector arithmetic in
 // front of it); ROW == 0: any row count (the generic, fused and wide kernels).
-template <int ROW = 0, typename Store>
+// MASK: the type of the per-column reach mask - 64 bits, or 32 when the call's obstacle rows hold at most 32 slots (the first-set-bit
+// walk over a 64-bit mask in vector registers costs twice the instructions; obstacles beyond the mask's width take the full test
+// per edge either way).
+template <int ROW = 0, typename MASK = unsigned long long, typename Store>
 __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, double ps, int nob, const double* tab,
                                                const double* t_smp, const double* my_obs_s, const double* my_obs_l,
                                                Store&& store) {
+    constexpr int kMaskBits = (int)sizeof(MASK) * 8;
     const int row = ROW > 0 ? ROW : P.row, rr = row * row;
-    const int nmask = min(nob, 64);
+    const int nmask = min(nob, kMaskBits);
     const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
     const double s9 = s0 + t_smp[kSamples - 1];
     const double T1 = t_smp[kSamples], T2 = t_smp[kSamples + 1];    // sum t_n, sum t_n^2 (sample_moments)
     // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
-    unsigned long long near_s = 0;
+    MASK near_s = 0;
     for (int m = 0; m < nmask; ++m) {
         const double os = my_obs_s[m];
-        if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= 1ull << m;
+        if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= (MASK)1 << m;
     }
     for (int k = 0; k < row; ++k) {
         const int p = k * row + i;
@@ -178,13 +182,13 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
         const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
         double coll = 0.0;
-        for (unsigned long long rest = near_s; rest; rest &= rest - 1) {   // ascending m, as the reference
-            const int m = __ffsll((long long)rest) - 1;
+        for (MASK rest = near_s; rest; rest &= rest - 1) {                 // ascending m, as the reference
+            const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
             const double os = my_obs_s[m], ol = my_obs_l[m];
             if (!obstacle_box_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;   // contributes exactly 0
             coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
         }
-        for (int m = 64; m < nob; ++m) {                                  // beyond the mask: full test per edge
+        for (int m = kMaskBits; m < nob; ++m) {                           // beyond the mask: full test per edge
             const double os = my_obs_s[m], ol = my_obs_l[m];
             if (!obstacle_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;
             coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
@@ -198,7 +202,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
 #ifndef EMP_EDGE_WAVES
 #define EMP_EDGE_WAVES 5
 #endif
-template <bool TILED, int ROW = 0>
+template <bool TILED, int ROW = 0, typename MASK = unsigned long long>
 // Five wavefronts per SIMD (at most 102 registers; 94 used, nothing spilled - the sample abscissae are rebuilt from
 // s0 + t_n where they are needed instead of living in twenty registers): alone the kernel takes the same 158 us as with
 // four, with a second batch's path-QP wavefronts on the SIMDs it gets a slot more (0.348 -> 0.340 ms per step).
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
         // (the sample offsets t_n are the same for every lane: read through the kernel argument they come back in scalar
         // registers, where the LDS copy costs a vector move and an LDS read per pair of them in every scan)
-        dp_edge_column<ROW>(P, j, i, ps, nob, tab, pair_tab + kTableFields * rr, my_obs_s, my_obs_l, [&](int k, double cost) {
+        dp_edge_column<ROW, MASK>(P, j, i, ps, nob, tab, pair_tab + kTableFields * rr, my_obs_s, my_obs_l, [&](int k, double cost) {
             if (TILED) {
                 edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + lane] = cost;
             } else {
