@@ -81,7 +81,11 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
     }
-    const size_t lds = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples + kSampleMoments) * sizeof(double);
+    // per block: pair table, the tile's obstacles, sample offsets; per wavefront: the longitudinal box terms of its column
+    // ([S][mask width] doubles, emp_dp_kernels.h: box_dx2)
+    const size_t lds_fixed = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples + kSampleMoments) * sizeof(double);
+    const size_t lds_wave = (size_t)d.S * (d.max_obs <= 32 ? d.max_obs : (d.max_obs < 64 ? d.max_obs : 64)) * sizeof(double);
+    size_t lds = lds_fixed + 2 * lds_wave;        // the block-size rule below prices a two-wavefront block; the launch its own
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
     int ncol = d.col - 1;
     int chunks = 1;
@@ -105,6 +109,8 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     if (tiled && tiled_elems(d) * sizeof(double) > ((size_t)256 << 20) && wpb < 4) wpb = 4;
     if (eb_env) wpb = eb_env / 64;
     const int eb = wpb * 64;
+    lds = lds_fixed + (size_t)wpb * lds_wave;
+    EMP_REQUIRE(ctx, lds <= 160 * 1024, "edge-cost block too large for the LDS");
     // each of the block's wavefronts takes whole columns: two per wavefront, or one while that leaves the chip short of blocks
     // (a single scene: 29 us with one column per wavefront, 44 with two); chunk sizes multiples of the wavefront count
     if (ncol > 0) {
@@ -239,6 +245,18 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     return EMP_OK;
 }
 
+// A launch that signals ctx->attach_stop from its own dispatch when the caller offered one and the kernel carries no timing
+// events (emp_context.h); else a plain launch.
+template <typename K, typename... A>
+static void launch_attaching(emp_ctx* ctx, bool timed, K kern, dim3 grid, dim3 block, size_t lds, A... args) {
+    if (ctx->attach_stop && !timed) {
+        hipExtLaunchKernelGGL(kern, grid, block, lds, ctx->stream, nullptr, ctx->attach_stop, 0, args...);
+        ctx->stop_attached = true;
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, args...);
+    }
+}
+
 static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const double* start, int max_pts,
                          double* path_s, double* path_l, int* path_len, int* status, int or_status,
                          const unsigned char* pre = nullptr, const int* term = nullptr, const int* n_obs = nullptr,
@@ -249,8 +267,8 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_enrich_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KernelTimer t(ctx, "dp_enrich");
-    hipLaunchKernelGGL(dp_enrich_wave_kernel, dim3(d.B), dim3(64), lds, ctx->stream, d, rows, start, max_pts, path_s, path_l,
-                       path_len, status, or_status, pre, term, n_obs, rows_out);
+    launch_attaching(ctx, t.stop != nullptr, dp_enrich_wave_kernel, dim3(d.B), dim3(64), lds, d, rows, start, max_pts, path_s, path_l,
+                     path_len, status, or_status, pre, term, n_obs, rows_out);
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -946,18 +964,18 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
         auto kern = cap <= 26 ? cycle_qp_rows_kernel<8, 3> : cap <= 34 ? cycle_qp_rows_kernel<8, 4> : cycle_qp_rows_kernel<16, 4>;
         if ((rc = set_lds(ctx, kern, per_wave))) return rc;
         const int spw = 64 / gp;
-        hipLaunchKernelGGL(kern, dim3((B + spw - 1) / spw), dim3(64), per_wave, ctx->stream, B, max_pts,
-                           max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+        launch_attaching(ctx, t.stop != nullptr, kern, dim3((B + spw - 1) / spw), dim3(64), per_wave, B, max_pts,
+                         max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     } else if (cap <= 34) {                                           // N, ns <= 32: two scenes per wavefront
         const size_t per_pair = 2 * ((size_t)5 * cap + 4 * (size_t)max_obs + path_qp_words_pair()) * sizeof(double);
         auto kern = cycle_qp_wave_kernel<32>;
         if ((rc = set_lds(ctx, kern, per_pair))) return rc;
-        hipLaunchKernelGGL(kern, dim3((B + 1) / 2), dim3(64), per_pair, ctx->stream, B, max_pts,
-                           max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+        launch_attaching(ctx, t.stop != nullptr, kern, dim3((B + 1) / 2), dim3(64), per_pair, B, max_pts,
+                         max_obs, cap, Q, dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     } else {
         if ((rc = set_lds(ctx, cycle_qp_wave_kernel<64>, per_group))) return rc;
-        hipLaunchKernelGGL(cycle_qp_wave_kernel<64>, dim3(B), dim3(64), per_group, ctx->stream, B, max_pts, max_obs, cap, Q,
-                           dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
+        launch_attaching(ctx, t.stop != nullptr, cycle_qp_wave_kernel<64>, dim3(B), dim3(64), per_group, B, max_pts, max_obs, cap, Q,
+                         dp_s, dp_l, dp_len, obs_s, obs_l, n_obs, start, path_s, path_l, path_len, status);
     }
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
@@ -1451,21 +1469,32 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->back_stream, front_done, 0));
         ctx->stream = ctx->back_stream;        // ~LaneSwap puts the main stream back
     }
+    // The two events the NEXT call's front stage waits for (densification done, path QP done) are signalled by the dispatches
+    // themselves where possible: a marker packet behind each idled the back queue ~6 us, and with the edge kernel's round-4 diet
+    // the back queue is what bounds the step.
+    const bool want_enrich_ev = staged && !enrich_front && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH] != 0;
+    ctx->attach_stop = want_enrich_ev ? lane.ln->ev_enrich : nullptr;
+    ctx->stop_attached = false;
     if (!enrich_front &&
         (rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
-                            deferred ? d_term : nullptr, d_no, d_rows)))
+                            deferred ? d_term : nullptr, d_no, d_rows))) {
+        ctx->attach_stop = nullptr;
         return rc;
-    if (staged && !enrich_front && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH]) {
-        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_enrich, ctx->stream));
+    }
+    ctx->attach_stop = nullptr;
+    if (want_enrich_ev) {
+        if (!ctx->stop_attached) EMP_HIP(ctx, hipEventRecord(lane.ln->ev_enrich, ctx->stream));
         lane.ln->enrich_valid = true;
     } else if (staged) {
         lane.ln->enrich_valid = false;
     }
-    if ((rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen,
-                           d_st)))
-        return rc;
+    ctx->attach_stop = staged ? lane.ln->ev_qp : nullptr;
+    ctx->stop_attached = false;
+    rc = dev_cycle_qp(ctx, B, max_pts, mo, Q, d_dps, d_dpl, d_dplen, d_os, d_ol, d_no, d_start, d_ps, d_pl, d_plen, d_st);
+    ctx->attach_stop = nullptr;
+    if (rc) return rc;
     if (staged) {
-        EMP_HIP(ctx, hipEventRecord(lane.ln->ev_qp, ctx->stream));
+        if (!ctx->stop_attached) EMP_HIP(ctx, hipEventRecord(lane.ln->ev_qp, ctx->stream));
         lane.ln->qp_valid = true;
     }
     const int path_cap = (max_pts + Q.decimate - 1) / Q.decimate + (Q.midpoint ? 1 : 0);

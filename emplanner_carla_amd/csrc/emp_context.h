@@ -84,6 +84,11 @@ struct emp_ctx {
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
     int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 0, 1, 1};
     hipEvent_t edge_wait = nullptr;     // EMP_OPT_EDGE_AFTER_ENRICH: what the next edge-cost launch waits for on its stream
+    // STAGED: an event the next densification / path-QP launch is asked to signal from its own dispatch (hipExtLaunchKernelGGL's
+    // stop event) instead of a marker packet behind it - a marker idles the back queue ~6 us, twice per step; `stop_attached`
+    // says whether the launcher did (it does not while the kernel carries timing events)
+    hipEvent_t attach_stop = nullptr;
+    bool stop_attached = false;
     hipEvent_t sweep_marker = nullptr;  // EMP_OPT_SWEEP_EXCLUSIVE: recorded on the front stream behind the sweep (emp_api.hip)
     int back_stream_cus = -1;           // the CU count back_stream was created with (-1: no back stream yet)
     // EMP_OPT_SWEEP_EXCLUSIVE: the event the next sweep launch waits for on its own stream (the previous call's back stage)

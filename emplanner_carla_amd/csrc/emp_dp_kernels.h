@@ -156,10 +156,15 @@ __device__ __forceinline__ bool obstacle_box_in_reach(double os, double ol, doub
 // MASK: the type of the per-column reach mask - 64 bits, or 32 when the call's obstacle rows hold at most 32 slots (the first-set-bit
 // walk over a 64-bit mask in vector registers costs twice the instructions; obstacles beyond the mask's width take the full test
 // per edge either way).
+// box_dx2 (the tiled edge kernel; else nullptr): this scene's slice [mask width] of the wavefront's LDS scratch for the longitudinal
+// half of the box test - (max(s0 - os, os - s9, 0))^2 depends on the scene, the column and the obstacle only, so the scene's `row`
+// lanes compute it once per column (lane i the obstacles i, i + row, ...) and the `row` source rows read it back: five of the
+// twelve vector instructions of every box test.  DS operations of a wavefront execute in issue order: no barrier but the
+// compiler's.  Same operands and operations as obstacle_box_in_reach.
 template <int ROW = 0, typename MASK = unsigned long long, typename Store>
 __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, double ps, int nob, const double* tab,
                                                const double* t_smp, const double* my_obs_s, const double* my_obs_l,
-                                               Store&& store) {
+                                               Store&& store, double* box_dx2 = nullptr) {
     constexpr int kMaskBits = (int)sizeof(MASK) * 8;
     const int row = ROW > 0 ? ROW : P.row, rr = row * row;
     const int nmask = min(nob, kMaskBits);
@@ -171,6 +176,14 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
     for (int m = 0; m < nmask; ++m) {
         const double os = my_obs_s[m];
         if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= (MASK)1 << m;
+    }
+    if (box_dx2) {
+        for (int m = i; m < nmask; m += row) {
+            const double os = my_obs_s[m];
+            const double dx = fmax(fmax(s0 - os, os - s9), 0.0);
+            box_dx2[m] = dx * dx;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     for (int k = 0; k < row; ++k) {
         const int p = k * row + i;
@@ -184,7 +197,14 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         double coll = 0.0;
         for (MASK rest = near_s; rest; rest &= rest - 1) {                 // ascending m, as the reference
             const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
-            const double os = my_obs_s[m], ol = my_obs_l[m];
+            const double ol = my_obs_l[m];
+            if (box_dx2) {
+                const double dy = fmax(fmax(l_lo - ol, ol - l_hi), 0.0);
+                if (!(box_dx2[m] + dy * dy < 36.5)) continue;                   // obstacle_box_in_reach: contributes exactly 0
+                coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, my_obs_s[m], ol, P.w_coll);
+                continue;
+            }
+            const double os = my_obs_s[m];
             if (!obstacle_box_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;   // contributes exactly 0
             coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
         }
@@ -195,6 +215,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
         }
         store(k, (smooth + coll) + tab[(kSamples + 4) * rr + p]);
     }
+    if (box_dx2) __builtin_amdgcn_wave_barrier();      // the next column's fill comes after every read of this one
 }
 
 // grid = (tiles, column chunks), block = 256.  Dynamic LDS: the pair table (copied from `pair_tab`),
@@ -223,6 +244,9 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
     double* t_obs_l = t_obs_s + P.S * P.max_obs;
     double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples + 2] sample offsets t_n, then sum t_n and sum t_n^2
+    // per wavefront: [S][mask width] longitudinal box terms of the column it works on (dp_edge_column: box_dx2)
+    const int box_w = min(P.max_obs, (int)sizeof(MASK) * 8);
+    double* box_all = t_smp + kSamples + kSampleMoments;
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
 
@@ -266,6 +290,7 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     const int nob = min(max(n_obs[b], 0), P.max_obs);      // a count beyond the row's capacity is clamped, never followed
     const double* my_obs_s = t_obs_s + s * P.max_obs;
     const double* my_obs_l = t_obs_l + s * P.max_obs;
+    double* my_box = box_all + ((size_t)(tid >> 6) * P.S + s) * box_w;
     for (int j = j_begin + (tid >> 6); j < j_end; j += (int)(blockDim.x >> 6)) {
         // (the sample offsets t_n are the same for every lane: read through the kernel argument they come back in scalar
         // registers, where the LDS copy costs a vector move and an LDS read per pair of them in every scan)
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
             } else {
                 edge[(size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + i * row + k] = cost;
             }
-        });
+        }, my_box);
     }
 }
 
