@@ -694,3 +694,36 @@ def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner, opti
         planner.set_pipeline(False)
         for k, v in old.items():
             planner.set_option(k, v)
+
+
+def test_measurement_entry_points_of_the_sweep(planner):
+    """emp_kernel_samples (the per-launch durations behind emp_kernel_ms) and the in-kernel clock probe
+    (EMP_OPT_SWEEP_CLOCK_PROBE: emp_sweep_clock_mhz, emp_sweep_probe_spans) on staged steps of 2048 scenes: one sample per
+    launch whose mean is the reported mean, a shader clock in the chip's range, wavefronts that start within microseconds of
+    each other and finish inside the launch's event-measured duration - and the probe changes no result."""
+    import torch
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    host = _host_inputs(S.make_batch(range(2048), cfg))
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in host.items()}
+    plain = _plan_resident(planner, cfg, host)
+    planner.set_option("sweep_clock_probe", 1)
+    planner.set_pipeline("staged")
+    planner.set_timing(True, only="dp_sweep")
+    try:
+        with torch.cuda.stream(planner.torch_stream()):
+            res = [planner.plan_cycle(p, q, sp, **dev) for _ in range(8)]
+        planner.synchronize()
+        smp = planner.kernel_samples("dp_sweep")
+        assert len(smp) == planner.kernel_launches("dp_sweep") == 8 and (smp > 0).all()
+        assert abs(float(smp.mean()) - planner.kernel_ms("dp_sweep")) < 1e-6
+        mhz, mean_us, max_us = planner.sweep_clock()
+        assert 1000.0 < mhz < 3000.0 and 0.0 < mean_us <= max_us
+        spread_us, span_us = planner.sweep_probe_spans()
+        assert 0.0 <= spread_us < span_us and max_us <= span_us + 1e-9
+        assert span_us < float(smp.mean()) * 1e3 * 1.5 + 5.0          # the wavefronts live inside the launch
+        _assert_same(plain, {k: getattr(res[-1], k).cpu().numpy() for k in OUTPUTS}, "staged call with the clock probe on")
+    finally:
+        planner.set_timing(False)
+        planner.set_pipeline(False)
+        planner.set_option("sweep_clock_probe", 0)
