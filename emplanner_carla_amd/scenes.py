@@ -72,11 +72,16 @@ class Scene:
     sl_start: np.ndarray = field(default=None)  # (4,) s, l, dl, ddl
 
 
-def _arc(rng, n_ref, ref_ds):
-    # gentle curvature: the reference projects every obstacle on the tangent line at the FIRST
-    # obstacle's match point (quirk of planning_utils.py:413), so its lateral error grows as
-    # (delta s)^2 / (2 R); R >= 1500 m keeps that below ~1.7 m over 70 m
-    radius = rng.uniform(1500.0, 6000.0)
+#: default arc radii: gentle curvature.  The reference projects every obstacle on the tangent line at the FIRST
+#: obstacle's match point (quirk of planning_utils.py:413), so its lateral error grows as (delta s)^2 / (2 R);
+#: R >= 1500 m keeps that below ~1.7 m over 70 m
+GENTLE_ARCS = (1500.0, 6000.0)
+#: SURVEY.md section 8(d)'s own radii: the quirk above bends the S-L picture by up to 16 m over 70 m at R = 150 m
+SURVEY_ARCS = (150.0, 1000.0)
+
+
+def _arc(rng, n_ref, ref_ds, radius_range=GENTLE_ARCS):
+    radius = rng.uniform(radius_range[0], radius_range[1])
     sign = 1.0 if rng.random() < 0.5 else -1.0
     kappa = sign / radius
     phi0 = rng.uniform(-np.pi, np.pi)
@@ -131,8 +136,9 @@ def _worst_obstacles(rng, n, horizon):
 
 
 def make_scene(seed: int, cfg: LatticeConfig = CFG2, origin_index: int = 5, start_ahead: float = 2.0,
-               blocked_fraction: float = 0.1, dist: str = "corridor") -> Scene:
-    """Scene ``seed``.
+               blocked_fraction: float = 0.1, dist: str = "corridor", radius_range=GENTLE_ARCS) -> Scene:
+    """Scene ``seed``.  ``radius_range``: the arc radius is drawn from U(radius_range) (first draw of the scene's
+    generator, so the default leaves every existing scene bit-identical); ``SURVEY_ARCS`` is SURVEY.md 8(d)'s range.
 
     Obstacle layout: the reference's quirked smoothness cost makes lateral moves beyond
     s ~ 28 m dearer than a collision (5000 * sum(dddl_quirk^2) ~ 1.5e6 * s^4 for one 1.5 m row
@@ -144,7 +150,7 @@ def make_scene(seed: int, cfg: LatticeConfig = CFG2, origin_index: int = 5, star
     feasible path" branch, path_planning.py:351-352).
     """
     rng = np.random.default_rng(seed)
-    ref, arc = _arc(rng, cfg.n_ref, cfg.ref_ds)
+    ref, arc = _arc(rng, cfg.n_ref, cfg.ref_ds, radius_range)
     radius = 1.0 / abs(arc[3])
     s_origin = origin_index * cfg.ref_ds
     origin_xy, _ = _arc_point(arc, s_origin, rng.normal(0.0, 0.2))
@@ -229,9 +235,25 @@ class SceneBatch:
         return len(self.seeds)
 
 
-def make_batch(seeds, cfg: LatticeConfig = CFG2, **kw) -> SceneBatch:
+#: planning start of the benchmark batch, metres ahead of the ego: NOT a multiple of ``ref_ds``.  With 2.0 (the
+#: fixtures of rounds 1-4) three scenes in four put the start exactly on a reference-line node, where
+#: ``s_map[idx + 1] < s`` (reference path_planning.py:63) is decided by the last bit of a dot product
+BENCH_START_AHEAD = 2.7
+
+
+def survey_geometry_kwargs(seed: int) -> dict:
+    """Scene options of the "tight" fixture and of bench.py's ``survey_leg``: SURVEY.md 8(d)'s arc radii for every
+    scene; even seeds keep the corridor layout (mostly plannable), odd seeds use the survey's own slalom (the
+    reference refuses nearly all of them: status paths); every other PAIR of seeds starts off the nodes."""
+    return dict(radius_range=SURVEY_ARCS, dist="survey" if seed % 2 else "corridor",
+                start_ahead=BENCH_START_AHEAD if (seed // 2) % 2 else 2.0)
+
+
+def make_batch(seeds, cfg: LatticeConfig = CFG2, per_seed=None, **kw) -> SceneBatch:
+    """``per_seed``: optional ``seed -> dict`` of ``make_scene`` options applied on top of ``kw``
+    (e.g. ``survey_geometry_kwargs``)."""
     seeds = np.asarray(list(seeds), dtype=np.int64)
-    scenes = [make_scene(int(s), cfg, **kw) for s in seeds]
+    scenes = [make_scene(int(s), cfg, **{**kw, **(per_seed(int(s)) if per_seed else {})}) for s in seeds]
     B = len(scenes)
     mo = max(cfg.n_obs, 1)
     obs_xy = np.zeros((B, mo, 2))

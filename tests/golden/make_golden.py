@@ -130,8 +130,10 @@ def stack(dicts, keys_shapes):
     return res
 
 
-def cycles_for(pp, pu, cfg, seeds, **mode):
-    scenes = [S.make_scene(int(s), cfg) for s in seeds]
+def cycles_for(pp, pu, cfg, seeds, scene_kw=None, per_seed=None, **mode):
+    """``scene_kw`` / ``per_seed``: options of ``scenes.make_scene`` for every scene / as a function of the seed."""
+    scene_kw = dict(scene_kw or {})
+    scenes = [S.make_scene(int(s), cfg, **{**scene_kw, **(per_seed(int(s)) if per_seed else {})}) for s in seeds]
     outs = [run_cycle(pp, pu, sc, cfg, **mode) for sc in scenes]
     mo = max(cfg.n_obs, 1)
     shapes = dict(s_map=(cfg.n_ref,), obs_s=(mo,), obs_l=(mo,), begin=(2,), start=(4,), deri=(7,), dp_len=(),
@@ -140,7 +142,7 @@ def cycles_for(pp, pu, cfg, seeds, **mode):
                   traj=(NTRAJ, 4), traj_len=(), smooth_stationarity=(), status=(), dp_infeasible_banner=(),
                   n_qp_calls=())
     res = stack(outs, shapes)
-    batch = S.make_batch(seeds, cfg)
+    batch = S.make_batch(seeds, cfg, per_seed=per_seed, **scene_kw)
     res.update(seeds=batch.seeds, in_ref=batch.ref, in_origin_xy=batch.origin_xy, in_start_xy=batch.start_xy,
                in_start_v=batch.start_v, in_start_a=batch.start_a, in_obs_xy=batch.obs_xy, in_n_obs=batch.n_obs)
     return res
@@ -288,6 +290,16 @@ def main():
         np.savez_compressed(os.path.join(outdir, f"cycle_{cfg.name}.npz"), **res)
         st = res["status"]
         print(cfg.name, "scenes", len(st), "status counts", {int(k): int((st == k).sum()) for k in np.unique(st)},
+              "dp infeasible", int(res["dp_infeasible_banner"].sum()))
+    # ---- the metric's lattice on SURVEY.md 8(d)'s own geometry (arc radii 150-1000 m, half of the scenes with the
+    # survey's slalom layout, half of them started off the reference-line nodes), and the first scenes of the
+    # benchmark batch (gentle arcs, corridor layout, start off the nodes: scenes.BENCH_START_AHEAD)
+    for tag, kw in (("tight", dict(per_seed=S.survey_geometry_kwargs)),
+                    ("bench", dict(scene_kw=dict(start_ahead=S.BENCH_START_AHEAD)))):
+        res = cycles_for(pp, pu, S.CFG2, list(range(32)), **kw)
+        np.savez_compressed(os.path.join(outdir, f"cycle_{S.CFG2.name}_{tag}.npz"), **res)
+        st = res["status"]
+        print(S.CFG2.name, tag, "status counts", {int(k): int((st == k).sum()) for k in np.unique(st)},
               "dp infeasible", int(res["dp_infeasible_banner"].sum()))
     # ---- driver variants on the default lattice (test_7: no decimation / no midpoint; test_5/6: no QP)
     for tag, mode in (("t7", dict(decimate=1, use_qp=True, midpoint=False)),

@@ -8,13 +8,14 @@ import pytest
 
 from emplanner_carla_amd import scenes as S
 from oracle import exact as ex
-from tests.conftest import assert_rel, load_golden
+from tests.conftest import assert_dp_l_vs_reference, assert_rel, load_golden
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
 GOLD = [(S.CFG1, "cycle_cfg1_20x5_0obs.npz"), (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz"),
-        (S.CFG2, "cycle_cfg2_40x9_8obs.npz")]
+        (S.CFG2, "cycle_cfg2_40x9_8obs.npz"), (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz"),
+        (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz")]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +35,7 @@ def _golden_inputs(g):
     return (np.nan_to_num(g["obs_s"]), np.nan_to_num(g["obs_l"]), g["in_n_obs"].astype(np.int32), g["start"].copy())
 
 
-@pytest.mark.parametrize("cfg,fname", GOLD[1:], ids=[c[0].name for c in GOLD[1:]])
+@pytest.mark.parametrize("cfg,fname", GOLD[1:], ids=[c[1][6:-4] for c in GOLD[1:]])
 def test_edge_costs_bit_exact_vs_exact_oracle(planner, cfg, fname):
     obs_s, obs_l, n_obs, start = _golden_inputs(load_golden(fname))
     p = _params(cfg)
@@ -80,7 +81,7 @@ def test_tiled_layout_matches_canonical(planner):
     assert np.array_equal(got[live], want[live])
 
 
-@pytest.mark.parametrize("cfg,fname", GOLD, ids=[c[0].name for c in GOLD])
+@pytest.mark.parametrize("cfg,fname", GOLD, ids=[c[1][6:-4] for c in GOLD])
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused", "two_kernel"])
 def test_dp_rows_index_exact_vs_reference(planner, cfg, fname, mode):
     g = load_golden(fname)
@@ -101,7 +102,7 @@ def test_dp_rows_index_exact_vs_reference(planner, cfg, fname, mode):
         n = int(g["dp_len"][b])
         assert ln[b] == n, "point count (int() truncation rule)"
         assert np.array_equal(ps[b, :n], g["dp_s"][b, :n]), "station s must be bit-exact with the reference"
-        assert_rel(pl[b, :n], g["dp_l"][b, :n], RTOL, "dp_l vs reference")
+        assert_dp_l_vs_reference(pl[b, :n], g["dp_l"][b, :n])
         xs, xl = xpaths[b]
         assert np.array_equal(pl[b, :n], np.asarray(xl)), "dp_l must be bit-exact with the exact oracle"
 

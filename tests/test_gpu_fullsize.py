@@ -17,11 +17,15 @@ import pytest
 
 from emplanner_carla_amd import scenes as S
 from oracle import exact as ex
-from tests.conftest import assert_rel, load_golden
+from tests.conftest import assert_dp_l_vs_reference, assert_rel, load_golden
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-6
+#: the benchmark batch (bench.py's default workload): gentle arcs, corridor layout, planning start OFF the reference-line
+#: nodes.  Until round 4 it started ON node 6 (start_ahead = 2.0), where `s_map[idx + 1] < s` (path_planning.py:63) is a
+#: tie decided by the host's libm: that batch is kept as the dedicated tie test below.
+BENCH = dict(start_ahead=S.BENCH_START_AHEAD)
 OUTPUTS = ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status")
 
 
@@ -83,25 +87,27 @@ def _assert_same(a, b, what):
                                  f"scene {i}: {detail}")
 
 
-def _check_golden_subset(out):
-    g = load_golden("cycle_cfg2_40x9_8obs.npz")
+def _check_golden_subset(out, fname="cycle_cfg2_40x9_8obs_bench.npz", min_checked=20):
+    """The imported reference's own outputs for seeds 0..31 (tests/golden/make_golden.py), which are the head of `out`."""
+    g = load_golden(fname)
     n = len(g["seeds"])
     assert np.array_equal(g["seeds"], np.arange(n)), "the fixture holds seeds 0..n-1, the head of the full batch"
     checked = 0
     for b in range(n):
         k = int(g["dp_len"][b])
         assert out["dp_len"][b] == k
-        assert_rel(out["dp_l"][b, :k], g["dp_l"][b, :k], RTOL, f"scene {b}: DP path")
+        assert_dp_l_vs_reference(out["dp_l"][b, :k], g["dp_l"][b, :k], f"scene {b}: DP path")
         assert bool(out["status"][b] & 1) == bool(g["dp_infeasible_banner"][b])
         if g["status"][b] != 0:
-            assert out["status"][b] & ~1
+            assert out["status"][b] & {3: 4, 4: 8, 5: 16}[int(g["status"][b])], f"scene {b}: refused for the reference's reason"
             continue
+        assert (out["status"][b] & ~1) == 0, f"scene {b}: status {out['status'][b]}"
         m = int(g["traj_len"][b])
         assert out["traj_len"][b] == m
         assert_rel(out["traj"][b, :m, :3], g["traj"][b, :m, :3], RTOL, f"scene {b} trajectory")
         assert_rel(out["traj"][b, :m, 3], g["traj"][b, :m, 3], RTOL, f"scene {b} curvature")
         checked += 1
-    assert checked >= 20
+    assert checked >= min_checked
 
 
 def _check_properties(planner, cfg, host, out):
@@ -124,7 +130,7 @@ def _check_properties(planner, cfg, host, out):
 def test_configs2_4096_scenes(planner):
     cfg = S.CFG2
     B = 4096
-    batch = S.make_batch(range(B), cfg)
+    batch = S.make_batch(range(B), cfg, **BENCH)
     host = _host_inputs(batch)
     out = _plan_resident(planner, cfg, host)
     _check_golden_subset(out)
@@ -154,9 +160,9 @@ def _port_cycle(cfg, batch, i, **kw):
                          verbose=False, **kw)
 
 
-def test_knot_tie_scenes_of_the_benchmark_batch_are_the_other_branch_and_nothing_else(planner):
-    """Seeds 177 and 3204 of the 4096-scene benchmark batch (and a few of their neighbours as controls).  The scene
-    generator puts the planning start on the normal through reference-line node 6, so `while s_map[idx + 1] < s`
+def test_knot_tie_scenes_of_the_on_node_batch_are_the_other_branch_and_nothing_else(planner):
+    """The dedicated tie test: seeds 177 and 3204 of the ON-NODE batch (start_ahead = 2.0; rounds 1-4 benchmarked it)
+    and a few of their neighbours as controls.  There the scene generator puts the planning start on the normal through reference-line node 6, so `while s_map[idx + 1] < s`
     (path_planning.py:62-63) compares two numbers that agree to an ulp and the segment the first trajectory points are
     extrapolated from is decided by the last bit of cos / sin / dot on the machine at hand (0.45 mm apart: kappa ds^2).
     On those two scenes the device lands on the other side than the port on this round's host.  What must hold, whatever
@@ -165,7 +171,7 @@ def test_knot_tie_scenes_of_the_benchmark_batch_are_the_other_branch_and_nothing
     tolerance of both is a failure."""
     cfg = S.CFG2
     seeds = [176, 177, 178, 3203, 3204, 3205, 5, 1024]
-    batch = S.make_batch(seeds, cfg)
+    batch = S.make_batch(seeds, cfg, start_ahead=2.0)
     out = _plan_resident(planner, cfg, _host_inputs(batch))
     tie_tol = 8e-15
     flipped_needed = 0
@@ -204,7 +210,7 @@ def test_start_off_the_reference_line_nodes_has_no_tie(planner):
     included."""
     cfg = S.CFG2
     seeds = list(range(170, 186)) + list(range(3200, 3208))
-    batch = S.make_batch(seeds, cfg, start_ahead=2.7)
+    batch = S.make_batch(seeds, cfg, **BENCH)
     out = _plan_resident(planner, cfg, _host_inputs(batch))
     compared = 0
     for i, seed in enumerate(seeds):
@@ -222,12 +228,55 @@ def test_start_off_the_reference_line_nodes_has_no_tie(planner):
     assert compared >= 16
 
 
+def test_on_node_batch_still_matches_its_reference_outputs(planner):
+    """The round 1-4 batch (start ON node 6): its 32 reference-generated scenes inside a 1024-scene batch."""
+    cfg = S.CFG2
+    out = _plan_resident(planner, cfg, _host_inputs(S.make_batch(range(1024), cfg, start_ahead=2.0)))
+    _check_golden_subset(out, "cycle_cfg2_40x9_8obs.npz")
+
+
+def test_survey_geometry_batch(planner):
+    """SURVEY 8(d)'s own geometry on the GPU: 2048 scenes on arcs of radius 150-1000 m, odd seeds with the survey's
+    slalom layout, every other pair started off the nodes (scenes.survey_geometry_kwargs).  On tight arcs the reference's
+    `match_point_index_list[0]` quirk (planning_utils.py:413) and its tangent-line projection (:414-424) bend the S-L
+    picture by metres.  Checked: the imported reference's outputs for seeds 0..31 (the fixture), the faithful port on a
+    sample of later seeds (outcome for outcome, trajectories at 1e-6), permutation / repetition bit-identical."""
+    cfg = S.CFG2
+    B = 2048
+    batch = S.make_batch(range(B), cfg, per_seed=S.survey_geometry_kwargs)
+    host = _host_inputs(batch)
+    out = _plan_resident(planner, cfg, host)
+    _check_golden_subset(out, "cycle_cfg2_40x9_8obs_tight.npz", min_checked=15)
+    ok = (out["status"] & ~1) == 0
+    assert 0.3 < ok.mean() < 0.8 and (out["status"] & 4).any() and (out["status"] & 8).any() and (out["status"] & 1).any()
+    compared = 0
+    for i in (1000, 1001, 1002, 1003, 1500, 1501, 1502, 1503, 2040, 2041, 2042, 2047):
+        try:
+            port = _port_cycle(cfg, batch, i)
+        except IndexError:
+            assert out["status"][i] & 4, f"seed {i}: the reference raises IndexError"
+            continue
+        p_ok = port.get("qp_status", "optimal") == "optimal" and port["smooth_status"] == "optimal"
+        assert p_ok == bool(ok[i]), f"seed {i}: outcome"
+        assert bool(out["status"][i] & 1) == (not port["dp_feasible"])
+        if not p_ok:
+            continue
+        want = np.asarray(port["trajectory"], dtype=np.float64)
+        assert out["traj_len"][i] == len(want)
+        assert_rel(out["traj"][i, :len(want)], want, RTOL, f"seed {i} (tight arc)")
+        compared += 1
+    assert compared >= 4
+    _assert_same(out, _plan_resident(planner, cfg, host), "repeated call")
+    perm = np.random.default_rng(17).permutation(B)
+    _assert_same({k: v[perm] for k, v in out.items()}, _plan_resident(planner, cfg, host, perm), "permuted batch")
+
+
 def test_configs3_32768_scenes_and_rank_shards(planner):
     from emplanner_carla_amd import dist as emp_dist
     from emplanner_carla_amd.api import dp_params_from_cfg
     cfg = S.CFG2
     B = 32768
-    batch = S.make_batch(range(B), cfg)
+    batch = S.make_batch(range(B), cfg, **BENCH)
     host = _host_inputs(batch)
     out = _plan_resident(planner, cfg, host)
     _check_golden_subset(out)
@@ -287,7 +336,7 @@ def test_rigid_motion_of_the_scene_moves_the_plan_with_it(planner):
     cfg = S.CFG2
     B = 4096
     m = 23
-    batch = S.make_batch(range(B), cfg)
+    batch = S.make_batch(range(B), cfg, **BENCH)
     host = _host_inputs(batch)
     out = _plan_resident(planner, cfg, host)
     rng = np.random.default_rng(5)
@@ -581,7 +630,7 @@ def _benchmark_batch_under(planner, option, value, time_kernel=None):
     """The 4096 benchmark scenes through the whole cycle with one emp_set_option value in force (restored afterwards).
     ``time_kernel``: also return the mean duration (ms) of that kernel over the call."""
     cfg = S.CFG2
-    host = _host_inputs(S.make_batch(range(4096), cfg))
+    host = _host_inputs(S.make_batch(range(4096), cfg, **BENCH))
     old = planner.get_option(option)
     planner.set_option(option, value)
     try:
@@ -642,7 +691,7 @@ def test_small_shards_equal_their_slice_of_the_full_batch(planner):
     neighbours in the batch."""
     cfg = S.CFG2
     B = 4096
-    host = _host_inputs(S.make_batch(range(B), cfg))
+    host = _host_inputs(S.make_batch(range(B), cfg, **BENCH))
     out = _plan_resident(planner, cfg, host)
     for a, n in ((0, 512), (3584, 512), (1024, 256), (777, 100), (4089, 7), (5, 1)):
         sl = slice(a, a + n)

@@ -66,12 +66,21 @@ def test_dp_bit_exact_on_random_lattices(planner, i):
         np.testing.assert_array_equal(pl_[k, :ln[k]], xl)
 
 
+#: scene options of the cycle fuzz: the generator's default geometry, and SURVEY 8(d)'s (arc radii 150-1000 m, the survey's
+#: slalom on odd seeds, starts off the nodes on every other pair - scenes.survey_geometry_kwargs).  Tight arcs only for the
+#: tiled lattices (<= 32 rows): there the faithful port is bit-identical to the imported reference (VERDICT r04's probe)
+GEOMETRIES = {"gentle": {}, "survey_arcs": dict(per_seed=S.survey_geometry_kwargs)}
+
+
+@pytest.mark.parametrize("geometry", list(GEOMETRIES))
 @pytest.mark.parametrize("i", range(len(SHAPES)))
-def test_cycle_vs_port_on_random_lattices(planner, i):
+def test_cycle_vs_port_on_random_lattices(planner, i, geometry):
     from emplanner_carla_amd.api import dp_params_from_cfg, qp_params, smooth_params, max_path_points
     cfg = _cfg(i)
+    if geometry != "gentle" and cfg.row > 32:
+        pytest.skip("tight arcs are run on the tiled lattices")
     seeds = list(range(1000 + 10 * i * SCALE, 1000 + 10 * i * SCALE + 5 * SCALE))
-    b = S.make_batch(seeds, cfg)
+    b = S.make_batch(seeds, cfg, **GEOMETRIES[geometry])
     P = b.ref.shape[1]
     p = dp_params_from_cfg(cfg)
     r = planner.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(),
@@ -100,7 +109,7 @@ def test_cycle_vs_port_on_random_lattices(planner, i):
         assert_rel(r.traj[k, :m, :3], want[:, :3], 1e-6, "x, y, theta")
         assert_rel(r.traj[k, :m, 3], want[:, 3], 1e-6, "kappa")
         compared += 1
-    assert compared >= 1 or cfg.n_obs >= 9
+    assert compared >= 1 or cfg.n_obs >= 9 or geometry != "gentle"
 
 
 @pytest.mark.parametrize("row", [33, 80, 200])

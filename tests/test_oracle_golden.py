@@ -16,7 +16,7 @@ from emplanner_carla_amd import scenes as S
 from oracle import exact as ex
 from oracle import qp_dense
 from oracle import ref_port as op
-from tests.conftest import assert_rel, load_golden
+from tests.conftest import assert_dp_l_vs_reference, assert_rel, load_golden
 
 RTOL = 1e-6  # north-star tolerance (BASELINE.json)
 
@@ -40,6 +40,8 @@ def _rows_from_path(cfg, dp_s, dp_l, n):
 CYCLES = [(S.CFG1, "cycle_cfg1_20x5_0obs.npz", {}),
           (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz", {}),
           (S.CFG2, "cycle_cfg2_40x9_8obs.npz", {}),
+          (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz", {}),       # SURVEY 8(d)'s geometry: arc radii 150-1000 m
+          (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz", {}),       # first scenes of the benchmark batch (start off the nodes)
           (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t7.npz", dict(decimate=1, use_qp=True, midpoint=False)),
           (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t6.npz", dict(decimate=1, use_qp=False, midpoint=False))]
 
@@ -49,7 +51,9 @@ def test_faithful_port_full_cycle(cfg, fname, mode):
     g = load_golden(fname)
     n_scene = len(g["seeds"])
     # the faithful port is slow (~0.5 s per cfg2 scene): sample the big config
-    idx = range(n_scene) if cfg is not S.CFG2 else (0, 3, 5, 9, 17)
+    # (tight: corridor and survey layouts, starts on and off the nodes, an IndexError scene, planned survey scenes)
+    idx = range(n_scene) if cfg is not S.CFG2 else {"tight": (0, 2, 3, 9, 11, 29), "bench": (0, 3, 9)}.get(
+        fname[:-4].rsplit("_", 1)[-1], (0, 3, 5, 9, 17))
     kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
     for i in idx:
         k = int(g["in_n_obs"][i])
@@ -89,7 +93,9 @@ def test_faithful_port_full_cycle(cfg, fname, mode):
 
 @pytest.mark.parametrize("cfg,fname", [(S.CFG1, "cycle_cfg1_20x5_0obs.npz"),
                                        (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz"),
-                                       (S.CFG2, "cycle_cfg2_40x9_8obs.npz")])
+                                       (S.CFG2, "cycle_cfg2_40x9_8obs.npz"),
+                                       (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz"),
+                                       (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz")])
 def test_exact_oracle_dp_index_exact(cfg, fname):
     """Closed-form DP == reference DP: rows index-exact on every golden scene, s exact, l 1e-6."""
     g = load_golden(fname)
@@ -108,7 +114,7 @@ def test_exact_oracle_dp_index_exact(cfg, fname):
         s, l = paths[i]
         assert len(s) == n
         assert np.array_equal(np.asarray(s), g["dp_s"][i, :n]), "station s must be bit-exact"
-        assert_rel(l, g["dp_l"][i, :n], RTOL, "dp_l")
+        assert_dp_l_vs_reference(l, g["dp_l"][i, :n])
         assert bool(g["dp_infeasible_banner"][i]) == (not feasible[i])
 
 
