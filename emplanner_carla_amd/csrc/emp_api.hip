@@ -49,8 +49,8 @@ static size_t tiled_elems(const DpDev& d) {
 // pair table of the lattice (emp_dp_kernels.h dp_pair_table_kernel): rebuilt only when the lattice parameters change,
 // stream-ordered before its first use
 static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
-    const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, 0.0, 0.0};
-    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kSamples + kSampleMoments) * sizeof(double);
+    const double key[8] = {(double)d.row, d.sample_s, d.sample_l, d.w0, d.w1, d.w_ref, d.w2, 0.0};
+    const size_t tab_bytes = ((size_t)kTableFields * d.row * d.row + kTableTail) * sizeof(double);
     emp_ctx::PairTable& pt = ctx->pair_tables[ctx->active_lane];
     emp_ctx::Buf& tb = pt.buf;
     if (tb.bytes < tab_bytes) {
@@ -83,8 +83,15 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     }
     // per block: pair table, the tile's obstacles, sample offsets; per wavefront: the longitudinal box terms of its column
     // ([S][mask width] doubles, emp_dp_kernels.h: box_dx2)
-    const size_t lds_fixed = ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kSamples + kSampleMoments) * sizeof(double);
-    const size_t lds_wave = (size_t)d.S * (d.max_obs <= 32 ? d.max_obs : (d.max_obs < 64 ? d.max_obs : 64)) * sizeof(double);
+    // EMP_OPT_EDGE_FORM: 0 (default) the work-ring kernel (emp_dp_kernels.h dp_edge_ring_kernel: edges with obstacles in reach are
+    // queued per wavefront and scanned one entry per lane), 1 the lockstep kernel of rounds 1-4 - bit-identical tensors.  The ring
+    // form needs every obstacle of a row inside one 64-bit mask and the column index inside 16 bits; anything else is lockstep.
+    const bool ring = ctx->opt[EMP_OPT_EDGE_FORM] == 0 && d.max_obs <= 64 && d.col <= 65535;
+    const bool m32 = d.max_obs <= 32;          // every obstacle of a row fits a 32-bit reach mask
+    const size_t lds_fixed = ring ? ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + 64) * sizeof(double)
+                                  : ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kTableTail) * sizeof(double);
+    const size_t lds_wave = ring ? 2 * (size_t)d.S * d.max_obs * sizeof(double) + (m32 ? sizeof(EdgeRing<unsigned>) : sizeof(EdgeRing<unsigned long long>))
+                                 : (size_t)d.S * (d.max_obs <= 32 ? d.max_obs : (d.max_obs < 64 ? d.max_obs : 64)) * sizeof(double);
     size_t lds = lds_fixed + 2 * lds_wave;        // the block-size rule below prices a two-wavefront block; the launch its own
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
     int ncol = d.col - 1;
@@ -97,11 +104,30 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // EMP_OPT_EDGE_BLOCK (emp_set_option) overrides it.
     const int eb_env = ctx->opt[EMP_OPT_EDGE_BLOCK];
     int wpb = 4;
-    {
+    if (!ring) {
         const int blocks_per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
         wpb = (20 + blocks_per_cu - 1) / (blocks_per_cu > 0 ? blocks_per_cu : 1);
         if (wpb < 2) wpb = 2;
         if (wpb > 16) wpb = 16;
+    } else {
+        // the ring form's wavefronts carry ~3 KB of LDS each: the smallest block that puts sixteen wavefronts on a CU (or as many
+        // as the LDS allows).  Small blocks matter in the staged step, where a block must find all its slots free at once beside
+        // the previous batch's path-QP wavefronts: at 40 x 9 two-wavefront blocks give 0.241 ms per step, three 0.258, four 0.266,
+        // eight 0.293 - although ALONE the kernel is fastest with four (profiles/r05_edge/README.md)
+        int best = 0;
+        for (int w = 2; w <= 16; ++w) {
+            const size_t l = lds_fixed + (size_t)w * lds_wave;
+            if (l > 160 * 1024) break;
+            best = std::max(best, (int)std::min<size_t>((160 * 1024 / l) * w, 20));
+        }
+        for (int w = 2; w <= 16; ++w) {
+            const size_t l = lds_fixed + (size_t)w * lds_wave;
+            if (l > 160 * 1024) break;
+            if ((int)std::min<size_t>((160 * 1024 / l) * w, 20) >= std::min(best, 16)) {
+                wpb = w;
+                break;
+            }
+        }
     }
     // (a tensor beyond the 256 MiB Infinity Cache - 32768 scenes of the 40 x 9 lattice - keeps four wavefronts per block: the
     // faster front stage otherwise leaves the sweep, which then streams from DRAM for 150 us, beside the previous batch's
@@ -114,7 +140,11 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // each of the block's wavefronts takes whole columns: two per wavefront, or one while that leaves the chip short of blocks
     // (a single scene: 29 us with one column per wavefront, 44 with two); chunk sizes multiples of the wavefront count
     if (ncol > 0) {
-        const int cpw = ((long long)d.tiles * ((ncol + 2 * wpb - 1) / (2 * wpb)) >= 1024) ? 2 : 1;
+        int cpw = ((long long)d.tiles * ((ncol + 2 * wpb - 1) / (2 * wpb)) >= 1024) ? 2 : 1;
+        // (ring form: a wavefront drains its rings once, at the end of its columns - four columns per wavefront while that
+        // still leaves several thousand blocks: 120 x 21 at 4096 scenes 2.18 -> 2.01 ms)
+        if (ring && (long long)d.tiles * ((ncol + 4 * wpb - 1) / (4 * wpb)) >= 4096) cpw = 4;
+        if (ctx->opt[EMP_OPT_EDGE_COLS_PER_WAVE] > 0) cpw = ctx->opt[EMP_OPT_EDGE_COLS_PER_WAVE];
         chunks = (ncol + cpw * wpb - 1) / (cpw * wpb);
         if (chunks < 1) chunks = 1;
     }
@@ -128,14 +158,14 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // the generic instantiation - the same operations either way
     using M32 = unsigned int;
     using M64 = unsigned long long;
-    const bool m32 = d.max_obs <= 32;          // every obstacle of a row fits a 32-bit reach mask
-#define EMP_EDGE_PICK(T)                                                                                              \
-    (d.row == 9 ? (m32 ? dp_edge_kernel<T, 9, M32> : dp_edge_kernel<T, 9, M64>)                                       \
-     : d.row == 21 ? (m32 ? dp_edge_kernel<T, 21, M32> : dp_edge_kernel<T, 21, M64>)                                  \
-     : d.row == 12 ? (m32 ? dp_edge_kernel<T, 12, M32> : dp_edge_kernel<T, 12, M64>)                                  \
-     : d.row == 5 ? (m32 ? dp_edge_kernel<T, 5, M32> : dp_edge_kernel<T, 5, M64>)                                     \
-                  : (m32 ? dp_edge_kernel<T, 0, M32> : dp_edge_kernel<T, 0, M64>))
-    auto kern = tiled ? EMP_EDGE_PICK(true) : EMP_EDGE_PICK(false);
+#define EMP_EDGE_PICK(K, T)                                                                                           \
+    (d.row == 9 ? (m32 ? K<T, 9, M32> : K<T, 9, M64>)                                                                 \
+     : d.row == 21 ? (m32 ? K<T, 21, M32> : K<T, 21, M64>)                                                            \
+     : d.row == 12 ? (m32 ? K<T, 12, M32> : K<T, 12, M64>)                                                            \
+     : d.row == 5 ? (m32 ? K<T, 5, M32> : K<T, 5, M64>)                                                               \
+                  : (m32 ? K<T, 0, M32> : K<T, 0, M64>))
+    auto kern = ring ? (tiled ? EMP_EDGE_PICK(dp_edge_ring_kernel, true) : EMP_EDGE_PICK(dp_edge_ring_kernel, false))
+                     : (tiled ? EMP_EDGE_PICK(dp_edge_kernel, true) : EMP_EDGE_PICK(dp_edge_kernel, false));
 #undef EMP_EDGE_PICK
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -634,11 +664,13 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_ENRICH_ON_FRONT:
         case EMP_OPT_EDGE_AFTER_ENRICH:
         case EMP_OPT_SWEEP_MARKER:
+        case EMP_OPT_EDGE_FORM:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
         case EMP_OPT_SWEEP_VARIANT: ok = value >= 0 && value <= 5; break;
         case EMP_OPT_FUSED_COLUMNS: ok = value >= 0 && value <= 64; break;
+        case EMP_OPT_EDGE_COLS_PER_WAVE: ok = value >= 0 && value <= 256; break;
         case EMP_OPT_BACK_STREAM_CUS: ok = value >= 0 && value <= 512; break;
     }
     EMP_REQUIRE(ctx, ok, "option value out of range (include/emplanner.h, emp_option)");

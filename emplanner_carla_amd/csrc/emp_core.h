@@ -202,6 +202,40 @@ EMP_HD double segment_cost(const Quintic& q, double s0, double sample_s, const d
     return (smooth + coll) + w_ref * S_l;
 }
 
+// The quirked jerk sum of a NEIGHBOUR edge (dl0 = ddl0 = 0), factorised (round 5): the edge's shifted coefficients are h
+// times the unit quintic's, h = l1 - l0, the reference's third-derivative term (path_planning.py:571) is linear in them, so
+// its sum of squares over the samples is (h h) F(s0) with F the unit quintic's sum - evaluated once per (scene, column) by
+// the kernels (emp_dp_kernels.h jerk_unit_sum: the same operations on tabulated u3, u4, u5, T1, T2).
+EMP_HD double neighbour_jerk_factor(double sample_s, double s0) {
+    double T1, T2;
+    sample_moments(sample_s, &T1, &T2);
+    const Quintic u = quintic_shifted(0.0, 0.0, 0.0, 1.0, sample_s);
+    return jerk_quirk_sum(u, s0, T1, T2);
+}
+// Full cost of a neighbour edge from (s0, l0) to (s0 + sample_s, l1) in the generic (untabulated) form: what the tiled, fused
+// and wide edge kernels compute from the pair table (ref: cal_neighbor_cost, path_planning.py:517-585).
+EMP_HD double neighbour_cost(double l0, double l1, double s0, double sample_s, const double* obs_s, const double* obs_l,
+                             int n_obs, double w_collision, double w0, double w1, double w2, double w_ref) {
+    const Quintic q = quintic_shifted(l0, 0.0, 0.0, l1, sample_s);
+    double l_s[kSamples];
+    double S_l = 0.0, S_dl = 0.0, S_ddl = 0.0;
+    for (int i = 0; i < kSamples; ++i) {
+        const double t = sample_t(i, sample_s);
+        const double l = quintic_l(q, t);
+        const double dl = quintic_dl(q, t);
+        const double ddl = quintic_ddl(q, t);
+        l_s[i] = l;
+        S_l = S_l + l * l;
+        S_dl = S_dl + dl * dl;
+        S_ddl = S_ddl + ddl * ddl;
+    }
+    double coll = 0.0;
+    for (int m = 0; m < n_obs; ++m) coll = coll + obstacle_cost(l_s, s0, sample_s, obs_s[m], obs_l[m], w_collision);
+    const double h = l1 - l0;
+    const double smooth = (w0 * S_dl + w1 * S_ddl) + (w2 * (h * h)) * neighbour_jerk_factor(sample_s, s0);
+    return (smooth + coll) + w_ref * S_l;
+}
+
 // number of samples numpy.arange(0, int(span), res) yields (ref: path_planning.py:405/:423)
 EMP_HD int arange_count(double span, double res) {
     const double top = (double)(long long)span;  // int(): truncation toward zero

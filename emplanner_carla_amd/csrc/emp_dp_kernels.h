@@ -32,7 +32,35 @@ struct DpDev {
     double w_coll, w0, w1, w2, w_ref;
 };
 
-constexpr int kTableFields = kSamples + 7;  // l samples, a3, a4, a5, base smooth, ref cost, l_lo, l_hi
+// Pair-table fields behind the kSamples lateral samples (round 5: the three quintic coefficients gave way to ONE jerk
+// weight - see kF_JERK - which takes the table from 17 to 15 fields: 53 instead of 60 KB of LDS at 21 rows)
+constexpr int kF_JERK = kSamples + 0;     // w2 (h h), h = l_cur - l_pre: the quirked jerk term of the edge is this times F(s0)
+constexpr int kF_BASE = kSamples + 1;     // w0 sum dl^2 + w1 sum ddl^2
+constexpr int kF_REF = kSamples + 2;      // w_ref sum l^2
+constexpr int kF_LLO = kSamples + 3;      // min(l_pre, l_cur)
+constexpr int kF_LHI = kSamples + 4;      // max(l_pre, l_cur)
+constexpr int kTableFields = kSamples + 5;
+// behind the fields: the kSamples sample offsets t_n, their two moments (emp_core.h sample_moments) and the UNIT quintic's
+// a3, a4, a5 (the coefficients of the neighbour edge with h = 1)
+constexpr int kUnitQuintic = 3;
+constexpr int kTableTail = kSamples + kSampleMoments + kUnitQuintic;
+
+// The quirked jerk sum of a NEIGHBOUR edge, factorised (round 5).  A neighbour edge starts with dl = ddl = 0, so its
+// shifted coefficients are h times the unit quintic's (a3, a4, a5) = h (u3, u4, u5), h = l_cur - l_pre; the absolute-s
+// coefficients c3, c4, c5 the reference's third-derivative term needs (path_planning.py:571) are linear in (a3, a4, a5), the
+// term is linear in them, and its sum of squares over the ten samples is therefore h^2 times a function of the edge's start
+// abscissa alone:   S_dddl(k -> i, s0) = (h h) F(s0),   F(s0) = jerk_quirk_sum(unit quintic, s0).
+// F is evaluated once per (scene, column) - 28 vector instructions - instead of once per edge; per edge one multiplication
+// by the tabulated w2 (h h) remains.  Same mathematics as jerk_quirk_sum on the edge's own coefficients (rounds 2-4), rounded
+// differently in the last bits; oracle/exact.py states the same operation order and stays the bit-exact target.
+__device__ __forceinline__ double jerk_unit_sum(const double* tail, double s0) {
+    Quintic u;
+    u.a0 = u.a1 = u.a2 = 0.0;
+    u.a3 = tail[kSamples + kSampleMoments + 0];
+    u.a4 = tail[kSamples + kSampleMoments + 1];
+    u.a5 = tail[kSamples + kSampleMoments + 2];
+    return jerk_quirk_sum(u, s0, tail[kSamples], tail[kSamples + 1]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // edge costs
@@ -41,8 +69,8 @@ constexpr int kTableFields = kSamples + 7;  // l samples, a3, a4, a5, base smoot
 // (dl0 = ddl0 = 0, T = sample_s: the lateral samples, sum l^2, sum dl^2, sum ddl^2, a3..a5 are functions of the
 // row pair (k, i) only; the quirked jerk term and the obstacles are what see the absolute s).  It depends only
 // on the lattice parameters, so it is built once per parameter set by this one-block kernel and kept in device
-// memory: [kTableFields][row*row] doubles (pair index = k*row + i) followed by the kSamples sample offsets t_n and
-// their two moments sum t_n, sum t_n^2 (emp_core.h sample_moments).
+// memory: [kTableFields][row*row] doubles (pair index = k*row + i) followed by the kSamples sample offsets t_n,
+// their two moments sum t_n, sum t_n^2 (emp_core.h sample_moments) and the unit quintic's a3, a4, a5 (kTableTail doubles).
 __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __restrict__ tab) {
     const int row = P.row, rr = P.row * P.row;
     for (int p = threadIdx.x; p < rr; p += blockDim.x) {
@@ -61,16 +89,21 @@ __global__ __launch_bounds__(256) void dp_pair_table_kernel(DpDev P, double* __r
             S_dl = S_dl + dl * dl;
             S_ddl = S_ddl + ddl * ddl;
         }
-        tab[(kSamples + 0) * rr + p] = q.a3;
-        tab[(kSamples + 1) * rr + p] = q.a4;
-        tab[(kSamples + 2) * rr + p] = q.a5;
-        tab[(kSamples + 3) * rr + p] = P.w0 * S_dl + P.w1 * S_ddl;
-        tab[(kSamples + 4) * rr + p] = P.w_ref * S_l;
-        tab[(kSamples + 5) * rr + p] = fmin(l_pre, l_cur);
-        tab[(kSamples + 6) * rr + p] = fmax(l_pre, l_cur);
+        const double h = l_cur - l_pre;                     // as quintic_shifted
+        tab[kF_JERK * rr + p] = P.w2 * (h * h);
+        tab[kF_BASE * rr + p] = P.w0 * S_dl + P.w1 * S_ddl;
+        tab[kF_REF * rr + p] = P.w_ref * S_l;
+        tab[kF_LLO * rr + p] = fmin(l_pre, l_cur);
+        tab[kF_LHI * rr + p] = fmax(l_pre, l_cur);
     }
     if (threadIdx.x < kSamples) tab[kTableFields * rr + threadIdx.x] = sample_t(threadIdx.x, P.sample_s);
-    if (threadIdx.x == 0) sample_moments(P.sample_s, &tab[kTableFields * rr + kSamples], &tab[kTableFields * rr + kSamples + 1]);
+    if (threadIdx.x == 0) {
+        sample_moments(P.sample_s, &tab[kTableFields * rr + kSamples], &tab[kTableFields * rr + kSamples + 1]);
+        const Quintic u = quintic_shifted(0.0, 0.0, 0.0, 1.0, P.sample_s);
+        tab[kTableFields * rr + kSamples + kSampleMoments + 0] = u.a3;
+        tab[kTableFields * rr + kSamples + kSampleMoments + 1] = u.a4;
+        tab[kTableFields * rr + kSamples + kSampleMoments + 2] = u.a5;
+    }
 }
 
 // kSoftGain / d2 for 16 < d2 < 36, equal to the IEEE binary64 quotient except with probability ~2^-43 per operand (NOT a
@@ -170,7 +203,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
     const int nmask = min(nob, kMaskBits);
     const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
     const double s9 = s0 + t_smp[kSamples - 1];
-    const double T1 = t_smp[kSamples], T2 = t_smp[kSamples + 1];    // sum t_n, sum t_n^2 (sample_moments)
+    const double F = jerk_unit_sum(t_smp, s0);                      // the column's jerk factor (see jerk_unit_sum)
     // longitudinal half of obstacle_in_reach (emp_core.h): same bounds, evaluated once per column
     MASK near_s = 0;
     for (int m = 0; m < nmask; ++m) {
@@ -187,13 +220,8 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
     }
     for (int k = 0; k < row; ++k) {
         const int p = k * row + i;
-        Quintic q;
-        q.a3 = tab[(kSamples + 0) * rr + p];
-        q.a4 = tab[(kSamples + 1) * rr + p];
-        q.a5 = tab[(kSamples + 2) * rr + p];
-        const double S_d3 = jerk_quirk_sum(q, s0, T1, T2);
-        const double smooth = tab[(kSamples + 3) * rr + p] + P.w2 * S_d3;
-        const double l_lo = tab[(kSamples + 5) * rr + p], l_hi = tab[(kSamples + 6) * rr + p];
+        const double smooth = tab[kF_BASE * rr + p] + tab[kF_JERK * rr + p] * F;
+        const double l_lo = tab[kF_LLO * rr + p], l_hi = tab[kF_LHI * rr + p];
         double coll = 0.0;
         for (MASK rest = near_s; rest; rest &= rest - 1) {                 // ascending m, as the reference
             const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
@@ -213,7 +241,7 @@ __device__ __forceinline__ void dp_edge_column(const DpDev& P, int j, int i, dou
             if (!obstacle_in_reach(os, ol, s0, s9, l_lo, l_hi)) continue;
             coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, os, ol, P.w_coll);
         }
-        store(k, (smooth + coll) + tab[(kSamples + 4) * rr + p]);
+        store(k, (smooth + coll) + tab[kF_REF * rr + p]);
     }
     if (box_dx2) __builtin_amdgcn_wave_barrier();      // the next column's fill comes after every read of this one
 }
@@ -243,15 +271,15 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
     double* t_obs_l = t_obs_s + P.S * P.max_obs;
-    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kSamples + 2] sample offsets t_n, then sum t_n and sum t_n^2
+    double* t_smp = t_obs_l + P.S * P.max_obs;          // [kTableTail] sample offsets t_n, sum t_n, sum t_n^2, unit quintic
     // per wavefront: [S][mask width] longitudinal box terms of the column it works on (dp_edge_column: box_dx2)
     const int box_w = min(P.max_obs, (int)sizeof(MASK) * 8);
-    double* box_all = t_smp + kSamples + kSampleMoments;
+    double* box_all = t_smp + kTableTail;
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
 
     for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
-    if (tid < kSamples + kSampleMoments) t_smp[tid] = pair_tab[kTableFields * rr + tid];
+    if (tid < kTableTail) t_smp[tid] = pair_tab[kTableFields * rr + tid];
     for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
         const int s = x / P.max_obs, m = x - s * P.max_obs;
         const int b = tile * P.S + s;
@@ -302,6 +330,207 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
             }
         }, my_box);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge costs, work-ring form (round 5; the default for the tiled lattices)
+// ---------------------------------------------------------------------------------------------
+// The lockstep kernel above walks, per (column, source row k), the obstacles within reach of the column with all lanes of
+// the wavefront executing the SAME scan: a lane idles while its own box test failed (destination rows out of the
+// obstacle's lateral reach) or while its scene has fewer obstacles near this column than a neighbour scene of the tile -
+// 0.49 active lanes per scan on the benchmark batch (profiles/r04a_sq.csv), on the kernel that is 40 % of the GPU time.
+//
+// Here the dense part stays in lockstep (base cost, box tests: lane = (scene, destination row i), as above), but an edge
+// with at least one obstacle in reach is not scanned in place: it is PUSHED as one entry {column j, source row k, owner
+// lane, obstacle mask} into a per-wavefront LDS ring, and whenever a ring holds 64 entries the wavefront
+// pops them, ONE ENTRY PER LANE, and every lane scans its own entry's obstacles in ascending order (the reference's
+// order, path_planning.py:573-582) - the same operations on the same operands as dp_edge_column, so the tensor is
+// bit-identical; only which lane computes an edge changes.  Two rings: edges with ONE obstacle in reach (a straight-line
+// scan, every lane busy) and edges with several (a loop over the mask; lanes idle only while their entry has fewer
+// obstacles than the round's maximum).  Priced on the CPU before it was built (tools/edge_ring_sim.py): 0.93 active lanes
+// of a scan instead of 0.49 at 40 x 9 with 8 obstacles, 0.84 instead of 0.54 at 120 x 21 with 16.
+// Edges without an obstacle in reach are stored from the dense part (coalesced, the other lanes masked); ring entries are
+// stored by the lane that scanned them, 8 bytes each - the entries of a round are neighbours in (j, k, lane) order, so the
+// stores of a round still fall into two or three 512-byte rows of the tiled tensor.
+// Capacity: a ring never holds more than 63 left-over + 64 pushed entries = 127 < kRingSlots.
+constexpr int kRingSlots = 128;
+
+template <typename MASK>
+struct EdgeRing {                        // per wavefront, in LDS
+    unsigned code[2][kRingSlots];        // (j << 16) | (k << 8) | owner lane
+    MASK mask[2][kRingSlots];            // obstacles of the owner's scene that passed the box test (ascending bit = ascending m)
+};                                       // (the edge's smoothness term is recomputed by the lane that pops the entry: 8 bytes
+                                         // per entry less - at 120 x 21 the 60 KB pair table leaves a wavefront 2.4 KB of LDS)
+
+#ifndef EMP_EDGE_RING_ATTR
+#define EMP_EDGE_RING_ATTR
+#endif
+template <bool TILED, int ROW = 0, typename MASK = unsigned>
+__global__ __launch_bounds__(1024, EMP_EDGE_WAVES) EMP_EDGE_RING_ATTR void dp_edge_ring_kernel(DpDev P, const double* __restrict__ pair_tab,
+                                                           const double* __restrict__ obs_s,
+                                                           const double* __restrict__ obs_l,
+                                                           const int* __restrict__ n_obs,
+                                                           const double* __restrict__ start,
+                                                           double* __restrict__ start_cost,
+                                                           double* __restrict__ edge, int cols_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __builtin_amdgcn_s_setprio(EMP_PRIO_FRONT);
+    constexpr int kMaskBits = (int)sizeof(MASK) * 8;
+    const int row = ROW > 0 ? ROW : P.row, rr = row * row;
+    double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
+    double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
+    double* t_obs_l = t_obs_s + P.S * P.max_obs;
+    double* t_ps = t_obs_l + P.S * P.max_obs;           // [S] plan_start_s of the tile's scenes (S <= 64)
+    double* box_all = t_ps + 64;                        // per wavefront: [2][S][max_obs] lateral reach band of each obstacle in its column
+    const int waves = (int)(blockDim.x >> 6);
+    EdgeRing<MASK>* rings = reinterpret_cast<EdgeRing<MASK>*>(box_all + (size_t)waves * 2 * P.S * P.max_obs);
+    const double* t_smp = pair_tab + kTableFields * rr; // sample offsets through the kernel argument: scalar registers
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
+    for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
+        const int sc = x / P.max_obs, m = x - sc * P.max_obs;
+        const int bb = tile * P.S + sc;
+        t_obs_s[x] = (bb < P.B) ? obs_s[(size_t)bb * P.max_obs + m] : 0.0;
+        t_obs_l[x] = (bb < P.B) ? obs_l[(size_t)bb * P.max_obs + m] : 0.0;
+    }
+    if (tid < P.S) t_ps[tid] = (tile * P.S + tid < P.B) ? start[(size_t)(tile * P.S + tid) * 4 + 0] : 0.0;
+    __syncthreads();
+
+    const int lanes_used = P.S * row;
+    // ---- start edges (column 0): generic form, one thread per (scene, row); only chunk 0 does them
+    if (blockIdx.y == 0 && start_cost != nullptr && tid < lanes_used) {
+        const int sc = tid / row, ii = tid - sc * row;
+        const int bb = tile * P.S + sc;
+        if (bb < P.B) {
+            const double ps0 = start[bb * 4 + 0], pl = start[bb * 4 + 1], pdl = start[bb * 4 + 2], pddl = start[bb * 4 + 3];
+            const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, ii, P.sample_l), P.sample_s);
+            start_cost[(size_t)bb * row + ii] =
+                segment_cost(q, ps0, P.sample_s, t_obs_s + sc * P.max_obs, t_obs_l + sc * P.max_obs, min(max(n_obs[bb], 0), P.max_obs),
+                             P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+        }
+    }
+
+    const int j_begin = 1 + blockIdx.y * cols_per_chunk;
+    const int j_end = min(P.col, j_begin + cols_per_chunk);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane / row, i = lane - s * row;
+    const int b = tile * P.S + s;
+    const bool live = (lane < lanes_used) && (b < P.B);      // dead lanes take no part in the dense pass, but pop entries
+    const int sl = live ? s : 0;
+    const double ps = t_ps[sl];
+    const int nob = live ? min(min(max(n_obs[b], 0), P.max_obs), kMaskBits) : 0;
+    const double* my_obs_s = t_obs_s + sl * P.max_obs;
+    const double* my_obs_l = t_obs_l + sl * P.max_obs;
+    double* my_lo = box_all + ((size_t)(2 * wave) * P.S + sl) * P.max_obs;
+    double* my_hi = my_lo + (size_t)P.S * P.max_obs;
+    EdgeRing<MASK>& R = rings[wave];
+    int head[2] = {0, 0}, cnt[2] = {0, 0};                   // wave-uniform ring state
+
+    auto store_edge = [&](int j, int k, int owner, double cost) {
+        if (TILED) {
+            edge[(((size_t)tile * (P.col - 1) + (j - 1)) * row + k) * 64 + owner] = cost;
+        } else {
+            const int so = owner / row, io = owner - so * row;
+            edge[(size_t)(tile * P.S + so) * (P.col - 1) * rr + (size_t)(j - 1) * rr + io * row + k] = cost;
+        }
+    };
+    // pop min(cnt, 64) entries of ring c, one per lane, scan, store
+    auto round = [&](int c) {
+        const int n = min(cnt[c], 64);
+        if (lane < n) {
+            const int slot = (head[c] + lane) & (kRingSlots - 1);
+            const unsigned code = R.code[c][slot];
+            MASK rest = R.mask[c][slot];
+            const int owner = (int)(code & 63u), k = (int)((code >> 8) & 255u), j = (int)(code >> 16);
+            const int so = owner / row, io = owner - so * row;
+            const int p = k * row + io;
+            const double s0 = t_ps[so] + (double)j * P.sample_s;            // ref :330 pre_node_s
+            const double smooth = tab[kF_BASE * rr + p] + tab[kF_JERK * rr + p] * jerk_unit_sum(t_smp, s0);   // as the dense pass
+            const double* o_s = t_obs_s + so * P.max_obs;
+            const double* o_l = t_obs_l + so * P.max_obs;
+            double coll = 0.0;
+            if (c == 0) {                                                     // exactly one obstacle in reach
+                const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
+                coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, o_s[m], o_l[m], P.w_coll);
+            } else {
+                for (; rest; rest &= rest - 1) {                              // ascending m, as the reference
+                    const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
+                    coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, o_s[m], o_l[m], P.w_coll);
+                }
+            }
+            store_edge(j, k, owner, (smooth + coll) + tab[kF_REF * rr + p]);
+        }
+        head[c] = (head[c] + n) & (kRingSlots - 1);
+        cnt[c] -= n;
+        __builtin_amdgcn_wave_barrier();                   // the slots are free for the next pushes
+    };
+
+    for (int j = j_begin + wave; j < j_end; j += waves) {
+        const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
+        const double s9 = s0 + t_smp[kSamples - 1];
+        // longitudinal half of the reach test, once per (scene, column): as dp_edge_column
+        MASK near_s = 0;
+        for (int m = 0; m < nob; ++m) {
+            const double os = my_obs_s[m];
+            if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= (MASK)1 << m;
+        }
+        // The box test (obstacle_box_in_reach: dx^2 + dy^2 < 36.5 with dy = max(l_lo - ol, ol - l_hi, 0)) solved for the lateral
+        // band once per (scene, column, obstacle): with r = sqrt(36.5 - dx^2) an edge's box [l_lo, l_hi] is in reach iff
+        // l_hi > ol - r and l_lo < ol + r - two compares per (edge, obstacle) instead of seven operations.  Like the box test
+        // itself this only PRUNES pairs that contribute exactly 0 (every sample 6.04 m or more away, against the 6 m where a
+        // cost begins): the half metre of margin dwarfs the rounding of the square root, and a pair pruned by one form and not
+        // the other contributes 0 either way, so the tensor does not depend on which form a kernel uses.
+        if (live) {
+            for (int m = i; m < nob; m += row) {
+                const double os = my_obs_s[m], ol = my_obs_l[m];
+                const double dx = fmax(fmax(s0 - os, os - s9), 0.0);
+                const double thr = 36.5 - dx * dx;
+                const double r = sqrt(fmax(thr, 0.0));
+                my_lo[m] = thr > 0.0 ? ol - r : __builtin_inf();
+                my_hi[m] = thr > 0.0 ? ol + r : -__builtin_inf();
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double F = jerk_unit_sum(t_smp, s0);                      // the column's jerk factor
+        for (int k = 0; k < row; ++k) {
+            const int p = k * row + i;
+            MASK pass = 0;
+            double smooth = 0.0;
+            if (live) {
+                smooth = tab[kF_BASE * rr + p] + tab[kF_JERK * rr + p] * F;
+                const double l_lo = tab[kF_LLO * rr + p], l_hi = tab[kF_LHI * rr + p];
+                for (MASK rest = near_s; rest; rest &= rest - 1) {
+                    const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
+                    if (l_hi > my_lo[m] && l_lo < my_hi[m]) pass |= (MASK)1 << m;
+                }
+                if (pass == 0) store_edge(j, k, lane, (smooth + 0.0) + tab[kF_REF * rr + p]);
+            }
+            const bool one = pass != 0 && (pass & (pass - 1)) == 0;
+            const bool many = pass != 0 && !one;
+            const unsigned long long b1 = __ballot(one), b2 = __ballot(many);
+            if (b1 | b2) {
+                const unsigned long long mine = one ? b1 : b2;
+                const int c = one ? 0 : 1;
+                const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
+                if (pass != 0) {
+                    const int slot = ((one ? head[0] + cnt[0] : head[1] + cnt[1]) + before) & (kRingSlots - 1);
+                    R.code[c][slot] = ((unsigned)j << 16) | ((unsigned)k << 8) | (unsigned)lane;
+                    R.mask[c][slot] = pass;
+                }
+                cnt[0] += __popcll(b1);
+                cnt[1] += __popcll(b2);
+                __builtin_amdgcn_wave_barrier();
+                if (cnt[0] >= 64) round(0);
+                if (cnt[1] >= 64) round(1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                   // the next column's box terms come after every read of this one
+    }
+    while (cnt[0] > 0) round(0);
+    while (cnt[1] > 0) round(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,7 +879,7 @@ struct FusedLds {
 __host__ __device__ inline FusedLds fused_lds(int row, int col, int S, int max_obs, int nc) {
     FusedLds L;
     int o = kTableFields * row * row * 8;
-    L.off_smp = o;   o += (kSamples + kSampleMoments) * 8;
+    L.off_smp = o;   o += kTableTail * 8;
     L.off_obs_s = o; o += S * max_obs * 8;
     L.off_obs_l = o; o += S * max_obs * 8;
     L.off_buf = o;   o += 2 * nc * row * 64 * 8;
@@ -686,7 +915,7 @@ __global__ __launch_bounds__(256, 4) void dp_fused_kernel(DpDev P, const double*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int x = tid; x < kTableFields * rr; x += blockDim.x) tab[x] = pair_tab[x];
-    if (tid < kSamples + kSampleMoments) t_smp[tid] = pair_tab[kTableFields * rr + tid];
+    if (tid < kTableTail) t_smp[tid] = pair_tab[kTableFields * rr + tid];
     for (int x = tid; x < P.S * P.max_obs; x += blockDim.x) {
         const int sc = x / P.max_obs, m = x - sc * P.max_obs;
         const int bb = tile * P.S + sc;

@@ -731,6 +731,9 @@ __global__ __launch_bounds__(64) void cycle_qp_wave_kernel(EMP_CYCLE_QP_PARAMS) 
 }
 // 64 / GP scenes per wavefront on groups of GP lanes, R stations per lane (emp_qp_rows.h): a quarter (GP = 8) of the
 // wavefronts of the two-per-wavefront kernel, each as long as before.
+// (Round 5, measured and not kept: amdgpu_waves_per_eu(2, 2) - 256 registers and 224 bytes of scratch per lane instead of 256 + 74
+// accumulation registers as spill space - so that two edge-cost wavefronts fit beside a path-QP wavefront on its SIMD instead of
+// one: the kernel alone 137 -> 157 us, the staged step 0.241 -> 0.250 ms.)
 template <int GP, int R>
 __global__ __launch_bounds__(64) void cycle_qp_rows_kernel(EMP_CYCLE_QP_PARAMS) {
     cycle_qp_body<GP, R>(EMP_CYCLE_QP_ARGS);

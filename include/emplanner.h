@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 9
+#define EMP_ABI_VERSION 10
 
 typedef struct emp_ctx emp_ctx;
 
@@ -163,7 +163,7 @@ int emp_pipeline_depth(emp_ctx* ctx);
  * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
 int emp_set_fence(emp_ctx* ctx, int enabled);
 
-/* ---- options (ABI version 9) ---------------------------------------------------------------------------------------
+/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE: version 10) ---------------------------------------------------------------------------------------
  * The library reads NO environment variable.  Everything that used to be an EMP_* environment switch of the development
  * builds is a per-context option here, set by the host program before the calls it should affect (a change takes effect
  * at the next call; EMP_OPT_BACK_STREAM_CUS at the next emp_set_pipeline).  Unknown options and values out of range are
@@ -184,6 +184,12 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             projected-gradient fallback (tests/test_gpu_fullsize.py)
  *   EMP_OPT_EDGE_BLOCK              0        tuning           threads per block of the edge-cost kernel (multiple of 64 up
  *                                                             to 1024); 0: from the lattice's LDS footprint
+ *   EMP_OPT_EDGE_FORM               0        A/B (bit-ident.) edge-cost kernel of the tiled lattices (<= 32 rows): 0 = work-ring
+ *                                                             form (edges with obstacles in reach are queued per wavefront and
+ *                                                             scanned one edge per lane: 0.93 active lanes of a scan at 40 x 9
+ *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
+ *                                                             obstacle rows wider than 64 slots always take the lockstep form
+ *   EMP_OPT_EDGE_COLS_PER_WAVE      0        tuning           lattice columns a wavefront of the edge-cost kernel takes; 0: auto
  *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto; 1/2/3: register ring 3/4/8 columns deep;
  *                                                             4/5: nontemporal / plain loads whatever the tensor's size
  *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
@@ -228,7 +234,9 @@ typedef enum emp_option {
     EMP_OPT_ENRICH_ON_FRONT = 10,
     EMP_OPT_EDGE_AFTER_ENRICH = 11,
     EMP_OPT_SWEEP_MARKER = 12,
-    EMP_OPT_COUNT = 13
+    EMP_OPT_EDGE_FORM = 13,
+    EMP_OPT_EDGE_COLS_PER_WAVE = 14,
+    EMP_OPT_COUNT = 15
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);

@@ -28,6 +28,12 @@ Operation order (one lattice edge from (s0, l0, dl0, ddl0) to (s0 + T, l1, 0, 0)
     (until round 2 the kernels summed dddl_i^2 sample by sample as the reference does; the closed form is the same
      mathematics, differs in the last bits, and is a quarter of the edge kernel's instructions cheaper)
     other sums over i ascending; cost = ((w0 S_dl + w1 S_ddl) + w2 S_dddl + collision) + w_ref S_l
+    NEIGHBOUR edges (dl0 = ddl0 = 0; round 5): their coefficients are h times the unit quintic's (u3, u4, u5) =
+    quintic_shifted(0, 0, 0, 1, T), and the quirk term is linear in them, so S_dddl = (h h) F(s0) with
+        F(s0) = S_dddl of the unit quintic at s0 (the closed form above, operation for operation),
+    evaluated once per (scene, column); the edge's smoothness term is (w0 S_dl + w1 S_ddl) + (w2 (h h)) F(s0).
+    Same mathematics as the closed form on the edge's own coefficients (rounds 2-4), different in the last bits, and 26 of
+    the ~100 vector instructions an edge costs the kernel outside its obstacle scans.  Start edges keep the general form.
     collision = sum over obstacles in order of the ordered, early-breaking scan (:588-609)
 """
 from __future__ import annotations
@@ -49,8 +55,9 @@ def quintic_shifted(l0, dl0, ddl0, l1, T):
     return l0, dl0, 0.5 * ddl0, a3, a4, a5
 
 
-def _segment_cost(a, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w_smooth, w_ref):
-    """Edge cost for arrays of edges.
+def _segment_cost(a, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w_smooth, w_ref, weighted_jerk=None):
+    """Edge cost for arrays of edges.  ``weighted_jerk``: the term w2 S_dddl computed by the caller (neighbour edges:
+    (w2 (h h)) F(s0), see the module docstring) instead of the general closed form.
 
     a        : tuple of 6 arrays, each shape E (any shape), shifted coefficients
     s0       : start s per edge (same shape)
@@ -106,7 +113,7 @@ def _segment_cost(a, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w_smooth, w_ref)
     coll = np.zeros(shape)
     for m in range(max_obs):                                   # obstacles in order
         coll = coll + np.where(valid[..., m], coll_each[..., m], 0.0)
-    smooth = (w_smooth[0] * S_dl + w_smooth[1] * S_ddl) + w_smooth[2] * S_d3
+    smooth = (w_smooth[0] * S_dl + w_smooth[1] * S_ddl) + (w_smooth[2] * S_d3 if weighted_jerk is None else weighted_jerk)
     return (smooth + coll) + w_ref * S_l
 
 
@@ -175,9 +182,18 @@ def edge_costs(obs_s, obs_l, n_obs, start, row, col, sample_s, sample_l,
     s0 = ps[:, None] + j[None, :] * sample_s                               # pre_node_s (:330)
     a = quintic_shifted(ll[None, None, None, :], 0.0, 0.0, ll[None, None, :, None], T)
     a = tuple(np.broadcast_to(x, (1, 1, row, row)) for x in a)
+    h = ll[:, None] - ll[None, :]                                          # l_cur - l_pre, [i][k] (as quintic_shifted)
     e = _segment_cost(a, s0[:, :, None, None], sample_s, obs_s[:, None, None, None, :],
-                      obs_l[:, None, None, None, :], n_obs[:, None, None, None], w_coll, w_smooth, w_ref)
+                      obs_l[:, None, None, None, :], n_obs[:, None, None, None], w_coll, w_smooth, w_ref,
+                      weighted_jerk=(w_smooth[2] * (h * h))[None, None] * neighbour_jerk_factor(s0, sample_s)[:, :, None, None])
     return c0, e
+
+
+def neighbour_jerk_factor(s0, sample_s):
+    """F(s0): the quirked third-derivative sum of the UNIT neighbour quintic (h = 1) that starts at s0 - what
+    csrc/emp_dp_kernels.h jerk_unit_sum evaluates once per (scene, column)."""
+    _, _, _, u3, u4, u5 = quintic_shifted(0.0, 0.0, 0.0, 1.0, float(sample_s))
+    return jerk_quirk_sum_closed_form(u3, u4, u5, s0, sample_s)
 
 
 def dp_sweep(c0, edge, row):

@@ -19,6 +19,8 @@ def load():
     d, i, p = C.c_double, C.c_int, C.c_void_p
     lib.hc_segment_cost.restype = d
     lib.hc_segment_cost.argtypes = [d, d, d, d, d, d, p, p, i, d, d, d, d, d]
+    lib.hc_neighbour_cost.restype = d
+    lib.hc_neighbour_cost.argtypes = [d, d, d, d, p, p, i, d, d, d, d, d]
     lib.hc_path_qp.restype = i
     lib.hc_path_qp.argtypes = [i, p, p, d, d, d, p, p, p, p, p]
     lib.hc_path_qp_gi.restype = i

@@ -18,6 +18,11 @@ double hc_segment_cost(double l0, double dl0, double ddl0, double l1, double s0,
     return segment_cost(q, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w0, w1, w2, w_ref);
 }
 
+double hc_neighbour_cost(double l0, double l1, double s0, double sample_s, const double* obs_s, const double* obs_l, int n_obs,
+                         double w_coll, double w0, double w1, double w2, double w_ref) {
+    return neighbour_cost(l0, l1, s0, sample_s, obs_s, obs_l, n_obs, w_coll, w0, w1, w2, w_ref);
+}
+
 int hc_path_qp(int n, const double* l_min, const double* l_max, double l0, double dl0, double ddl0, const double* prm8,
                double* out_l, double* out_dl, double* out_ddl, int* iters) {
     static double mem[path_qp_words(256)];

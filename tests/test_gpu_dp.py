@@ -248,3 +248,46 @@ def test_soft_cost_quotient_is_ieee_division_on_its_whole_range(tmp_path):
     assert build.returncode == 0, build.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "differing from IEEE division: 0" in run.stdout, run.stdout + run.stderr
+
+
+@pytest.mark.parametrize("shape", [(9, 40, 2.5, 1.5, 8, 8, 45), (21, 30, 1.0, 0.6, 16, 16, 11), (12, 6, 15.0, 1.5, 3, 3, 17),
+                                   (5, 20, 5.0, 1.0, 0, 1, 25), (7, 11, 4.5, 1.0, 6, 40, 19), (9, 12, 2.5, 1.5, 40, 40, 15),
+                                   (9, 9, 2.5, 1.5, 70, 70, 9), (3, 5, 7.5, 1.5, 2, 2, 43), (32, 4, 5.0, 0.4, 5, 5, 5)],
+                         ids=lambda s: f"{s[1]}x{s[0]}_{s[4]}of{s[5]}obs")
+def test_edge_ring_form_is_bit_identical_to_the_lockstep_form(planner, shape):
+    """EMP_OPT_EDGE_FORM: the work-ring edge kernel (default; emp_dp_kernels.h dp_edge_ring_kernel) against the lockstep kernel
+    of rounds 1-4, both layouts: compiled and generic row counts, ragged last tiles, 32- and 64-bit obstacle masks, obstacle rows
+    wider than a mask (the ring form then hands over to the lockstep kernel), no obstacles at all, one tile's worth of scenes and
+    fewer.  Obstacles are packed densely (several per metre) so that the multi-obstacle ring fills as well."""
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd.api import dp_params
+    row, col, ss, sl, n_obs, max_obs, B = shape
+    rng = np.random.default_rng(row * 1000 + col)
+    p = dp_params(row=row, col=col, sample_s=ss, sample_l=sl)
+    horizon = col * ss
+    obs_s = rng.uniform(-5.0, horizon + 5.0, (B, max_obs))
+    obs_l = rng.uniform(-row * sl * 0.7, row * sl * 0.7, (B, max_obs))
+    nob = rng.integers(0, n_obs + 1, B).astype(np.int32)
+    nob[0] = n_obs
+    start = np.column_stack([rng.uniform(0.0, 5.0, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-0.05, 0.05, B),
+                             rng.uniform(-0.01, 0.01, B)])
+    out = {}
+    for form in (0, 1):
+        planner.set_option("edge_form", form)
+        try:
+            out[form] = [planner.dp_edge_costs(p, obs_s, obs_l, nob, start, layout=lay)
+                         for lay in (L.EMP_EDGE_CANONICAL, L.EMP_EDGE_TILED)]
+        finally:
+            planner.set_option("edge_form", 0)
+    for lay in (0, 1):
+        assert np.array_equal(out[0][lay][0], out[1][lay][0]), "start edges"
+        a, b = out[0][lay][1], out[1][lay][1]
+        if lay == 1:          # tiled: lanes beyond S * row and scenes beyond B are padding (unspecified)
+            S_ = 64 // row
+            t = a.reshape(-1, 64)[:, :S_ * row].reshape(-1, (col - 1) * row, S_, row)
+            u = b.reshape(-1, 64)[:, :S_ * row].reshape(-1, (col - 1) * row, S_, row)
+            live = (np.arange(t.shape[0])[:, None] * S_ + np.arange(S_)[None, :]) < B
+            a, b = t.transpose(0, 2, 1, 3)[live], u.transpose(0, 2, 1, 3)[live]
+        assert np.array_equal(a, b), f"layout {lay}: {(a != b).sum()} of {a.size} edges differ between the two kernels"
+    rc0, re = ex.edge_costs(obs_s, obs_l, nob, start, row, col, ss, sl)
+    assert np.array_equal(out[0][0][1], re), "ring form against the exact oracle"

@@ -179,9 +179,14 @@ def test_segment_cost_bit_exact_with_exact_oracle(hc):
         for (j, i, kk) in ((1, 0, 0), (3, 11, 2), (5, 4, 9)):
             l0 = ((cfg.row + 1) / 2 - 1 - kk) * cfg.sample_l
             l1 = ((cfg.row + 1) / 2 - 1 - i) * cfg.sample_l
-            v = hc.hc_segment_cost(l0, 0.0, 0.0, l1, ps + j * cfg.sample_s, cfg.sample_s, obs_s.ctypes.data,
-                                   obs_l.ctypes.data, k, 1e12, 300.0, 1000.0, 5000.0, 20.0)
+            # neighbour edges: the factorised jerk term (emp_core.h neighbour_cost = what the edge kernels tabulate)
+            v = hc.hc_neighbour_cost(l0, l1, ps + j * cfg.sample_s, cfg.sample_s, obs_s.ctypes.data,
+                                     obs_l.ctypes.data, k, 1e12, 300.0, 1000.0, 5000.0, 20.0)
             assert v == e[0, j - 1, i, kk]
+            # ... which is the general form (start edges) to a few units in the last place
+            w = hc.hc_segment_cost(l0, 0.0, 0.0, l1, ps + j * cfg.sample_s, cfg.sample_s, obs_s.ctypes.data,
+                                   obs_l.ctypes.data, k, 1e12, 300.0, 1000.0, 5000.0, 20.0)
+            assert abs(v - w) <= 1e-13 * abs(w)
 
 
 # ---- S-T speed DP scalar pieces (csrc/emp_st_core.h; reference planner/speed_planning_test.py) ---------------

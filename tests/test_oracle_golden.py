@@ -605,3 +605,27 @@ def test_closed_form_jerk_sum_agrees_with_the_reference_order_sample_loop():
         worst = max(worst, float((np.abs(loop - closed)[nz] / loop[nz]).max()))
         assert np.array_equal(loop == 0, closed == 0)
     assert worst < 1e-14, worst
+
+
+def test_factorised_neighbour_jerk_agrees_with_the_reference_order_sample_loop():
+    """Round 5: for a neighbour edge (dl0 = ddl0 = 0) the kernels and oracle/exact.py evaluate the quirked jerk sum as
+    (h h) F(s0), F = the unit quintic's sum at s0 once per (scene, column) - the same number rounded differently again.
+    Held against the per-sample accumulation in the reference's own order (path_planning.py:565-572) and against the
+    per-edge closed form of rounds 2-4, on the lattices' own row offsets: within 1e-14 of the sum (measured: 3e-15)."""
+    rng = np.random.default_rng(2)
+    worst = worst_closed = 0.0
+    for sample_s, sample_l in ((2.5, 1.5), (15.0, 1.5), (1.0, 0.6), (10.0, 1.0), (14.7, 1.5)):
+        n = 100000
+        l0 = rng.integers(-10, 11, n) * sample_l
+        l1 = rng.integers(-10, 11, n) * sample_l
+        _, _, _, a3, a4, a5 = ex.quintic_shifted(l0, 0.0, 0.0, l1, sample_s)
+        s0 = rng.uniform(0.0, 125.0, n)
+        loop = ex.jerk_quirk_sum_sample_loop(a3, a4, a5, s0, sample_s)
+        closed = ex.jerk_quirk_sum_closed_form(a3, a4, a5, s0, sample_s)
+        h = l1 - l0
+        fact = (h * h) * ex.neighbour_jerk_factor(s0, sample_s)
+        nz = loop > 0
+        assert np.array_equal(loop == 0, fact == 0)
+        worst = max(worst, float((np.abs(loop - fact)[nz] / loop[nz]).max()))
+        worst_closed = max(worst_closed, float((np.abs(closed - fact)[nz] / closed[nz]).max()))
+    assert worst < 1e-14 and worst_closed < 1e-14, (worst, worst_closed)
