@@ -34,7 +34,7 @@ def hw_queues() -> int:
         return 4
 
 
-EMP_HOST, EMP_DEVICE = 0, 1
+EMP_HOST, EMP_DEVICE, EMP_HOST_PINNED = 0, 1, 2
 EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1
 EMP_DP_FUSED, EMP_DP_TWO_KERNEL = 0, 1
 EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
@@ -115,6 +115,10 @@ PROTOTYPES = {
     "emp_last_error": (C.c_char_p, [_vp]),
     "emp_synchronize": (C.c_int, [_vp]),
     "emp_stream": (_vp, [_vp]),
+    "emp_host_alloc": (C.c_int, [_vp, _u64, C.POINTER(_vp)]),
+    "emp_host_free": (C.c_int, [_vp, _vp]),
+    "emp_wait_cycle": (C.c_int, [_vp, _i32]),
+    "emp_cycle_ticket": (_u64, [_vp]),
     "emp_device_alloc": (C.c_int, [_vp, _u64, C.POINTER(_vp)]),
     "emp_device_free": (C.c_int, [_vp, _vp]),
     "emp_copy_to_device": (C.c_int, [_vp, _vp, _vp, _u64]),

@@ -218,6 +218,109 @@ class _Args:
         return a, C.c_void_p(a.ctypes.data)
 
 
+class HostRing:
+    """The overlapped host path of the planning cycle (reference: one planning request per Pipe message, test_9.py:92-96,
+    220, 390-395 - here a batch of them per call).  ``depth`` slots, each a set of page-locked NumPy arrays for the inputs
+    and outputs of ``B`` scenes.  Per call: take the next slot (``next()`` waits, on the host, until the call that used it
+    ``depth`` calls ago has delivered), fill its ``inputs`` in place or ``load(**arrays)`` them, ``plan_cycle(..., slot=slot)``;
+    the call returns while the inputs are still crossing PCIe on the copy stream, the previous call computes, and the call
+    before that is sending its outputs home.  ``slot.wait()`` - or taking the slot again - makes ``slot.outputs`` valid."""
+
+    class Slot:
+        def __init__(self, ring, index):
+            self.ring, self.index = ring, index
+            pl, B, P, mo, M, col = ring.planner, ring.B, ring.max_ref, ring.max_obs, ring.max_pts, ring.col
+            self.B, self.max_ref, self.max_obs, self.max_pts = B, P, mo, M
+            self.use_dyn = False
+            self._ticket = None
+            f, i = np.float64, np.int32
+            # ONE page-locked block for the inputs and one for the outputs (arrays at 256-byte offsets): the library then moves
+            # each as a single PCIe copy (emp_context.h Stage::place)
+            self.inputs, self._in_block = self._carve(pl, (
+                ("ref_line", (B, P, 4), f), ("n_ref", (B,), i), ("origin_xy", (B, 2), f), ("start_xy", (B, 2), f),
+                ("start_v", (B, 2), f), ("start_a", (B, 2), f), ("obs_xy", (B, max(mo, 1), 2), f), ("n_obs", (B,), i),
+                ("dyn_dis_speed", (B, 2), f)))
+            self.outputs, self._out_block = self._carve(pl, (
+                ("dp_rows", (B, col), f), ("dp_s", (B, M), f), ("dp_l", (B, M), f), ("dp_len", (B,), i), ("path_s", (B, M), f),
+                ("path_l", (B, M), f), ("path_len", (B,), i), ("traj", (B, M + 1, 4), f), ("traj_len", (B,), i),
+                ("status", (B,), i)))
+
+        @staticmethod
+        def _carve(pl, spec):
+            offs, total = [], 0
+            for _, shp, dt in spec:
+                offs.append(total)
+                total += -(-int(np.prod(shp)) * np.dtype(dt).itemsize // 256) * 256
+            block = pl.pinned_empty((total,), np.uint8)
+            views = {}
+            for (name, shp, dt), o in zip(spec, offs):
+                n = int(np.prod(shp)) * np.dtype(dt).itemsize
+                views[name] = block[o:o + n].view(dt).reshape(shp)
+            return views, block
+
+        def load(self, pool=None, **arrays):
+            """Copy ordinary arrays into the slot's page-locked inputs (``dyn_dis_speed`` switches the virtual obstacles of
+            test_9.py:137-169 on for this call).  Arrays with fewer scenes than the slot holds fill its head: set ``slot.B``
+            to that count for the call.  ``pool``: a ``concurrent.futures`` executor - the big array (the
+            reference lines) is then copied in chunks by its workers (NumPy's copy releases the GIL)."""
+            self.use_dyn = arrays.get("dyn_dis_speed") is not None
+            jobs = []
+            for name, src in arrays.items():
+                if src is None:
+                    continue
+                dst = self.inputs[name]
+                src = np.asarray(src)
+                if len(src) < len(dst):                    # a smaller batch in this slot: its scenes are the head of the arrays
+                    dst = dst[:len(src)]
+                if pool is not None and dst.nbytes >= (1 << 20):
+                    n = len(dst)
+                    parts = max(2, getattr(pool, "_max_workers", 4))
+                    for k in range(parts):
+                        a, b = n * k // parts, n * (k + 1) // parts
+                        jobs.append(pool.submit(np.copyto, dst[a:b], src[a:b]))
+                else:
+                    np.copyto(dst, src)
+            for j in jobs:
+                j.result()
+            return self
+
+        def wait(self):
+            """Block until this slot's latest call has delivered its outputs."""
+            if self._ticket is None:
+                return self
+            pl = self.ring.planner
+            back = int(pl._lib.emp_cycle_ticket(pl._h)) - self._ticket
+            if 0 <= back < self.ring.depth_seen():          # beyond: the call that took its pool over has waited for it
+                pl.wait_cycle(back)
+            self._ticket = None
+            return self
+
+    def __init__(self, planner, p, B, max_ref, max_obs, max_pts, depth):
+        self.planner, self.B, self.max_ref, self.max_obs, self.max_pts, self.col = planner, B, max_ref, max_obs, max_pts, int(p.col)
+        self.slots = [HostRing.Slot(self, k) for k in range(depth)]
+        self._next = 0
+
+    def depth_seen(self):
+        return max(int(self.planner._lib.emp_pipeline_depth(self.planner._h)), 1)
+
+    def next(self) -> "HostRing.Slot":
+        s = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        return s.wait()
+
+    def wait_all(self):
+        for s in self.slots:
+            s.wait()
+
+    def close(self):
+        self.planner.synchronize()
+        for s in self.slots:
+            s.inputs, s.outputs = {}, {}
+            for block in (s._in_block, s._out_block):
+                self.planner.pinned_free(block)
+        self.slots = []
+
+
 @dataclass
 class CycleResult:
     dp_rows: object      # (B, col) float64
@@ -251,6 +354,7 @@ class Planner:
         self.in_flight = 1
         self._retain = 1
         self._inflight = []
+        self._pinned = {}                # data address -> emp_host_alloc pointer of the pinned_empty arrays still alive
         self._cur = None
 
     def close(self):
@@ -829,10 +933,42 @@ class Planner:
         return t, no, st
 
     # ---- whole cycle ------------------------------------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """A NumPy array on page-locked host memory of this context (emp_host_alloc): what ``plan_cycle_pinned`` moves over
+        PCIe without a staging copy.  Lives until ``close()`` (or ``pinned_free``)."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) if len(tuple(shape)) else 1
+        ptr = C.c_void_p()
+        self._check(self._lib.emp_host_alloc(self._h, max(n * dt.itemsize, 8), C.byref(ptr)))
+        buf = (C.c_char * max(n * dt.itemsize, 8)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dt, count=n).reshape(tuple(shape))
+        self._pinned[arr.__array_interface__["data"][0]] = ptr.value
+        return arr
+
+    def pinned_free(self, arr):
+        """Give a ``pinned_empty`` array back (the array must not be used afterwards)."""
+        key = arr.__array_interface__["data"][0]
+        ptr = self._pinned.pop(key)
+        self._check(self._lib.emp_host_free(self._h, C.c_void_p(ptr)))
+
+    def host_ring(self, p: DpParams, B: int, max_ref: int, max_obs: int, max_pts=None, depth=None) -> "HostRing":
+        """``depth`` (default: the pipeline depth) slots of page-locked input and output arrays for ``B`` scenes each: the
+        overlapped host path of the planning cycle (``HostRing``)."""
+        return HostRing(self, p, int(B), int(max_ref), int(max_obs), int(max_pts) if max_pts else max_path_points(p),
+                        int(depth) if depth else max(int(self._lib.emp_pipeline_depth(self._h)), 1))
+
+    def wait_cycle(self, calls_back: int = 0):
+        """Block until the host outputs of the pinned cycle issued ``calls_back`` calls ago are in place (emp_wait_cycle)."""
+        self._check(self._lib.emp_wait_cycle(self._h, int(calls_back)))
+
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
-                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None) -> CycleResult:
+                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None, slot=None) -> CycleResult:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
-        of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169."""
+        of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169.
+        ``slot``: a ``HostRing`` slot whose page-locked arrays ARE the inputs (the array arguments are then ignored) and
+        receive the outputs - with a pipeline set the call returns before they are there (``slot.wait()``)."""
+        if slot is not None:
+            return self._plan_cycle_pinned(p, q, sp, slot, mode)
         a = self._args(ref_line, origin_xy)
         a.cycle = True               # pipelined mode: the outputs become complete on the result stream (see _Args.done)
         B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
@@ -871,6 +1007,21 @@ class Planner:
             if len(self._inflight) > self._retain:
                 self._inflight.pop(0)
         return CycleResult(**res)
+
+    def _plan_cycle_pinned(self, p, q, sp, slot, mode):
+        io = L.CycleIO()
+        for name in ("ref_line", "n_ref", "origin_xy", "start_xy", "start_v", "start_a"):
+            setattr(io, name, C.c_void_p(slot.inputs[name].ctypes.data))
+        mo = slot.max_obs
+        io.obs_xy = C.c_void_p(slot.inputs["obs_xy"].ctypes.data) if mo else None
+        io.n_obs = C.c_void_p(slot.inputs["n_obs"].ctypes.data) if mo else None
+        io.dyn_dis_speed = C.c_void_p(slot.inputs["dyn_dis_speed"].ctypes.data) if slot.use_dyn else None
+        for name, arr in slot.outputs.items():
+            setattr(io, name, C.c_void_p(arr.ctypes.data))
+        self._check(self._lib.emp_plan_cycle(self._h, C.byref(p), C.byref(q), C.byref(sp), slot.B, slot.max_ref, mo, slot.max_pts,
+                                             int(mode), C.byref(io), L.EMP_HOST_PINNED))
+        slot._ticket = int(self._lib.emp_cycle_ticket(self._h)) if self.pipelined else None
+        return CycleResult(**slot.outputs)
 
     def pack_records(self, res: "CycleResult", col: int, max_pts: int, path_cap=None, fields: str = "full"):
         """One fixed-stride float64 record per scene from a cycle's outputs on the device, in ONE launch

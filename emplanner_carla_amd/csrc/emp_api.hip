@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "emp_context.h"
 #include "emp_dp_kernels.h"
 #include "emp_st_kernels.h"
@@ -457,9 +459,15 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.ev_qp) (void)hipEventDestroy(ln.ev_qp);
         if (ln.ev_enrich) (void)hipEventDestroy(ln.ev_enrich);
+        if (ln.ev_host) (void)hipEventDestroy(ln.ev_host);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
+    if (ctx->ev_h2d) (void)hipEventDestroy(ctx->ev_h2d);
+    if (ctx->ev_host_last) (void)hipEventDestroy(ctx->ev_host_last);
+    for (void* hp : ctx->pinned) (void)hipHostFree(hp);
     if (ctx->clock_probe.p) (void)hipFree(ctx->clock_probe.p);
     if (ctx->clock_probe_done) (void)hipEventDestroy(ctx->clock_probe_done);
     if (ctx->sweep_marker) (void)hipEventDestroy(ctx->sweep_marker);
@@ -1345,7 +1353,16 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     // stands in for ctx->stream and its pool for ctx->pool - behind whatever the caller has ordered on the main stream so
     // far.  STAGED: the call takes the pool of the next of two lanes once the back stage that used it last is done; its
     // front stage runs on the main stream.
-    const int pmode = (where == EMP_DEVICE && B > 0) ? ctx->pipe_mode : 0;
+    // EMP_HOST_PINNED: the caller's arrays are page-locked; the call is pipelined like a device-pointer call, its inputs
+    // arrive over the copy stream and its outputs leave over the d2h stream (emp_context.h Stage: async_host)
+    const bool pinned = where == EMP_HOST_PINNED;
+    if (pinned && !ctx->copy_stream) {
+        EMP_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        EMP_HIP(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+        EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming));
+        EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_host_last, hipEventDisableTiming));
+    }
+    const int pmode = ((where == EMP_DEVICE || pinned) && B > 0) ? ctx->pipe_mode : 0;
     const bool piped = pmode != 0, staged = pmode == EMP_PIPELINE_STAGED;
     struct LaneSwap {
         emp_ctx* c;
@@ -1354,6 +1371,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         LaneSwap(emp_ctx* c_, int mode) : c(c_), main_stream(c_->stream) {
             if (!mode) return;
             c->lane = (c->lane + 1) % c->lanes_in_use();
+            ++c->cycle_calls;
             ln = &c->lanes[c->lane];
             std::swap(c->pool, ln->pool);
             if (mode != EMP_PIPELINE_STAGED) {
@@ -1371,7 +1389,9 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if (staged) {
         // the pool's previous user is four calls back: a host-side wait (emp_context.h, kStagedPools)
         if (lane.ln->done_valid) EMP_HIP(ctx, hipEventSynchronize(lane.ln->ev_done));
+        if (lane.ln->host_valid) EMP_HIP(ctx, hipEventSynchronize(lane.ln->ev_host));   // ... and its outputs have left the pool
     } else if (piped) {
+        if (lane.ln->host_valid) EMP_HIP(ctx, hipEventSynchronize(lane.ln->ev_host));
         // The lane's previous occupant (call k - n) and whatever its caller queued behind it on the lane's stream (record
         // packing) must be done before anything ordered on the main stream from here on may touch memory they use: the
         // caller keeps a call's outputs alive only until this call is issued, and the NEXT call runs on another lane.
@@ -1382,7 +1402,8 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
     }
-    Stage st(ctx, where, piped);
+    if (piped) lane.ln->host_valid = false;
+    Stage st(ctx, where, piped, pinned);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
     const int *d_nr, *d_no;
     if ((rc = st.in(io->ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
@@ -1395,6 +1416,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.in(io->n_obs, (size_t)B, &d_no))) return rc;
     const double* d_dyn = nullptr;
     if (has_dyn && (rc = st.in(io->dyn_dis_speed, (size_t)B * 2, &d_dyn))) return rc;
+    if ((rc = st.inputs_ready())) return rc;
     // outputs (optional ones fall back to device temporaries); no memsets: every kernel of the cycle writes its
     // rows completely, padding included
     double *d_rows, *d_dps, *d_dpl, *d_ps, *d_pl, *d_traj;
@@ -1416,6 +1438,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.out(io->traj, (size_t)B * (max_pts + 1) * 4, &d_traj, false))) return rc;
     if ((rc = st.out(io->traj_len, (size_t)B, &d_tlen, false))) return rc;
     if ((rc = st.out(io->status, (size_t)B, &d_st, false))) return rc;
+    if ((rc = st.outputs_ready())) return rc;
     // intermediates
     double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
     const int mo = obs_cap > 0 ? obs_cap : 1;
@@ -1537,7 +1560,52 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipEventRecord(lane.ln->ev_done, ctx->stream));
         lane.ln->done_valid = true;
     }
+    if (st.async_host()) {
+        // outputs go home on the d2h stream behind the cycle's last kernel; pipelined: nobody waits here (emp_wait_cycle,
+        // emp_synchronize, or the call that takes this pool over); not pipelined: the pool is the next call's, so wait
+        if (piped) {
+            if (!lane.ln->ev_host) EMP_HIP(ctx, hipEventCreateWithFlags(&lane.ln->ev_host, hipEventDisableTiming));
+            if ((rc = st.finish_async(lane.ln->ev_done, lane.ln->ev_host))) return rc;
+            lane.ln->host_valid = true;
+            return EMP_OK;
+        }
+        EMP_HIP(ctx, hipEventRecord(ctx->ev_h2d, ctx->stream));
+        if ((rc = st.finish_async(ctx->ev_h2d, ctx->ev_host_last))) return rc;
+        EMP_HIP(ctx, hipEventSynchronize(ctx->ev_host_last));
+        return EMP_OK;
+    }
     return st.finish();
+}
+
+uint64_t emp_cycle_ticket(emp_ctx* ctx) { return ctx ? ctx->cycle_calls : 0; }
+
+int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    if (!ctx->pipelined()) return EMP_OK;                       // a non-pipelined call returned with its outputs in place
+    const int n = ctx->lanes_in_use();
+    EMP_REQUIRE(ctx, calls_back >= 0 && calls_back < n, "calls_back beyond the pipeline depth");
+    emp_ctx::Lane& ln = ctx->lanes[((ctx->lane - calls_back) % n + n) % n];
+    if (ln.host_valid) EMP_HIP(ctx, hipEventSynchronize(ln.ev_host));
+    return EMP_OK;
+}
+
+int emp_host_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
+    EMP_REQUIRE(ctx, ctx && out, "NULL argument");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    EMP_HIP(ctx, hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
+    ctx->pinned.push_back(p);
+    *out = p;
+    return EMP_OK;
+}
+int emp_host_free(emp_ctx* ctx, void* ptr) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    auto it = std::find(ctx->pinned.begin(), ctx->pinned.end(), ptr);
+    EMP_REQUIRE(ctx, it != ctx->pinned.end(), "not an emp_host_alloc pointer of this context");
+    EMP_HIP(ctx, (hipError_t)sync_all(ctx));
+    EMP_HIP(ctx, hipHostFree(ptr));
+    ctx->pinned.erase(it);
+    return EMP_OK;
 }
 
 int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* coeff, emp_mem where) {

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <utility>
@@ -61,6 +62,8 @@ struct emp_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr, ev_tail = nullptr;
+        hipEvent_t ev_host = nullptr;   // EMP_HOST_PINNED cycles: the lane's latest cycle's outputs have reached the caller's host arrays
+        bool host_valid = false;
         hipEvent_t ev_qp = nullptr;     // STAGED: end of the cycle's path QP on the back stream (EMP_OPT_SWEEP_EXCLUSIVE = 2)
         hipEvent_t ev_enrich = nullptr; // STAGED: end of the cycle's densification kernel on the back stream (EMP_OPT_EDGE_AFTER_ENRICH)
         bool done_valid = false, qp_valid = false, enrich_valid = false;
@@ -68,6 +71,12 @@ struct emp_ctx {
     };
     std::vector<Lane> lanes;            // created on demand, kept until emp_destroy
     hipStream_t back_stream = nullptr;  // STAGED: the back stages (highest queue priority)
+    // EMP_HOST_PINNED (emp_plan_cycle): inputs go host -> device on copy_stream while the previous call computes, outputs device ->
+    // host on d2h_stream behind the cycle's last kernel - neither ever sits on a queue that carries kernels.  Created on first use.
+    hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+    hipEvent_t ev_h2d = nullptr;        // the latest call's inputs have arrived
+    hipEvent_t ev_host_last = nullptr;  // non-pipelined pinned call: outputs have reached the host
+    std::vector<void*> pinned;          // emp_host_alloc allocations still alive (freed by emp_destroy)
     // STAGED: the event the front stage's LAST kernel (the sweep) is asked to signal when it completes (hipExtLaunchKernelGGL's
     // stop event: no marker packet behind the kernel), and the event that launch did attach - its own timing event when the
     // kernel is being timed, else front_stop, else nullptr (launchers that attach nothing: the caller records an event).
@@ -79,6 +88,7 @@ struct emp_ctx {
     bool bt_deferred = false;
     int pipe_mode = 0;                  // 0 off, 1 STAGED, n >= 2 LANES with n lanes
     int lane = 0;                       // lane of the latest pipelined cycle call
+    uint64_t cycle_calls = 0;           // pipelined emp_plan_cycle calls issued so far (emp_cycle_ticket)
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
@@ -145,8 +155,9 @@ inline int sync_all(emp_ctx* ctx) {
         const hipError_t e2 = ln.stream ? hipStreamSynchronize(ln.stream) : hipSuccess;
         if (e == hipSuccess) e = e2;
     }
-    if (ctx->back_stream) {
-        const hipError_t e2 = hipStreamSynchronize(ctx->back_stream);
+    for (hipStream_t st : {ctx->back_stream, ctx->copy_stream, ctx->d2h_stream}) {
+        if (!st) continue;
+        const hipError_t e2 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e2;
     }
     return (int)e;
@@ -186,7 +197,11 @@ class Stage {
     // in_cycle: the pipelined emp_plan_cycle (and a launch placed on its lane) orders itself; every OTHER call in
     // pipelined mode first lets the main stream wait for the cycles still in flight, so that it may consume a cycle's
     // outputs as before
-    Stage(emp_ctx* c, emp_mem where, bool in_cycle = false) : ctx_(c), dev_(where == EMP_DEVICE) {
+    // async_host (emp_plan_cycle with EMP_HOST_PINNED): the caller's arrays are page-locked (emp_host_alloc) - inputs are copied
+    // on ctx->copy_stream (inputs_ready() orders the compute stream behind them), outputs on ctx->d2h_stream behind `after`
+    // (finish_async), and nothing blocks the host
+    Stage(emp_ctx* c, emp_mem where, bool in_cycle = false, bool async_host = false)
+        : ctx_(c), dev_(where == EMP_DEVICE), async_(async_host && where != EMP_DEVICE) {
         c->cursor = 0;
         if (!in_cycle && c->pipelined() && c->fence)
             for (auto& ln : c->lanes)
@@ -197,6 +212,11 @@ class Stage {
     int in(const T* host, size_t n, const T** out) {
         if (host == nullptr) { *out = nullptr; return EMP_OK; }
         if (dev_) { *out = host; return EMP_OK; }
+        if (async_) {            // deferred: inputs_ready() places all inputs of the call at once and fills *out then
+            ins_.push_back({(void*)host, nullptr, n * sizeof(T), (void**)out});
+            *out = reinterpret_cast<const T*>(kPending);
+            return EMP_OK;
+        }
         void* d = nullptr;
         int rc = pool_get(ctx_, n * sizeof(T), &d);
         if (rc) return rc;
@@ -204,18 +224,53 @@ class Stage {
         *out = (const T*)d;
         return EMP_OK;
     }
+    // async_host: every input of the call is known.  Arrays that lie side by side in host memory (a HostRing slot is ONE
+    // page-locked block: api.py) get one device block at the same offsets and cross PCIe as ONE copy - a copy command costs
+    // 10-20 us of host and engine time whatever its size, and a call has nine inputs; others are copied one by one.  Then the
+    // compute stream waits for the copy stream.
+    int inputs_ready() {
+        if (!async_) return EMP_OK;
+        int rc = place(ins_, true);
+        if (rc) return rc;
+        EMP_HIP(ctx_, hipEventRecord(ctx_->ev_h2d, ctx_->copy_stream));
+        EMP_HIP(ctx_, hipStreamWaitEvent(ctx_->stream, ctx_->ev_h2d, 0));
+        return EMP_OK;
+    }
+    // async_host: every output of the call is known - device buffers for them, one block where the host arrays are one block
+    int outputs_ready() {
+        if (!async_) return EMP_OK;
+        return place(backs_, false);
+    }
+    // async_host: copy the outputs back on the d2h stream once `after` (the cycle's completion event) has fired, then signal `done`
+    int finish_async(hipEvent_t after, hipEvent_t done) {
+        EMP_HIP(ctx_, hipStreamWaitEvent(ctx_->d2h_stream, after, 0));
+        if (block_out_.bytes) {
+            EMP_HIP(ctx_, hipMemcpyAsync(block_out_.host, block_out_.dev, block_out_.bytes, hipMemcpyDeviceToHost, ctx_->d2h_stream));
+        } else {
+            for (auto& b : backs_)
+                if (b.bytes) EMP_HIP(ctx_, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx_->d2h_stream));
+        }
+        EMP_HIP(ctx_, hipEventRecord(done, ctx_->d2h_stream));
+        return EMP_OK;
+    }
+    bool async_host() const { return async_; }
     // Outputs are zero-filled on the context's stream before the kernels run, so padding beyond a scene's
     // length reads as 0 in both memory spaces (pass zero=false for arrays the kernels fully overwrite).
     template <typename T>
     int out(T* host, size_t n, T** outp, bool zero = true) {
         if (host == nullptr) { *outp = nullptr; return EMP_OK; }
         T* d = host;
+        if (async_) {            // deferred: outputs_ready()
+            backs_.push_back({host, nullptr, n * sizeof(T), (void**)outp});
+            *outp = reinterpret_cast<T*>(kPending);
+            return EMP_OK;
+        }
         if (!dev_) {
             void* v = nullptr;
             int rc = pool_get(ctx_, n * sizeof(T), &v);
             if (rc) return rc;
             d = (T*)v;
-            backs_.push_back({host, d, n * sizeof(T)});
+            backs_.push_back({host, d, n * sizeof(T), nullptr});
         }
         if (zero && n) EMP_HIP(ctx_, hipMemsetAsync(d, 0, n * sizeof(T), ctx_->stream));
         *outp = d;
@@ -244,10 +299,51 @@ class Stage {
         void* host;
         void* dev;
         size_t bytes;
+        void** slot;       // async_host: where the device pointer goes once it is known
     };
+    static constexpr uintptr_t kPending = 8;     // non-null placeholder of a deferred pointer (never dereferenced)
+    // device memory for a call's arrays (async_host).  If the host arrays span a block with less than 1/8 of padding, the
+    // device side is one block with the same offsets (inputs: copied at once; outputs: block_out_ remembers it for finish_async).
+    int place(std::vector<Back>& v, bool inputs) {
+        if (v.empty()) return EMP_OK;
+        uintptr_t lo = ~(uintptr_t)0, hi = 0;
+        size_t sum = 0;
+        for (auto& b : v) {
+            lo = std::min(lo, (uintptr_t)b.host);
+            hi = std::max(hi, (uintptr_t)b.host + b.bytes);
+            sum += b.bytes;
+        }
+        const size_t span = hi - lo;
+        const bool block = v.size() > 1 && span <= sum + sum / 8 + 4096 * v.size();
+        if (block) {
+            void* d = nullptr;
+            int rc = pool_get(ctx_, span, &d);
+            if (rc) return rc;
+            for (auto& b : v) {
+                b.dev = (char*)d + ((uintptr_t)b.host - lo);
+                *b.slot = b.dev;
+            }
+            if (inputs) {
+                if (span) EMP_HIP(ctx_, hipMemcpyAsync(d, (void*)lo, span, hipMemcpyHostToDevice, ctx_->copy_stream));
+            } else {
+                block_out_ = {(void*)lo, d, span, nullptr};
+            }
+            return EMP_OK;
+        }
+        for (auto& b : v) {
+            void* d = nullptr;
+            int rc = pool_get(ctx_, b.bytes, &d);
+            if (rc) return rc;
+            b.dev = d;
+            *b.slot = d;
+            if (inputs && b.bytes) EMP_HIP(ctx_, hipMemcpyAsync(d, b.host, b.bytes, hipMemcpyHostToDevice, ctx_->copy_stream));
+        }
+        return EMP_OK;
+    }
     emp_ctx* ctx_;
-    bool dev_;
-    std::vector<Back> backs_;
+    bool dev_, async_;
+    std::vector<Back> backs_, ins_;
+    Back block_out_ = {nullptr, nullptr, 0, nullptr};
 };
 
 // RAII kernel timer: when ctx->timing is on, brackets a launch with a fresh HIP event pair on the context's

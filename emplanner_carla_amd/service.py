@@ -70,6 +70,78 @@ def plan_arrays(planner: Planner, a, dp=None, qp=None, sp=None, stages=None):
     return st_ref, match, res, M
 
 
+class CycleStream:
+    """``plan_arrays`` for callers that have more than one batch in the air (the wire server's sessions, a driver that plans for
+    several vehicles): the overlapped host path of the planning cycle (``api.HostRing``, EMP_HOST_PINNED).
+
+    ``submit`` runs the front end, copies the batch into the next page-locked ring slot and queues the cycle on the staged
+    pipeline - it returns while the inputs are still crossing PCIe; ``result`` waits for that batch's outputs and hands them
+    back as ordinary arrays.  Calls from different threads interleave: while one thread waits in ``result``, another's
+    ``submit`` already has the GPU working on the next batch (``submit`` itself is serialised by a lock: one context, one
+    call at a time).  Results are bit for bit those of ``plan_arrays`` - same kernels, same order."""
+
+    def __init__(self, planner: Planner, capacity: int = 256, max_static: int = 8):
+        import threading
+        self.planner, self.capacity, self.max_static = planner, int(capacity), int(max_static)
+        self._lock = threading.Lock()
+        self._rings = {}
+        planner.set_pipeline(1)                                             # staged: two batches in flight
+        planner.set_fence(False)                                            # the front end reads nothing of the cycles in flight
+
+    def _ring(self, dp, B, P, mo):
+        cap = max(self.capacity, 1 << max(B - 1, 0).bit_length())
+        key = (int(dp.row), int(dp.col), float(dp.sample_s), float(dp.sampling_res), cap, P, mo)
+        if key not in self._rings:
+            self._rings[key] = self.planner.host_ring(dp, cap, P, mo, max_path_points(dp))
+        return self._rings[key]
+
+    def submit(self, a, dp=None, qp=None, sp=None):
+        dp = dp or dp_params()
+        qp = qp or qp_params()
+        sp = sp or smooth_params()
+        B = len(a["n_global"])
+        with self._lock:
+            pl = self.planner
+            ref, n_ref, match, _, st_ref = pl.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
+            if B == 0:
+                return dict(B=0, st_ref=st_ref, match=match, M=max_path_points(dp), slot=None)
+            mo = max(int(a["obs_xy"].shape[1]), self.max_static)
+            slot = self._ring(dp, B, int(ref.shape[1]), mo).next()
+            n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
+            slot.inputs["obs_xy"][:B] = 0.0
+            slot.inputs["obs_xy"][:B, :a["obs_xy"].shape[1]] = a["obs_xy"]
+            slot.load(ref_line=ref, n_ref=n_ref_used, origin_xy=a["veh"], start_xy=a["pred"], start_v=a["v"], start_a=a["a"],
+                      n_obs=a["n_obs"], dyn_dis_speed=a["dyn"])
+            cap, slot.B = slot.B, B
+            try:
+                pl.plan_cycle(dp, qp, sp, None, None, None, None, None, None, None, None, slot=slot)
+            finally:
+                slot.B = cap
+            return dict(B=B, st_ref=st_ref, match=match, M=slot.max_pts, slot=slot)
+
+    def result(self, h):
+        """(reference-line status, match index, CycleResult, max_pts) of a submitted batch, as ``plan_arrays`` returns them."""
+        from .api import CycleResult
+        if h["slot"] is None:
+            z = np.zeros((0,))
+            return h["st_ref"], h["match"], CycleResult(*([z] * 10)), h["M"]
+        with self._lock:
+            h["slot"].wait()
+            out = {k: np.array(v[:h["B"]]) for k, v in h["slot"].outputs.items()}     # the slot goes back to the ring
+        return h["st_ref"], h["match"], CycleResult(**out), h["M"]
+
+    def plan_arrays(self, a, dp=None, qp=None, sp=None):
+        return self.result(self.submit(a, dp, qp, sp))
+
+    def close(self):
+        with self._lock:
+            for r in self._rings.values():
+                r.close()
+            self._rings = {}
+            self.planner.set_fence(True)
+            self.planner.set_pipeline(0)
+
+
 def plan_requests(planner: Planner, requests, dp=None, qp=None, sp=None, stages=None):
     """requests: list of request tuples.  Returns a list of (reply tuple or None, status): None where the reference
     would have raised (IndexError paths) or where a QP is infeasible.  ``stages``: a dict that receives the packed

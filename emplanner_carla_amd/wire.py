@@ -219,11 +219,14 @@ MAX_ROW, MAX_COL, MAX_OBSTACLE_SLOTS, MAX_PATH_POINTS = 256, 256, 64, 255
 class PlannerServer:
     """``PlannerServer(plan_arrays).serve_forever()``: ``plan_arrays(arrays, dp) -> (st_ref, match, CycleResult, max_pts)``
     is what answers a batch (``serve`` below binds it to a GPU planner; tests bind a stub).  One thread per connection;
-    the planner call itself is serialised (one device context)."""
+    the planner call itself is serialised (one device context) unless ``overlapped`` says that ``plan_arrays`` does that
+    itself (``service.CycleStream.plan_arrays``: submissions are serialised, the sessions' batches overlap on the GPU)."""
 
     def __init__(self, plan_arrays, host: str = "127.0.0.1", port: int = 0, max_payload: int = 256 << 20,
-                 max_paths: int = 4096, max_path_bytes: int = 64 << 20, max_reply_bytes: int = 256 << 20):
+                 max_paths: int = 4096, max_path_bytes: int = 64 << 20, max_reply_bytes: int = 256 << 20,
+                 overlapped: bool = False):
         self.plan_arrays = plan_arrays
+        self.overlapped = bool(overlapped)
         self.max_payload, self.max_paths = int(max_payload), int(max_paths)     # per frame / per session
         self.max_path_bytes, self.max_reply_bytes = int(max_path_bytes), int(max_reply_bytes)   # per session / per frame
         self.sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -275,8 +278,11 @@ class PlannerServer:
                         if count * layout.reply_stride > self.max_reply_bytes:
                             raise WireError(f"{count} replies of {layout.reply_stride} bytes exceed {self.max_reply_bytes}")
                         ids, arrays = layout.decode_requests(payload, count, paths)
-                        with self._lock:
+                        if self.overlapped:      # the planner serialises its own submissions; sessions overlap on the GPU
                             st_ref, match, res, _ = self.plan_arrays(arrays, layout.dp)
+                        else:
+                            with self._lock:
+                                st_ref, match, res, _ = self.plan_arrays(arrays, layout.dp)
                         send_frame(conn, T_REPLY, layout.encode_replies(ids, st_ref, match, res), count)
                     elif ftype == T_BYE:
                         return
@@ -299,7 +305,8 @@ def serve(host: str = "127.0.0.1", port: int = 5055, device_id: int = 0):
     from . import service
     from .api import Planner
     planner = Planner(device_id)
-    srv = PlannerServer(lambda arrays, dp: service.plan_arrays(planner, arrays, dp=dp), host, port)
+    stream = service.CycleStream(planner)             # page-locked rings, staged pipeline: the sessions' batches overlap
+    srv = PlannerServer(lambda arrays, dp: stream.plan_arrays(arrays, dp=dp), host, port, overlapped=True)
     print(f"emplanner wire server v{WIRE_VERSION} on {srv.address[0]}:{srv.address[1]}, device {device_id}", flush=True)
     srv.serve_forever()
 

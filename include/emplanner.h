@@ -43,7 +43,12 @@ typedef enum emp_error {
     EMP_ERR_NOMEM = -4
 } emp_error;
 
-typedef enum emp_mem { EMP_HOST = 0, EMP_DEVICE = 1 } emp_mem;
+/* Where the arrays of a call live.  EMP_HOST: ordinary host memory - the call copies in, computes, copies out and returns when
+ * the outputs are there.  EMP_DEVICE: device memory, used in place; the call returns at once (stream-ordered).
+ * EMP_HOST_PINNED (ABI 10): page-locked host memory from emp_host_alloc.  Every entry point accepts it like EMP_HOST;
+ * emp_plan_cycle additionally overlaps it (see there): inputs cross PCIe on a copy stream while the previous call computes,
+ * outputs come back on a stream of their own, and with a pipeline set the call does not wait for them - emp_wait_cycle does. */
+typedef enum emp_mem { EMP_HOST = 0, EMP_DEVICE = 1, EMP_HOST_PINNED = 2 } emp_mem;
 
 /* per-scene status bits */
 enum {
@@ -108,6 +113,16 @@ int emp_synchronize(emp_ctx* ctx);
 /* the context's HIP stream (hipStream_t) so callers can order their own work after ours */
 void* emp_stream(emp_ctx* ctx);
 /* device memory helpers for callers without a HIP binding (ctypes hosts) */
+/* Page-locked host memory for EMP_HOST_PINNED calls (hipHostMalloc); freed by emp_host_free or emp_destroy. */
+int emp_host_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
+int emp_host_free(emp_ctx* ctx, void* ptr);
+/* EMP_HOST_PINNED cycles: block until the outputs of the emp_plan_cycle call issued `calls_back` calls ago (0 = the latest)
+ * are in the caller's host arrays.  calls_back < emp_pipeline_depth(); EMP_ERR_INVALID beyond (that call's arrays were already
+ * waited for when its pool was taken over).  A call that was not an EMP_HOST_PINNED cycle has nothing to wait for: EMP_OK. */
+int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back);
+/* The number of pipelined emp_plan_cycle calls issued on this context so far: the ticket of the latest one.  A caller that keeps
+ * the ticket of a call finds it again as calls_back = emp_cycle_ticket() - ticket. */
+uint64_t emp_cycle_ticket(emp_ctx* ctx);
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
 int emp_device_free(emp_ctx* ctx, void* ptr);
 int emp_copy_to_device(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);

@@ -18,9 +18,9 @@ def _driver_request(g, c):
             tuple(g["pred"][c]), tuple(g["v"][c]), tuple(g["a"][c]), [tuple(r) for r in g["path"][c]], [int(g["pre_match"][c])])
 
 
-def _start(plan_arrays):
+def _start(plan_arrays, **kw):
     from emplanner_carla_amd import wire
-    srv = wire.PlannerServer(plan_arrays)
+    srv = wire.PlannerServer(plan_arrays, **kw)
     th = threading.Thread(target=srv.serve_forever, daemon=True)
     th.start()
     return srv
@@ -188,4 +188,49 @@ def test_remote_planning_equals_the_reference_driver_run():
         cl.close()
     finally:
         srv.shutdown()
+        planner.close()
+
+
+@pytest.mark.gpu
+def test_overlapped_server_with_concurrent_sessions_equals_the_serial_path():
+    """What ``wire.serve`` runs: the server on ``service.CycleStream`` (page-locked rings, staged pipeline, no server-side
+    lock).  Four client sessions fire PLAN frames of different sizes at once, eight rounds each; every reply must be the
+    reply of the serial path (``service.plan_requests`` on a plain planner), bit for bit, whatever overlapped with it."""
+    import threading
+    from emplanner_carla_amd import service, wire
+    from emplanner_carla_amd.api import Planner, dp_params
+    g = load_golden("driver_s147.npz")
+    reqs = [_driver_request(g, c) for c in range(len(g["case"]))]
+    dp = dp_params(sample_s=14.7)
+    plain = Planner(0)
+    want = service.plan_requests(plain, reqs, dp=dp)
+    plain.close()
+    planner = Planner(0)
+    stream = service.CycleStream(planner, capacity=32, max_static=4)
+    srv = _start(lambda arrays, dp_: stream.plan_arrays(arrays, dp=dp_), overlapped=True)
+    errors = []
+
+    def session(k):
+        try:
+            cl = wire.PlannerClient(*srv.address, dp=dp, max_static=4, max_dynamic=2)
+            for r in range(8):
+                pick = [(k * 5 + r * 3 + j) % len(reqs) for j in range(3 + 4 * k)]
+                got = cl.plan([reqs[c] for c in pick])
+                for c, (reply, status) in zip(pick, got):
+                    assert status == want[c][1] and reply == want[c][0], f"session {k} round {r} request {c}"
+            cl.close()
+        except Exception as exc:          # noqa: BLE001 - reported by the main thread
+            errors.append(f"session {k}: {type(exc).__name__}: {exc}")
+
+    try:
+        threads = [threading.Thread(target=session, args=(k,)) for k in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in threads)
+    finally:
+        srv.shutdown()
+        stream.close()
         planner.close()

@@ -34,3 +34,30 @@ for _ in range(K):
 dt = (time.perf_counter() - t0) / K
 print(f"host buffers: {B} scenes, {dt * 1e3:.3f} ms per step, {B / dt / 1e6:.3f} M planning cycles/s "
       f"(inputs {in_bytes / 1e6:.1f} MB, results {out_bytes / 1e6:.1f} MB per step)")
+
+# ---- the overlapped host path (api.HostRing: page-locked rings, copy streams, staged pipeline)
+from concurrent.futures import ThreadPoolExecutor
+pl.set_pipeline(1)
+ring = pl.host_ring(p, B, P, cfg.n_obs, M)
+for label, loader in (("inputs written in place (zero copy)", None), ("np.copyto from pageable arrays, 1 thread", "serial"),
+                      ("np.copyto from pageable arrays, 8 threads", "pool"), ("inputs written in place (zero copy), again", None)):
+    pool = ThreadPoolExecutor(8) if loader == "pool" else None
+    for s_ in ring.slots:
+        s_.load(**inputs)
+    for _ in range(8):
+        pl.plan_cycle(p, q, sp, None, None, None, None, None, None, None, None, max_pts=M, slot=ring.next())
+    ring.wait_all()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        slot = ring.next()
+        if loader:
+            slot.load(pool=pool, **inputs)
+        pl.plan_cycle(p, q, sp, None, None, None, None, None, None, None, None, max_pts=M, slot=slot)
+    ring.wait_all()
+    dt = (time.perf_counter() - t0) / K
+    print(f"host ring, {label}: {dt * 1e3:.3f} ms per step, {B / dt / 1e6:.3f} M planning cycles/s, "
+          f"{(in_bytes + out_bytes) / dt / 1e9:.1f} GB/s over PCIe (both directions)")
+    if pool:
+        pool.shutdown()
+ok = float(((ring.slots[0].outputs["status"] & ~1) == 0).mean())
+print("planned to the end:", ok)
