@@ -34,10 +34,17 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   value / all_scenes_cycles_per_s   `value` counts the scenes whose cycle ran to the end (scenes_fully_planned_frac of the batch;
                 the rest are refused at the end of the cycle: walls, blocked corridors, infeasible QPs - they were computed
                 too and cost the same time); all_scenes_cycles_per_s = scenes per step / ms_per_step
-  overlapped_sweep_leg, dram_leg, cfg5_leg, latency_leg   (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them)
-                short secondary measurements after the headline: the rounds 1-3 pipeline with the sweep free to overlap the
-                back stage; 32768 scenes (the edge tensor streams from HBM instead of the Infinity Cache); BASELINE
-                configs[4] (120x21 lattice + S-T speed DP) on 4096 scenes; configs[1] (one scene per synchronous call)
+  roofline_step   the whole step against the chip's vector-issue capacity: sum over the step's kernels of their VALU-busy
+                quad-cycles (committed SQ counter pass, source named) / (1024 SIMDs x clock / 4 x ms_per_step), with the measured
+                cost of a wave64 FP64 instruction (tools/fp64_pipe_bench.hip: 4.3 cycles, not the 4 the counter charges)
+  exclusive_sweep_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
+                (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them) short secondary measurements after the
+                headline: the sweep held back behind the previous batch's path QP (EMP_OPT_SWEEP_EXCLUSIVE = 2: the sweep's
+                bandwidth at its best, the step 6 % slower); 32768 scenes (the edge tensor streams from HBM instead of the
+                Infinity Cache); BASELINE configs[4] (120x21 lattice + S-T speed DP) on 4096 scenes; configs[1] (one scene per
+                synchronous call); SURVEY 8(d)'s own geometry (arc radii 150-1000 m) with its slalom layout and with the
+                corridor layout; the host path (NumPy arrays in and out through the page-locked ring, PCIe included); the
+                per-step code of an N > 1 rank (record packing + gather streams) on this one GPU
 """
 from __future__ import annotations
 
@@ -54,17 +61,17 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (public spec figure)
 
 
-def cpu_baseline(cfg, n_scenes, seed0, dist_name="corridor", budget_s=25.0):
+def cpu_baseline(cfg, n_scenes, seed0, scene_kw=None, budget_s=25.0):
     """Time the reference-structured CPU path (the oracle's faithful port) on a bounded sample."""
+    scene_kw = dict(scene_kw or {})
     import contextlib
     import io
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
     kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
-    scenes = [S.make_scene(seed0 + i, cfg, dist=dist_name) for i in range(n_scenes)]
+    scenes = [S.make_scene(seed0 + i, cfg, **scene_kw) for i in range(n_scenes)]
     t0 = time.perf_counter()
     done = 0
     for sc in scenes:
@@ -97,7 +104,7 @@ def usable_cores(cap):
     return max(1, min(n, cap))
 
 
-def cpu_baseline_pool(cfg_name, workers, per_worker):
+def cpu_baseline_pool(cfg_name, workers, per_worker, scene_kw=None):
     """The same CPU path on `workers` host cores at once (one single-threaded process per core, spawned so that no
     worker inherits this process's HIP state): whole-pool throughput over workers * per_worker scenes."""
     import multiprocessing as mp
@@ -108,7 +115,8 @@ def cpu_baseline_pool(cfg_name, workers, per_worker):
     try:
         with mp.get_context("spawn").Pool(workers) as pool:
             pool.map(cpu_pool.warm, range(workers), chunksize=1)           # processes up, modules imported
-            jobs = [(cfg_name, list(range(10000 + w * per_worker, 10000 + (w + 1) * per_worker))) for w in range(workers)]
+            jobs = [(cfg_name, list(range(10000 + w * per_worker, 10000 + (w + 1) * per_worker)), dict(scene_kw or {}))
+                    for w in range(workers)]
             t0 = time.perf_counter()
             done = pool.map(cpu_pool.plan_seeds, jobs, chunksize=1)
             dt = time.perf_counter() - t0
@@ -155,7 +163,7 @@ def latency_main(args):
     cfg = S.CFG2
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    batch = S.make_batch([7], cfg, dist=args.scene_dist)
+    batch = S.make_batch([7], cfg, **scene_kwargs(args))
     P = batch.ref.shape[1]
     host = dict(ref_line=batch.ref, n_ref=np.full(1, P, np.int32), origin_xy=batch.origin_xy, start_xy=batch.start_xy,
                 start_v=batch.start_v, start_a=batch.start_a, obs_xy=batch.obs_xy, n_obs=batch.n_obs)
@@ -193,14 +201,21 @@ def latency_main(args):
             "note": "a single scene occupies one wavefront per kernel: the cycle is launch and dependent-instruction latency, "
                     "no roofline applies"}
     if not args.no_cpu_baseline:
-        cb = cpu_baseline(cfg, 8, 7, args.scene_dist, budget_s=10.0)
+        cb = cpu_baseline(cfg, 8, 7, scene_kwargs(args), budget_s=10.0)
         line["cpu_baseline"] = {**cb, "value": round(1e3 / cb["value"], 2), "unit": "ms per planning cycle"}
     print(json.dumps(line), flush=True)
     pl.close()
 
 
-def _device_inputs(torch, S, cfg, seeds, device, dist_name="corridor"):
-    batch = S.make_batch(seeds, cfg, dist=dist_name)
+def scene_kwargs(args):
+    """scenes.make_scene options of the run: obstacle layout, planning start (default: off the reference-line nodes), arc radii."""
+    from emplanner_carla_amd import scenes as S
+    return dict(dist=args.scene_dist, start_ahead=args.start_ahead,
+                radius_range=S.SURVEY_ARCS if args.arcs == "survey" else S.GENTLE_ARCS)
+
+
+def _device_inputs(torch, S, cfg, seeds, device, scene_kw=None):
+    batch = S.make_batch(seeds, cfg, **(scene_kw or {}))
     P = batch.ref.shape[1]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return dict(ref_line=t(batch.ref), n_ref=t(np.full(len(batch.seeds), P, np.int32)), origin_xy=t(batch.origin_xy),
@@ -208,7 +223,7 @@ def _device_inputs(torch, S, cfg, seeds, device, dist_name="corridor"):
                 obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
 
 
-def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, dist_name="corridor", speed=False):
+def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, scene_kw=None, speed=False, options=None):
     """A short, separately reported measurement of ANOTHER workload inside the default run (the driver's one command then
     observes it too): `untimed` steps, a fence, `steps` timed steps with the sweep bracketed by events, a fence - the
     headline's own procedure - then three steps with every kernel bracketed, one batch in flight, for the kernel table.
@@ -217,8 +232,12 @@ def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, dist_name="cor
     from emplanner_carla_amd import scenes as S
     from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params, speed_dp_params
     t_leg = time.perf_counter()
+    saved = {}
     try:
-        inputs = _device_inputs(torch, S, cfg, range(scenes), device, dist_name)
+        for k, v in (options or {}).items():
+            saved[k] = pl.get_option(k)
+            pl.set_option(k, v)
+        inputs = _device_inputs(torch, S, cfg, range(scenes), device, scene_kw)
         st_inputs = None
         if speed:
             dyn = S.make_dynamic_batch(range(scenes), 16)
@@ -281,6 +300,10 @@ def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, dist_name="cor
                "kernels_ms_one_batch_in_flight": kernels}
         if speed and "speed_dp" in kernels:
             out["speed_dp_us"] = round(kernels["speed_dp"] * 1e3, 1)
+        if options:
+            out["options"] = dict(options)
+        if scene_kw:
+            out["scenes"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in scene_kw.items()}
         out["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
         return out
     except Exception as exc:                                    # a secondary leg never costs the headline
@@ -290,16 +313,22 @@ def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, dist_name="cor
         except Exception:
             pass
         return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    finally:
+        for k, v in saved.items():
+            try:
+                pl.set_option(k, v)
+            except Exception:
+                pass
 
 
-def latency_leg(pl, torch, device, calls=50, dist_name="corridor"):
+def latency_leg(pl, torch, device, calls=50, scene_kw=None):
     """BASELINE configs[1] inside the default run: ONE scene on the 40x9 lattice, one synchronous call per cycle."""
     from emplanner_carla_amd import scenes as S
     from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params
     t_leg = time.perf_counter()
     try:
         cfg = S.CFG2
-        dev = _device_inputs(torch, S, cfg, [7], device, dist_name)
+        dev = _device_inputs(torch, S, cfg, [7], device, scene_kw)
         p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
         M = max_path_points(p)
         pl.set_timing(False)
@@ -322,6 +351,207 @@ def latency_leg(pl, torch, device, calls=50, dist_name="corridor"):
         return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
 
 
+def host_io_leg(pl, torch, cfg, scenes, steps, scene_kw=None):
+    """The host path inside the default run: NumPy arrays in, NumPy arrays out, PCIe included (reference boundary: Python
+    lists per request, test_9.py:92-96, 220, 390-395).  Ordinary (pageable) input arrays are copied into the page-locked
+    ring (api.HostRing) with np.copyto, the cycle runs on the staged pipeline with its inputs on a copy stream and its outputs
+    on a stream of their own, the results are read from the ring's page-locked output arrays.  Also the synchronous
+    EMP_HOST path of rounds 1-4 (pageable arrays staged by the library, one call at a time), and one scene per call."""
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params
+    t_leg = time.perf_counter()
+    ring = None
+    try:
+        batch = S.make_batch(range(scenes), cfg, **(scene_kw or {}))
+        P = batch.ref.shape[1]
+        c = np.ascontiguousarray
+        host = dict(ref_line=c(batch.ref), n_ref=np.full(scenes, P, np.int32), origin_xy=c(batch.origin_xy), start_xy=c(batch.start_xy),
+                    start_v=c(batch.start_v), start_a=c(batch.start_a), obs_xy=c(batch.obs_xy), n_obs=c(batch.n_obs))
+        p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+        M = max_path_points(p)
+        pl.set_timing(False)
+        pl.set_pipeline(0)
+        for _ in range(2):
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **host)
+        t0 = time.perf_counter()
+        n_sync = max(3, steps // 4)
+        for _ in range(n_sync):
+            r = pl.plan_cycle(p, q, sp, max_pts=M, **host)
+        sync_ms = (time.perf_counter() - t0) / n_sync * 1e3
+        in_bytes = sum(a.nbytes for a in host.values())
+        pl.set_pipeline(1)
+        ring = pl.host_ring(p, scenes, P, cfg.n_obs, M)
+        out_bytes = sum(a.nbytes for a in ring.slots[0].outputs.values())
+        none8 = (None,) * 8
+
+        def run(k, load):
+            for _ in range(k):
+                slot = ring.next()
+                if load:
+                    slot.load(**host)
+                pl.plan_cycle(p, q, sp, *none8, max_pts=M, slot=slot)
+            ring.wait_all()
+
+        for s_ in ring.slots:
+            s_.load(**host)
+        run(120, True)                  # (the first hundred calls through fresh page-locked memory run at half speed)
+        t0 = time.perf_counter()
+        run(steps, True)
+        ring_ms = (time.perf_counter() - t0) / steps * 1e3
+        t0 = time.perf_counter()
+        run(steps, False)
+        inplace_ms = (time.perf_counter() - t0) / steps * 1e3
+        ok = float(((ring.slots[0].outputs["status"] & ~1) == 0).mean())
+        same = bool(np.array_equal(ring.slots[0].outputs["status"], r.status) and
+                    np.array_equal(ring.slots[0].outputs["traj_len"], r.traj_len))
+        ring.close()
+        ring = None
+        # one scene per call through the same path (a driver that plans for one vehicle and holds NumPy arrays)
+        one = {k: v[:1] for k, v in host.items()}
+        pl.set_pipeline(0)
+        for _ in range(5):
+            pl.plan_cycle(p, q, sp, max_pts=M, **one)
+        t0 = time.perf_counter()
+        for _ in range(30):
+            pl.plan_cycle(p, q, sp, max_pts=M, **one)
+        one_ms = (time.perf_counter() - t0) / 30 * 1e3
+        return {"workload": f"{scenes} scenes, lattice col={cfg.col} x row={cfg.row}, {cfg.n_obs} obstacles; NumPy arrays in and out "
+                            "(host memory at the boundary, PCIe included)",
+                "steps": steps, "bytes_in_per_step": int(in_bytes), "bytes_out_per_step": int(out_bytes),
+                "host_ring": {"ms_per_step": round(ring_ms, 4), "all_scenes_cycles_per_s": round(scenes / ring_ms * 1e3, 1),
+                              "fully_planned_cycles_per_s": round(scenes / ring_ms * 1e3 * ok, 1),
+                              "pcie_gbs_both_directions": round((in_bytes + out_bytes) / ring_ms / 1e6, 1),
+                              "how": "pageable NumPy inputs -> np.copyto into a page-locked ring slot -> emp_plan_cycle(EMP_HOST_PINNED) "
+                                     "on the staged pipeline (one H2D copy on the copy stream, one D2H copy on its own stream) -> "
+                                     "results read in place from the slot's page-locked arrays"},
+                "host_ring_inputs_written_in_place": {"ms_per_step": round(inplace_ms, 4),
+                                                      "all_scenes_cycles_per_s": round(scenes / inplace_ms * 1e3, 1)},
+                "synchronous_pageable_path": {"ms_per_step": round(sync_ms, 4), "all_scenes_cycles_per_s": round(scenes / sync_ms * 1e3, 1),
+                                              "how": "emp_plan_cycle(EMP_HOST): the library stages pageable arrays, one call at a time (rounds 1-4)"},
+                "one_scene_host_latency_ms": round(one_ms, 4), "scenes_fully_planned_frac": round(ok, 4),
+                "ring_outputs_equal_the_synchronous_path": same, "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    finally:
+        try:
+            if ring is not None:
+                ring.close()
+            pl.set_pipeline(0)
+        except Exception:
+            pass
+
+
+def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=None, records="full"):
+    """The per-step code of an N > 1 rank on this one GPU (what `--force-gather-path` runs as a line of its own): the staged
+    step + record packing on the result stream + the gather on a stream of its own (the identity without a process group).
+    No 2/4/8-GPU node has been available to any round: this leg, the gloo step-loop tests and the shard == slice tests are
+    what stands in for the scaling run."""
+    from emplanner_carla_amd import _lib as L
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import dp_params_from_cfg, max_path_points, qp_params, smooth_params
+    t_leg = time.perf_counter()
+    try:
+        inputs = _device_inputs(torch, S, cfg, range(scenes), device, scene_kw)
+        p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+        M = max_path_points(p)
+        pl.set_timing(False)
+        pl.set_pipeline(1)
+        ts = pl.torch_stream()
+        sg = emp_dist.StepGather(p.col, M, scenes, planner=pl, fields=records, device=device, dst=0, timing=True)
+
+        def step(gather=True):
+            with torch.cuda.stream(ts):
+                res = pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
+            return sg.submit(res) if gather else res
+
+        def fence():
+            pl.synchronize()
+            torch.cuda.synchronize()
+
+        for _ in range(120):
+            step()
+        fence()
+        sg.timed = []
+        pl.set_timing(True, only="dp_sweep")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        el = time.perf_counter() - t0
+        sweep_ms = pl.kernel_ms("dp_sweep")
+        pl.set_timing(False)
+        sg.drain()
+        gms = sg.gather_ms()
+        for _ in range(8):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(False)
+        fence()
+        nog = time.perf_counter() - t0
+        pl.set_timing(True, only="pack_records")
+        for _ in range(4):
+            step()
+        fence()
+        pack_ms = pl.kernel_ms("pack_records")
+        pl.set_timing(False)
+        sg.drain()
+        pl.set_pipeline(0)
+        complete = bool(sg.unpack(out)["status"].shape[0] == scenes)
+        bytes_dp = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * scenes
+        return {"workload": f"{scenes} scenes on ONE GPU through the N > 1 per-step code: staged cycle, {records} records packed on the "
+                            "result stream, gather to rank 0 on its own stream (identity: one process)",
+                "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "ms_per_step_without_pack_and_gather": round(nog / steps * 1e3, 4),
+                "all_scenes_cycles_per_s": round(scenes * steps / el, 1),
+                "sweep_mean_launch_us": round(sweep_ms * 1e3, 2), "sweep_frac": round(bytes_dp / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pack_kernel_us": (round(pack_ms * 1e3, 2) if pack_ms >= 0 else None),
+                "gather_us_on_its_stream": (round(gms[0] * 1e3, 2) if gms else None),
+                "doubles_per_scene": sg.width, "bytes_sent_per_rank_and_step": sg.bytes_per_rank_and_step(scenes),
+                "rank0_ingest_at_8_ranks": {"bytes_per_step": 7 * sg.bytes_per_rank_and_step(scenes),
+                                            "per_xgmi_link_gbs": round(sg.bytes_per_rank_and_step(scenes) / (el / steps) / 1e9, 1),
+                                            "note": "each peer reaches rank 0 over its own point-to-point xGMI link (~153 GB/s): the grouped "
+                                                    "send / recv form of torch's gather uses the seven links side by side (DESIGN 7)"},
+                "records_complete": complete, "no_scaling_curve_exists": "no 2/4/8-GPU node in any round (SCALE_r0x.json: skipped)",
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        try:
+            pl.set_timing(False)
+            pl.set_pipeline(0)
+        except Exception:
+            pass
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
+#: cycles a wave64 FP64 vector instruction holds a SIMD's vector pipe, measured (tools/fp64_pipe_bench.hip, four wavefronts per
+#: SIMD: v_fma_f64 / v_add_f64 / v_mul_f64 / v_min_f64 4.31; the SQ counters charge an active VALU instruction 4) and the engine
+#: clock the capacity is priced at (MI355X_MICROARCH.md; the sweep's in-kernel clock probe read 2.41-2.42 GHz in the step)
+FP64_PIPE_CYCLES, SQ_CHARGED_CYCLES, ENGINE_CLOCK_HZ, SIMDS = 4.31, 4.0, 2.4e9, 1024
+
+
+def roofline_step(cfg, count, scene_dist, ms_per_step):
+    """The whole step against the chip's vector-issue capacity (the path is FP64-issue bound everywhere but in the sweep): the
+    VALU-busy quad-cycles of the step's six kernels, from the committed SQ counter pass of this workload (kernels run one at a
+    time there: what they NEED, whatever overlaps what in the step), over what 1024 SIMDs offer in ms_per_step."""
+    prof = committed_profile("step_valu_counters", config=cfg.name, scenes_per_gpu=count, scene_dist=scene_dist)
+    if not prof:
+        return None
+    busy = sum(k["valu_busy_quad_cycles"] for k in prof["kernels"].values())
+    capacity = SIMDS * ENGINE_CLOCK_HZ / 4.0 * ms_per_step * 1e-3
+    frac = busy / capacity
+    return {"bound": "fp64_valu_issue", "unit": "fraction of the step's VALU issue capacity (1024 SIMDs) its kernels keep busy",
+            "frac": round(frac, 4), "frac_with_the_measured_fp64_pipe_cost": round(frac * FP64_PIPE_CYCLES / SQ_CHARGED_CYCLES, 4),
+            "valu_busy_quad_cycles_per_step": int(busy), "capacity_quad_cycles_per_step": int(capacity),
+            "per_kernel_valu_busy_quad_cycles": {n: int(k["valu_busy_quad_cycles"]) for n, k in prof["kernels"].items()},
+            "per_kernel_active_lane_frac": {n: k.get("lanes_active_frac") for n, k in prof["kernels"].items()},
+            "engine_clock_hz": ENGINE_CLOCK_HZ, "fp64_pipe_cycles_per_wave_instruction": FP64_PIPE_CYCLES,
+            "counters_source": prof["source"],
+            "note": "SQ_ACTIVE_INST_VALU charges 4 cycles per wave64 vector instruction; an FP64 one holds the pipe 4.31 (v_rcp_f64: "
+                    "16.2), measured by tools/fp64_pipe_bench.hip - the second figure scales by that.  What is left is ordering: the "
+                    "front queue's kernels wait for each other (projection -> edge costs -> sweep), the path QP is one wavefront "
+                    "per two SIMDs and as long as its slowest scene"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +560,11 @@ def main():
     ap.add_argument("--config", choices=["cfg2", "cfg5"], default="cfg2", help="cfg2 = BASELINE configs[2]/[3] (default); cfg5 = configs[4]")
     ap.add_argument("--scenes-per-gpu", type=int, default=0, help="default 4096")
     ap.add_argument("--scene-dist", choices=["corridor", "survey", "worst"], default="corridor")
+    ap.add_argument("--start-ahead", type=float, default=2.7,
+                    help="planning start, metres ahead of the ego (scenes.BENCH_START_AHEAD = 2.7: off the reference-line nodes; 2.0 "
+                         "puts it ON node 6 in three scenes of four - the batch rounds 1-4 benchmarked)")
+    ap.add_argument("--arcs", choices=["gentle", "survey"], default="gentle",
+                    help="arc radii of the reference lines: gentle = U(1500, 6000) m (default), survey = SURVEY 8(d)'s U(150, 1000) m")
     ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
     ap.add_argument("--dp-mode", choices=["two_kernel", "fused"], default="two_kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -354,10 +589,11 @@ def main():
                     help="emp_set_option before the pipeline is set up (include/emplanner.h emp_option; names: "
                          "emplanner_carla_amd._lib.OPTIONS), e.g. --opt sweep_exclusive=1 --opt back_stream_cus=128; repeatable")
     ap.add_argument("--no-legs", action="store_true",
-                    help="skip the secondary legs of the default run (N = 1, config cfg2, default batch): overlapped_sweep_leg "
-                         "(the same steps with the sweep left to overlap the back stage, --opt sweep_exclusive=0), dram_leg "
-                         "(32768 scenes: the edge tensor streams from HBM), cfg5_leg (BASELINE configs[4], 4096 scenes), "
-                         "latency_leg (configs[1], one scene per call)")
+                    help="skip the secondary legs of the default run (N = 1, config cfg2, default batch): exclusive_sweep_leg "
+                         "(the same steps with the sweep held back behind the previous batch's path QP, --opt sweep_exclusive=2), "
+                         "dram_leg (32768 scenes: the edge tensor streams from HBM), cfg5_leg (BASELINE configs[4], 4096 scenes), "
+                         "latency_leg (configs[1], one scene per call), survey_leg / tight_corridor_leg (SURVEY 8(d)'s arc radii), "
+                         "host_io_leg (NumPy in and out, PCIe included), gather_path_leg (the N > 1 per-step code on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=48)
     ap.add_argument("--cpu-pool", type=int, default=-1, help="processes of the multi-core CPU baseline (0 = skip, "
                     "-1 = the cores this process may use - affinity and cgroup quota - up to 64)")
@@ -399,7 +635,8 @@ def main():
     B = args.scenes_per_gpu or 4096
     total = B * world
     start, count = emp_dist.shard_range(total, rank, world)
-    batch = S.make_batch(range(start, start + count), cfg, dist=args.scene_dist)
+    scene_kw = scene_kwargs(args)
+    batch = S.make_batch(range(start, start + count), cfg, **scene_kw)
     P = batch.ref.shape[1]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(count, P, np.int32)), origin_xy=t(batch.origin_xy),
@@ -545,6 +782,7 @@ def main():
         a_sweep = pl.kernel_ms("dp_sweep")
         alt = {"pipeline": "off" if amode == 0 else "staged" if amode == 1 else f"{amode} lanes", "batches_in_flight": pl.in_flight,
                "all_scenes_cycles_per_s": round(total * args.steps / a_el, 1), "unit": "planning cycles/s",
+               "value": round(total * args.steps / a_el, 1),
                "ms_per_step": round(a_el / args.steps * 1e3, 4), "sweep_mean_launch_us": round(a_sweep * 1e3, 2)}
         pl.set_timing(False)
     # Per-kernel breakdown: a separate diagnostic pass AFTER the timed region, every kernel bracketed, one batch in
@@ -571,13 +809,14 @@ def main():
     legs = {}
     if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096)
             and args.dp_mode == "two_kernel" and pmode == 1 and args.scene_dist == "corridor"):
-        # (a) the headline's steps with the sweep free to overlap the previous batch's back stage (rounds 1-3)
+        # (a) the headline's steps with the sweep held back behind the previous batch's densification and path QP: the sweep's
+        # bandwidth at its best (the library's default until round 4), the step ~6 % slower
         if "sweep_exclusive" not in options:
             try:
                 fence()
                 pl.set_timing(False)
                 old_excl = pl.get_option("sweep_exclusive")
-                pl.set_option("sweep_exclusive", 0)
+                pl.set_option("sweep_exclusive", 2)
                 pl.set_pipeline(1)
                 for _ in range(60):
                     step()
@@ -593,18 +832,25 @@ def main():
                 pl.set_option("sweep_exclusive", old_excl)
                 pl.set_pipeline(0)
                 o_bytes = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * count
-                legs["overlapped_sweep_leg"] = {
-                    "options": {"sweep_exclusive": 0}, "steps": args.steps, "ms_per_step": round(o_el / args.steps * 1e3, 4),
+                legs["exclusive_sweep_leg"] = {
+                    "options": {"sweep_exclusive": 2}, "steps": args.steps, "ms_per_step": round(o_el / args.steps * 1e3, 4),
                     "all_scenes_cycles_per_s": round(total * args.steps / o_el, 1),
                     "sweep_mean_launch_us": round(o_sweep * 1e3, 2),
                     "sweep_frac": round(o_bytes / (o_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "note": "the sweep of step k is not held back and overlaps the densification and path QP of step k-1 (the "
-                            "pipeline of rounds 1-3): a faster step, a slower sweep"}
+                    "note": "the sweep of step k waits (stream-side) for the densification and path QP of step k-1 and overlaps only the "
+                            "Cartesian tail: the HBM-bound kernel at its best, for two more barrier packets on the front queue"}
             except Exception as exc:
-                legs["overlapped_sweep_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
-        legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device)
-        legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, speed=True)
-        legs["latency_leg"] = latency_leg(pl, torch, device)
+                legs["exclusive_sweep_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
+        legs["gather_path_leg"] = gather_path_leg(pl, torch, emp_dist, S.CFG2, 4096, max(args.steps, 20), device, scene_kw)
+        legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device, scene_kw)
+        legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, scene_kw, speed=True)
+        legs["latency_leg"] = latency_leg(pl, torch, device, scene_kw=scene_kw)
+        # SURVEY 8(d)'s own geometry: arcs of radius 150-1000 m, with its slalom layout (the reference refuses nearly every
+        # scene there: status paths) and with the corridor layout (mostly plannable)
+        tight = dict(scene_kw, radius_range=S.SURVEY_ARCS)
+        legs["survey_leg"] = secondary_leg(pl, torch, S.CFG2, 4096, 10, 20, device, dict(tight, dist="survey"))
+        legs["tight_corridor_leg"] = secondary_leg(pl, torch, S.CFG2, 4096, 10, 20, device, dict(tight, dist="corridor"))
+        legs["host_io_leg"] = host_io_leg(pl, torch, S.CFG2, 4096, 60, scene_kw)
 
     # outcome statistics of the last step (sanity: the work was really done); every rank looks at its own shard and the
     # fractions are averaged over the ranks
@@ -654,10 +900,11 @@ def main():
             # carried work, busy x active lanes (null without a profile).  SURVEY 8(d)'s ALGORITHMIC flop count over the
             # duration reads 1.0 and more of the vector peak, because obstacles out of reach are skipped at run time: it stays
             # as a secondary key, it is not a roofline.
-            e = {"kernel": "dp_edge_kernel", "bound": "fp64_valu_issue", "frac": None, "unit": "fraction of the FP64 issue slots doing work",
+            e = {"kernel": "dp_edge_ring_kernel" if pl.get_option("edge_form") == 0 else "dp_edge_kernel", "bound": "fp64_valu_issue", "frac": None, "unit": "fraction of the FP64 issue slots doing work",
                  "mean_launch_us": round(kernels["dp_edge"] * 1e3, 2), "source": "diagnostic pass after the timed region",
-                 "algorithmic_tflops": round(tf, 2), "algorithmic_tflops_over_vector_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-                 "algorithmic_flops_per_launch": flops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
+                 "survey_8d_flop_count_per_launch": flops, "survey_8d_flop_count_over_duration_tflops": round(tf, 2),
+                 "survey_8d_flop_count_note": "SURVEY 8(d)'s count prices every (edge, obstacle) pair; the kernel skips pairs out of reach "
+                                              "exactly, so this is not a rate the vector pipe sustained and never a fraction of its peak"}
             if cprof:
                 busy = cprof.get("valu_issue_busy_frac")
                 if busy is None:            # round-2 entries: quad-cycles against the 2.4 GHz peak clock and this run's duration
@@ -683,11 +930,10 @@ def main():
             # algorithmic count reads MORE than the vector peak because the kernel prunes most of what it prices - a
             # secondary key, never a fraction of anything
             e = {"kernel": "speed_dp_kernel", "bound": "fp64_valu_issue", "frac": None,
-                 "unit": "fraction of the FP64 issue slots doing work", "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                 "algorithmic_tflops": round(tf, 2), "algorithmic_tflops_over_vector_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
-                 "algorithmic_note": "SURVEY 8(d)'s flop count with all 16 obstacle slots present; the kernel skips the 92 % of "
-                                     "(sample, obstacle) pairs out of reach, so this is not a roofline",
-                 "algorithmic_flops_per_launch": flops,
+                 "unit": "fraction of the FP64 issue slots doing work",
+                 "survey_8d_flop_count_per_launch": flops, "survey_8d_flop_count_over_duration_tflops": round(tf, 2),
+                 "survey_8d_flop_count_note": "SURVEY 8(d)'s flop count with all 16 obstacle slots present; the kernel skips the 92 % of "
+                                              "(sample, obstacle) pairs out of reach, so this is not a roofline",
                  "mean_launch_us": round(kernels["speed_dp"] * 1e3, 1), "speed_dps_per_s": round(count / (kernels["speed_dp"] * 1e-3), 1),
                  "edges_per_dp": e_st, "hbm_bytes_per_scene": 16 * 4 * 8 + 8 + 2 * 16 * 8 + 8,
                  "source": "diagnostic pass after the timed region (one batch in flight); tables stay in LDS (emp_st_kernels.h)"}
@@ -714,6 +960,9 @@ def main():
                            "it and are not counted, although they cost the same time: all_scenes_cycles_per_s = scenes per "
                            "step / ms_per_step is the rate at which scenes go through the pipeline",
             "value": round(value, 1),
+            "value_definition": "fully_planned_cycles_per_s (since round 4; rounds 1-3 reported all_scenes_cycles_per_s as value: "
+                                "compare rounds on all_scenes_cycles_per_s)",
+            "fully_planned_cycles_per_s": round(value, 1),
             "all_scenes_cycles_per_s": round(all_scenes_rate, 1),
             "unit": "planning cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "rccl_world_size": (dist.get_world_size() if world > 1 else None),     # what the process group itself reports
@@ -727,15 +976,17 @@ def main():
                                    + ", inputs resident in HBM" + gather_note,
                        "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
-                       "scene_dist": args.scene_dist, "ref_line_points": int(P), "dp_mode": args.dp_mode,
+                       "scene_dist": args.scene_dist, "start_ahead_m": args.start_ahead, "arc_radii_m": list(scene_kw["radius_range"]),
+                       "ref_line_points": int(P), "dp_mode": args.dp_mode,
                        "batches_in_flight": in_flight, "pipeline": "off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes",
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
+            "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3) if pmode == 1 else None),
             **extra,
             "kernels_ms": kernels,
             "alt_pipeline": alt,
             "scenes_fully_planned_frac": round(ok_frac, 4),
-            "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "edge_after_enrich", "enrich_on_front", "path_qp_form")}, **options},
+            "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "edge_after_enrich", "enrich_on_front", "path_qp_form", "edge_form")}, **options},
             **legs,
         }
         if gather_path:
@@ -748,11 +999,11 @@ def main():
             line["gather"] = {"mode": "none", "note": "no pack, no gather: compute scaling only",
                               "world_size_seen_by_the_process_group": (dist.get_world_size() if world > 1 else 1)}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample if not wide else 2, 0, args.scene_dist)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample if not wide else 2, 0, scene_kw)
             workers = usable_cores(64) if args.cpu_pool < 0 else args.cpu_pool
             if workers > 0 and not wide:
                 try:
-                    line["cpu_baseline_pool"] = cpu_baseline_pool("CFG2", workers, args.cpu_pool_scenes)
+                    line["cpu_baseline_pool"] = cpu_baseline_pool("CFG2", workers, args.cpu_pool_scenes, scene_kw)
                 except Exception as exc:                                       # informational: never fails the bench
                     line["cpu_baseline_pool"] = {"error": f"{type(exc).__name__}: {exc}"}
         else:

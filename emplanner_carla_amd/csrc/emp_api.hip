@@ -553,9 +553,14 @@ int emp_pack_records(emp_ctx* ctx, int32_t B, int32_t col, int32_t max_pts, int3
     if ((rc = st.out(rec, (size_t)B * width, &d_rec, false))) return rc;
     if (B) {
         const size_t total = (size_t)B * width;
-        hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           on_rs ? ctx->result_stream() : ctx->stream, B, col, max_pts, path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll,
-                           d_traj, d_rec);
+        hipStream_t target = on_rs ? ctx->result_stream() : ctx->stream, saved = ctx->stream;
+        ctx->stream = target;                                  // (the timer's events belong on the stream that carries the launch)
+        {
+            KernelTimer t(ctx, "pack_records");
+            hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, target, B, col, max_pts,
+                               path_cap, d_st, d_tl, d_pl, d_rows, d_ps, d_pll, d_traj, d_rec);
+        }
+        ctx->stream = saved;
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();
@@ -594,8 +599,14 @@ int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_
     if ((rc = st.out(rec, (size_t)B * width, &d_rec, false))) return rc;      // every slot is written by the kernel
     if (B) {
         const size_t total = (size_t)B * width;
-        hipLaunchKernelGGL(pack_trajectory_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           on_rs ? ctx->result_stream() : ctx->stream, B, max_pts, path_cap, d_st, d_tl, d_traj, d_rec);
+        hipStream_t target = on_rs ? ctx->result_stream() : ctx->stream, saved = ctx->stream;
+        ctx->stream = target;
+        {
+            KernelTimer t(ctx, "pack_records");
+            hipLaunchKernelGGL(pack_trajectory_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, target, B, max_pts,
+                               path_cap, d_st, d_tl, d_traj, d_rec);
+        }
+        ctx->stream = saved;
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();

@@ -26,6 +26,9 @@
 #ifndef EMP_PRIO_BACK
 #define EMP_PRIO_BACK 3      // path QP, Cartesian tail
 #endif
+#ifndef EMP_PRIO_CART
+#define EMP_PRIO_CART EMP_PRIO_BACK   // Cartesian tail (what the sweep of the next batch runs beside)
+#endif
 #ifndef EMP_PRIO_FRONT
 #define EMP_PRIO_FRONT 0     // projection, edge costs
 #endif

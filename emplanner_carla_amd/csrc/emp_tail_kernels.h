@@ -771,7 +771,7 @@ __device__ __forceinline__ void cycle_cartesian_body(
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
     double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);          // as in the path QP kernel
+    __builtin_amdgcn_s_setprio(EMP_PRIO_CART);          // as in the path QP kernel
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     double* sm = lds;                       // [max_ref]
     double* txy = sm + max_ref;             // [cap][2] interleaved x, y
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(64) void cycle_cartesian_rows_kernel(
     const double* __restrict__ path_s, const double* __restrict__ path_l, const int* __restrict__ path_len,
     double* __restrict__ traj, int* __restrict__ traj_len, int* __restrict__ status, int force_fallback) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __builtin_amdgcn_s_setprio(EMP_PRIO_BACK);
+    __builtin_amdgcn_s_setprio(EMP_PRIO_CART);
     constexpr int SL = 2 * GP, SPW = 64 / SL;     // lanes per scene, scenes per wavefront
     const int lane = threadIdx.x & 63, sc = lane / SL, sl = lane & (SL - 1);
     const int b = blockIdx.x * SPW + sc;

@@ -209,13 +209,15 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             4/5: nontemporal / plain loads whatever the tensor's size
  *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
  *   EMP_OPT_ST_ORDER                1        tuning           speed DP: 1 heaviest scenes first, 0 input order (same results)
- *   EMP_OPT_SWEEP_EXCLUSIVE         2        tuning           staged pipeline, what the HBM-bound sweep of call k may run beside:
- *                                                             2 (default) = it waits (stream-side) for call k-1's densification
- *                                                             and path QP and overlaps only the tail of its Cartesian kernel -
- *                                                             the sweep then streams as fast as alone (0.70 of the HBM peak at
- *                                                             4096 scenes instead of 0.60-0.65) for ~6 % of the step;
- *                                                             1 = it waits for the whole back stage of call k-1 (+11 %);
- *                                                             0 = no wait, rounds 1-3 (the fastest step)
+ *   EMP_OPT_SWEEP_EXCLUSIVE         0        tuning           staged pipeline, what the HBM-bound sweep of call k may run beside:
+ *                                                             0 (default since round 5) = no wait: the fastest step.  With the
+ *                                                             work-ring edge kernel the sweep of call k starts after call k-1's
+ *                                                             path QP by itself and overlaps its Cartesian tail: 0.66-0.67 of
+ *                                                             the HBM peak at 4096 scenes, 0.227 ms per step;
+ *                                                             2 = it waits (stream-side) for call k-1's densification and
+ *                                                             path QP: 0.70-0.72 at +6 % step time (0.241 ms) - the two
+ *                                                             barrier packets, not any waiting, are what the 6 % buy;
+ *                                                             1 = it waits for the whole back stage of call k-1 (0.259 ms)
  *   EMP_OPT_EDGE_AFTER_ENRICH       1        tuning           staged pipeline: 1 (default) = the edge-cost kernel of call k waits
  *                                                             (stream-side) for the densification kernel of call k-1, so that
  *                                                             the path QP behind it is dispatched BEFORE the edge kernel's

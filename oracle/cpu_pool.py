@@ -18,15 +18,16 @@ def warm(_):
 
 
 def plan_seeds(job):
-    """job = (lattice config name, seeds) -> (scenes done, seconds)."""
-    cfg_name, seeds = job
+    """job = (lattice config name, seeds[, scenes.make_scene options]) -> (scenes done, seconds)."""
+    cfg_name, seeds = job[0], job[1]
+    scene_kw = job[2] if len(job) > 2 else {}
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
     cfg = getattr(S, cfg_name)
     kw = dict(sampling_res=cfg.sampling_res, row=cfg.row, col=cfg.col, sample_s=cfg.sample_s, sample_l=cfg.sample_l)
     t0 = time.perf_counter()
     for sd in seeds:
-        sc = S.make_scene(int(sd), cfg)
+        sc = S.make_scene(int(sd), cfg, **scene_kw)
         try:
             with contextlib.redirect_stdout(io.StringIO()):
                 op.plan_cycle([tuple(r) for r in sc.ref], sc.origin_xy, sc.start_xy, sc.start_v, sc.start_a, sc.obs_xy,

@@ -235,6 +235,45 @@ def test_step_loop_of_the_many_scene_mode_world_size_2_gloo(total, fields, dst):
             assert set(u) == {"status", "traj_len", "traj"}
 
 
+def _worker_steps_big(rank, world, port, total, q):
+    """One rank of the 8-rank step loop: a few steps on its ragged shard of `total` scenes; rank 0 reports a digest of
+    what it gathered (the whole matrix is 4099 x 63 doubles - small enough to send, but only rank 0 has it)."""
+    import torch.distributed as dist
+    from emplanner_carla_amd.dist import StepGather, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    col, M = 6, 9
+    start, count = shard_range(total, rank, world)
+    stub = _StubPlanner(col, M)
+    sg = StepGather(col, M, total, planner=None, fields="full", dst=0, depth=2)
+    last = None
+    for step in range(4):
+        last = sg.submit(stub.plan_cycle(list(range(start, start + count)), step))
+    sg.drain()
+    q.put((rank, None if last is None else last.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_step_loop_world_size_8_ragged_shards_gather_to_rank_0():
+    """The 8-GPU shape of BASELINE configs[3] on CPU (gloo): eight ranks, 4099 scenes (ragged: three ranks hold 513, five
+    512), the whole per-step loop (pack -> gather to rank 0 -> in-flight ring) for four steps.  Rank 0's matrix must equal
+    the ONE-PROCESS result - the records of all 4099 scenes of the last step, in scene order - and no other rank receives
+    anything.  (No 2/4/8-GPU node has been available in any round: this and the shard == slice GPU tests are what stands
+    in for the scaling run; README says so.)"""
+    import torch.multiprocessing as mp
+    from emplanner_carla_amd.dist import pack_records, path_capacity, shard_range
+    ctx = mp.get_context("spawn")
+    port, total, world = _free_port(), 4099, 8
+    assert sorted(shard_range(total, r, world)[1] for r in range(world)) == [512] * 5 + [513] * 3
+    got = _run_ranks(ctx, _worker_steps_big, lambda r: (r, world, port, total), world=world)
+    col, M = 6, 9
+    want = pack_records(_StubPlanner(col, M).plan_cycle(list(range(total)), 3), col, M, path_cap=path_capacity(M)).numpy()
+    assert got[0].shape == want.shape and np.array_equal(got[0], want)
+    assert all(got[r] is None for r in range(1, world))
+
+
 def test_pack_unpack_records_roundtrip():
     import torch
     from emplanner_carla_amd.api import CycleResult

@@ -77,13 +77,32 @@ def test_other_bench_lines(extra, metric_part):
 
 
 def test_default_run_carries_the_secondary_legs():
-    """The driver's one command (no flags beyond steps / warm-up) also observes the other workloads: the rounds 1-3 pipeline
-    with the sweep overlapping the back stage, 32768 scenes (edge tensor from HBM), BASELINE configs[4] on 4096 scenes and
-    configs[1] - each a short leg behind the headline, none of which may fail or change the headline's keys."""
+    """The driver's one command (no flags beyond steps / warm-up) also observes the other workloads: the sweep held back behind
+    the previous batch's path QP, 32768 scenes (edge tensor from HBM), BASELINE configs[4] on 4096 scenes, configs[1], SURVEY
+    8(d)'s arc radii with both obstacle layouts, the host path (NumPy in and out) and the N > 1 per-step code - each a short
+    leg behind the headline, none of which may fail or change the headline's keys."""
     d = _run("--legs")
-    assert d["options"]["sweep_exclusive"] == 2
-    o = d["overlapped_sweep_leg"]
-    assert "error" not in o and o["options"] == {"sweep_exclusive": 0} and o["all_scenes_cycles_per_s"] > 1e6 and 0.3 < o["sweep_frac"] < 1.0
+    assert d["options"]["sweep_exclusive"] == 0 and d["options"]["edge_form"] == 0          # the library's defaults: the fastest step
+    assert d["value_definition"].startswith("fully_planned") and d["fully_planned_cycles_per_s"] == d["value"]
+    assert d["config"]["start_ahead_m"] == 2.7 and d["config"]["arc_radii_m"] == [1500.0, 6000.0]
+    o = d["exclusive_sweep_leg"]
+    assert "error" not in o and o["options"] == {"sweep_exclusive": 2} and o["all_scenes_cycles_per_s"] > 1e6 and 0.3 < o["sweep_frac"] < 1.0
+    # SURVEY 8(d)'s own geometry, with its slalom layout (the reference refuses nearly everything) and with the corridor layout
+    sv, tc = d["survey_leg"], d["tight_corridor_leg"]
+    assert "error" not in sv and "error" not in tc, (sv, tc)
+    assert sv["scenes"]["radius_range"] == [150.0, 1000.0] and sv["scenes"]["dist"] == "survey" and tc["scenes"]["dist"] == "corridor"
+    assert sv["all_scenes_cycles_per_s"] > 1e6 and 0.0 < sv["scenes_fully_planned_frac"] < 0.5 < tc["scenes_fully_planned_frac"] < 0.95
+    # the host path: NumPy in and out through the page-locked ring beats the synchronous pageable path, with the same results
+    h = d["host_io_leg"]
+    assert "error" not in h, h
+    assert h["ring_outputs_equal_the_synchronous_path"] is True and h["bytes_in_per_step"] > 8e6 and h["bytes_out_per_step"] > 1e7
+    assert h["host_ring"]["all_scenes_cycles_per_s"] > 1.2 * h["synchronous_pageable_path"]["all_scenes_cycles_per_s"] > 1e6
+    assert 0.05 < h["one_scene_host_latency_ms"] < 5.0
+    # the N > 1 per-step code on this one GPU
+    gp = d["gather_path_leg"]
+    assert "error" not in gp, gp
+    assert gp["records_complete"] is True and gp["doubles_per_scene"] == 179 and gp["bytes_sent_per_rank_and_step"] == 4096 * 179 * 8
+    assert gp["ms_per_step"] > 0 and gp["ms_per_step_without_pack_and_gather"] > 0 and gp["pack_kernel_us"] > 0 and 0.1 < gp["sweep_frac"] < 1.0
     g = d["dram_leg"]
     assert "error" not in g, g
     assert g["ms_per_step"] > 4 * d["ms_per_step"] and 0.4 < g["sweep"]["frac"] < 1.0 and g["sweep"]["algorithmic_bytes_per_launch"] == 26944 * 32768

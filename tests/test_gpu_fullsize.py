@@ -769,7 +769,9 @@ def test_measurement_entry_points_of_the_sweep(planner):
         mhz, mean_us, max_us = planner.sweep_clock()
         assert 1000.0 < mhz < 3000.0 and 0.0 < mean_us <= max_us
         spread_us, span_us = planner.sweep_probe_spans()
-        assert 0.0 <= spread_us < span_us and max_us <= span_us + 1e-9
+        # (max_us is the longest-lived wavefront of ANY of the eight launches, span_us the launches' MEAN first-start-to-last-end
+        # span: with the sweep free to overlap the previous batch's Cartesian tail - the default since round 5 - launches differ)
+        assert 0.0 <= spread_us < span_us and max_us <= span_us * 1.5 + 1e-9
         assert span_us < float(smp.mean()) * 1e3 * 1.5 + 5.0          # the wavefronts live inside the launch
         _assert_same(plain, {k: getattr(res[-1], k).cpu().numpy() for k in OUTPUTS}, "staged call with the clock probe on")
     finally:

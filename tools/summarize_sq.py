@@ -45,8 +45,23 @@ if record:
     tag, config, scenes, scene_dist = record
     dst = os.path.join(_counters.ROOT, "profiles", f"{tag}_sq.csv")
     shutil.copy(os.path.join(root, "summary.csv"), dst)
+    STEP = {"frenet_project_wave_kernel": "project", "dp_edge": "dp_edge", "dp_sweep_kernel": "dp_sweep", "dp_enrich_wave_kernel": "dp_enrich",
+            "cycle_qp_rows_kernel": "path_qp", "cycle_cartesian_rows_kernel": "to_cartesian"}
+    kernels = {}
     for k in sorted(agg):
-        if k.startswith("dp_edge_kernel"):
+        for prefix, name in STEP.items():
+            if k.startswith(prefix) and "wide" not in k:
+                v = {c: sum(x) / len(x) for c, x in agg[k].items()}
+                kernels[name] = {"kernel": k.split("<")[0], "insts_valu": int(v["SQ_INSTS_VALU"]), "valu_busy_quad_cycles": int(v["SQ_ACTIVE_INST_VALU"]),
+                                 "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4),
+                                 "mean_us_under_pmc": round(sum(dur[k]) / len(dur[k]), 1) if dur.get(k) else None}
+    if len(kernels) == 6:      # the whole planning cycle was in the pass: what bench.py's roofline_step adds up
+        _counters.upsert("step_valu_counters", {
+            "config": config, "scenes_per_gpu": int(scenes), "scene_dist": scene_dist, "kernels": kernels,
+            "source": f"profiles/{tag}_sq.csv (rocprofv3 --pmc SQ passes of bench.py --no-pipeline, tools/pmc_sq.sh: every kernel alone)"},
+            ("config", "scenes_per_gpu", "scene_dist"))
+    for k in sorted(agg):
+        if k.startswith("dp_edge_kernel") or k.startswith("dp_edge_ring_kernel"):
             v = {c: sum(x) / len(x) for c, x in agg[k].items()}
             _counters.upsert("dp_edge_counters", {
                 "config": config, "scenes_per_gpu": int(scenes), "scene_dist": scene_dist,
