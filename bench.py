@@ -529,23 +529,32 @@ def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=No
 FP64_PIPE_CYCLES, SQ_CHARGED_CYCLES, ENGINE_CLOCK_HZ, SIMDS = 4.31, 4.0, 2.4e9, 1024
 
 
-def roofline_step(cfg, count, scene_dist, ms_per_step):
+def roofline_step(cfg, count, scene_dist, ms_per_step, speed=False):
     """The whole step against the chip's vector-issue capacity (the path is FP64-issue bound everywhere but in the sweep): the
     VALU-busy quad-cycles of the step's six kernels, from the committed SQ counter pass of this workload (kernels run one at a
     time there: what they NEED, whatever overlaps what in the step), over what 1024 SIMDs offer in ms_per_step."""
     prof = committed_profile("step_valu_counters", config=cfg.name, scenes_per_gpu=count, scene_dist=scene_dist)
     if not prof:
         return None
-    busy = sum(k["valu_busy_quad_cycles"] for k in prof["kernels"].values())
+    per_kernel = {n: int(k["valu_busy_quad_cycles"]) for n, k in prof["kernels"].items()}
+    lanes = {n: k.get("lanes_active_frac") for n, k in prof["kernels"].items()}
+    sources = [prof["source"]]
+    if speed:          # configs[4]: the S-T speed DP of the same scenes belongs to the step (its own committed counter pass)
+        sp_prof = committed_profile("speed_dp_counters", scenes_per_gpu=count, obstacle_slots=16)
+        if not sp_prof:
+            return None
+        per_kernel["speed_dp"] = int(sp_prof["valu_busy_quad_cycles"])
+        lanes["speed_dp"] = sp_prof.get("lanes_active_frac")
+        sources.append(sp_prof["source"])
+    busy = sum(per_kernel.values())
     capacity = SIMDS * ENGINE_CLOCK_HZ / 4.0 * ms_per_step * 1e-3
     frac = busy / capacity
     return {"bound": "fp64_valu_issue", "unit": "fraction of the step's VALU issue capacity (1024 SIMDs) its kernels keep busy",
             "frac": round(frac, 4), "frac_with_the_measured_fp64_pipe_cost": round(frac * FP64_PIPE_CYCLES / SQ_CHARGED_CYCLES, 4),
             "valu_busy_quad_cycles_per_step": int(busy), "capacity_quad_cycles_per_step": int(capacity),
-            "per_kernel_valu_busy_quad_cycles": {n: int(k["valu_busy_quad_cycles"]) for n, k in prof["kernels"].items()},
-            "per_kernel_active_lane_frac": {n: k.get("lanes_active_frac") for n, k in prof["kernels"].items()},
+            "per_kernel_valu_busy_quad_cycles": per_kernel, "per_kernel_active_lane_frac": lanes,
             "engine_clock_hz": ENGINE_CLOCK_HZ, "fp64_pipe_cycles_per_wave_instruction": FP64_PIPE_CYCLES,
-            "counters_source": prof["source"],
+            "counters_source": "; ".join(sources),
             "note": "SQ_ACTIVE_INST_VALU charges 4 cycles per wave64 vector instruction; an FP64 one holds the pipe 4.31 (v_rcp_f64: "
                     "16.2), measured by tools/fp64_pipe_bench.hip - the second figure scales by that.  What is left is ordering: the "
                     "front queue's kernels wait for each other (projection -> edge costs -> sweep), the path QP is one wavefront "
@@ -981,7 +990,7 @@ def main():
                        "batches_in_flight": in_flight, "pipeline": "off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes",
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
-            "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3) if pmode == 1 else None),
+            "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3, speed=wide) if pmode == 1 else None),
             **extra,
             "kernels_ms": kernels,
             "alt_pipeline": alt,

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "emp_host_free": (C.c_int, [_vp, _vp]),
     "emp_wait_cycle": (C.c_int, [_vp, _i32]),
     "emp_cycle_ticket": (_u64, [_vp]),
+    "emp_wait_ticket": (C.c_int, [_vp, _u64]),
     "emp_device_alloc": (C.c_int, [_vp, _u64, C.POINTER(_vp)]),
     "emp_device_free": (C.c_int, [_vp, _vp]),
     "emp_copy_to_device": (C.c_int, [_vp, _vp, _vp, _u64]),

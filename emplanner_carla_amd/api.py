@@ -289,9 +289,9 @@ class HostRing:
             if self._ticket is None:
                 return self
             pl = self.ring.planner
-            back = int(pl._lib.emp_cycle_ticket(pl._h)) - self._ticket
-            if 0 <= back < self.ring.depth_seen():          # beyond: the call that took its pool over has waited for it
-                pl.wait_cycle(back)
+            rc = pl._lib.emp_wait_ticket(pl._h, int(self._ticket))      # thread-safe beside a call in progress (emplanner.h)
+            if rc != 0:
+                raise EmpError(f"emp_wait_ticket failed ({rc})")
             self._ticket = None
             return self
 

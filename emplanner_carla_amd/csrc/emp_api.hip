@@ -1384,6 +1384,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
             c->lane = (c->lane + 1) % c->lanes_in_use();
             ++c->cycle_calls;
             ln = &c->lanes[c->lane];
+            ln->ticket = c->cycle_calls;
             std::swap(c->pool, ln->pool);
             if (mode != EMP_PIPELINE_STAGED) {
                 c->active_lane = c->lane;
@@ -1597,6 +1598,20 @@ int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back) {
     EMP_REQUIRE(ctx, calls_back >= 0 && calls_back < n, "calls_back beyond the pipeline depth");
     emp_ctx::Lane& ln = ctx->lanes[((ctx->lane - calls_back) % n + n) % n];
     if (ln.host_valid) EMP_HIP(ctx, hipEventSynchronize(ln.ev_host));
+    return EMP_OK;
+}
+
+int emp_wait_ticket(emp_ctx* ctx, uint64_t ticket) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    // Touches nothing a concurrent emp_plan_cycle on another thread changes for THIS ticket's lane: the lane's event exists
+    // since the call that got the ticket, and the lane is not reused before four more calls - whose first act is to wait for
+    // the same event.  A ticket that no lane holds any more has therefore been waited for already.
+    for (auto& ln : ctx->lanes)
+        if (ln.ticket == ticket && ln.host_valid && ln.ev_host) {
+            const hipError_t e = hipEventSynchronize(ln.ev_host);
+            if (e != hipSuccess) return EMP_ERR_HIP;       // (no ctx->err write: another thread may be inside a call)
+            break;
+        }
     return EMP_OK;
 }
 

@@ -64,6 +64,7 @@ struct emp_ctx {
         hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr, ev_tail = nullptr;
         hipEvent_t ev_host = nullptr;   // EMP_HOST_PINNED cycles: the lane's latest cycle's outputs have reached the caller's host arrays
         bool host_valid = false;
+        uint64_t ticket = 0;            // emp_cycle_ticket of the lane's latest cycle
         hipEvent_t ev_qp = nullptr;     // STAGED: end of the cycle's path QP on the back stream (EMP_OPT_SWEEP_EXCLUSIVE = 2)
         hipEvent_t ev_enrich = nullptr; // STAGED: end of the cycle's densification kernel on the back stream (EMP_OPT_EDGE_AFTER_ENRICH)
         bool done_valid = false, qp_valid = false, enrich_valid = false;

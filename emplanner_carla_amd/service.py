@@ -83,7 +83,8 @@ class CycleStream:
     def __init__(self, planner: Planner, capacity: int = 256, max_static: int = 8):
         import threading
         self.planner, self.capacity, self.max_static = planner, int(capacity), int(max_static)
-        self._lock = threading.Lock()
+        self._lock = threading.Lock()            # one context: one call at a time
+        self._free = threading.Condition()       # slots are owned from submit() until result() has copied their outputs out
         self._rings = {}
         planner.set_pipeline(1)                                             # staged: two batches in flight
         planner.set_fence(False)                                            # the front end reads nothing of the cycles in flight
@@ -92,21 +93,35 @@ class CycleStream:
         cap = max(self.capacity, 1 << max(B - 1, 0).bit_length())
         key = (int(dp.row), int(dp.col), float(dp.sample_s), float(dp.sampling_res), cap, P, mo)
         if key not in self._rings:
-            self._rings[key] = self.planner.host_ring(dp, cap, P, mo, max_path_points(dp))
+            ring = self.planner.host_ring(dp, cap, P, mo, max_path_points(dp))
+            ring.free = list(ring.slots)
+            self._rings[key] = ring
         return self._rings[key]
+
+    def _take_slot(self, ring):
+        """A slot nobody owns.  Sessions consume their results in any order, so the ring is NOT walked round-robin: a slot goes
+        back to the free list only when its batch's outputs have been copied out (``result``)."""
+        with self._free:
+            while not ring.free:
+                self._free.wait()
+            return ring.free.pop(0)
 
     def submit(self, a, dp=None, qp=None, sp=None):
         dp = dp or dp_params()
         qp = qp or qp_params()
         sp = sp or smooth_params()
         B = len(a["n_global"])
+        slot = None
+        if B:
+            with self._lock:
+                ring = self._ring(dp, B, 51, max(int(a["obs_xy"].shape[1]), self.max_static))
+            slot = self._take_slot(ring)                                    # may wait for another session's result() - outside the lock
         with self._lock:
             pl = self.planner
             ref, n_ref, match, _, st_ref = pl.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
             if B == 0:
-                return dict(B=0, st_ref=st_ref, match=match, M=max_path_points(dp), slot=None)
-            mo = max(int(a["obs_xy"].shape[1]), self.max_static)
-            slot = self._ring(dp, B, int(ref.shape[1]), mo).next()
+                return dict(B=0, st_ref=st_ref, match=match, M=max_path_points(dp), slot=None, ring=None)
+            assert ref.shape[1] == slot.max_ref, "the front end hands over 51-point reference lines (planning_utils.py:244-246)"
             n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
             slot.inputs["obs_xy"][:B] = 0.0
             slot.inputs["obs_xy"][:B, :a["obs_xy"].shape[1]] = a["obs_xy"]
@@ -117,7 +132,7 @@ class CycleStream:
                 pl.plan_cycle(dp, qp, sp, None, None, None, None, None, None, None, None, slot=slot)
             finally:
                 slot.B = cap
-            return dict(B=B, st_ref=st_ref, match=match, M=slot.max_pts, slot=slot)
+            return dict(B=B, st_ref=st_ref, match=match, M=slot.max_pts, slot=slot, ring=ring)
 
     def result(self, h):
         """(reference-line status, match index, CycleResult, max_pts) of a submitted batch, as ``plan_arrays`` returns them."""
@@ -125,9 +140,11 @@ class CycleStream:
         if h["slot"] is None:
             z = np.zeros((0,))
             return h["st_ref"], h["match"], CycleResult(*([z] * 10)), h["M"]
-        with self._lock:
-            h["slot"].wait()
-            out = {k: np.array(v[:h["B"]]) for k, v in h["slot"].outputs.items()}     # the slot goes back to the ring
+        h["slot"].wait()                         # emp_wait_ticket: safe beside another thread's submit - the lock is NOT held
+        out = {k: np.array(v[:h["B"]]) for k, v in h["slot"].outputs.items()}
+        with self._free:                         # only now may another batch take the slot
+            h["ring"].free.append(h["slot"])
+            self._free.notify_all()
         return h["st_ref"], h["match"], CycleResult(**out), h["M"]
 
     def plan_arrays(self, a, dp=None, qp=None, sp=None):

@@ -123,6 +123,10 @@ int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back);
 /* The number of pipelined emp_plan_cycle calls issued on this context so far: the ticket of the latest one.  A caller that keeps
  * the ticket of a call finds it again as calls_back = emp_cycle_ticket() - ticket. */
 uint64_t emp_cycle_ticket(emp_ctx* ctx);
+/* Block until the host outputs of the EMP_HOST_PINNED cycle that got `ticket` are in place; a ticket older than the pipeline
+ * depth has been waited for by the call that took its pool over: EMP_OK at once.  The ONE entry point that may be called from
+ * another thread while a call on this context is in progress (a server thread waits for its batch while another submits). */
+int emp_wait_ticket(emp_ctx* ctx, uint64_t ticket);
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
 int emp_device_free(emp_ctx* ctx, void* ptr);
 int emp_copy_to_device(emp_ctx* ctx, void* dst, const void* src, uint64_t bytes);

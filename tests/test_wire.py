@@ -194,7 +194,7 @@ def test_remote_planning_equals_the_reference_driver_run():
 @pytest.mark.gpu
 def test_overlapped_server_with_concurrent_sessions_equals_the_serial_path():
     """What ``wire.serve`` runs: the server on ``service.CycleStream`` (page-locked rings, staged pipeline, no server-side
-    lock).  Four client sessions fire PLAN frames of different sizes at once, eight rounds each; every reply must be the
+    lock).  Six client sessions - more than the ring has slots - fire PLAN frames of different sizes at once, twelve rounds each; every reply must be the
     reply of the serial path (``service.plan_requests`` on a plain planner), bit for bit, whatever overlapped with it."""
     import threading
     from emplanner_carla_amd import service, wire
@@ -213,8 +213,8 @@ def test_overlapped_server_with_concurrent_sessions_equals_the_serial_path():
     def session(k):
         try:
             cl = wire.PlannerClient(*srv.address, dp=dp, max_static=4, max_dynamic=2)
-            for r in range(8):
-                pick = [(k * 5 + r * 3 + j) % len(reqs) for j in range(3 + 4 * k)]
+            for r in range(12):
+                pick = [(k * 5 + r * 3 + j) % len(reqs) for j in range(3 + 4 * (k % 4))]
                 got = cl.plan([reqs[c] for c in pick])
                 for c, (reply, status) in zip(pick, got):
                     assert status == want[c][1] and reply == want[c][0], f"session {k} round {r} request {c}"
@@ -223,7 +223,7 @@ def test_overlapped_server_with_concurrent_sessions_equals_the_serial_path():
             errors.append(f"session {k}: {type(exc).__name__}: {exc}")
 
     try:
-        threads = [threading.Thread(target=session, args=(k,)) for k in range(4)]
+        threads = [threading.Thread(target=session, args=(k,)) for k in range(6)]
         for t in threads:
             t.start()
         for t in threads:
