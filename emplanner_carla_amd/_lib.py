@@ -42,7 +42,7 @@ EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 # emp_option (include/emplanner.h): per-context tuning / A-B / test-hook values - the library reads no environment variable
 OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
            "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9,
-           "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14}
+           "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15}
 #: the values a fresh context holds (everything else is 0)
 OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1}
 
@@ -133,6 +133,7 @@ PROTOTYPES = {
     "emp_set_option": (C.c_int, [_vp, _i32, _i32]),
     "emp_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
     "emp_sweep_clock_mhz": (_f64, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
+    "emp_edge_probe": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i32)]),
     "emp_sweep_probe_spans": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
@@ -166,6 +167,8 @@ PROTOTYPES = {
     "emp_dy_obs_deri": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_quintic_coefficients": (C.c_int, [_vp, _i32, _vp, _vp, C.c_int]),
     "emp_obs_cost": (C.c_int, [_vp, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
+    "emp_obs_cost_n": (C.c_int, [_vp, _i32, _i32, _f64, _f64, _f64, _vp, _vp, C.c_int]),
+    "emp_free_edge_costs": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f64, C.POINTER(_f64), _f64, _vp, C.c_int]),
     "emp_reference_line": (C.c_int, [_vp, C.POINTER(SmoothParams), _i32, _i32] + [_vp] * 10 + [C.c_int]),
     "emp_mpc_params_default": (None, [C.POINTER(MpcParams)]),
     "emp_mpc_lateral": (C.c_int, [_vp, C.POINTER(MpcParams), _i32, _i32] + [_vp] * 15 + [C.c_int]),

@@ -433,10 +433,9 @@ class Planner:
         self._check(self._lib.emp_set_fence(self._h, 1 if enabled else 0))
 
     def set_option(self, name, value: int):
-        """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` ("path_qp_form",
-        "cartesian_form", "smooth_force_fallback", "edge_block", "sweep_variant", "fused_columns", "st_order",
-        "sweep_exclusive", "back_stream_cus", "sweep_clock_probe", "enrich_on_front", "edge_after_enrich") or the option's number.  Takes effect at the next call
-        ("back_stream_cus": at the next ``set_pipeline``).  The library reads no environment variable."""
+        """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` (the list is appended to this
+        docstring at import) or the option's number.  Takes effect at the next call ("back_stream_cus": at the next
+        ``set_pipeline``).  The library reads no environment variable."""
         key = L.OPTIONS[name] if isinstance(name, str) else int(name)
         self._check(self._lib.emp_set_option(self._h, key, int(value)))
 
@@ -447,11 +446,19 @@ class Planner:
         return int(v.value)
 
     def sweep_clock(self):
-        """With option "sweep_clock_probe" on: (shader clock in MHz, mean and longest wavefront residence in us) of the
-        latest sweep launch, or None when nothing was recorded."""
+        """With option "sweep_clock_probe" on: (shader clock in MHz, mean and longest wavefront residence in us) over the sweep
+        launches recorded since the probe was switched on (the 32 most recent of them), or None when nothing was recorded."""
         mean_us, max_us = C.c_double(0.0), C.c_double(0.0)
         mhz = float(self._lib.emp_sweep_clock_mhz(self._h, C.byref(mean_us), C.byref(max_us)))
         return None if mhz < 0 else (mhz, float(mean_us.value), float(max_us.value))
+
+    def edge_probe(self):
+        """With option "edge_clock_probe" on: (mean wavefront residence us, first start to last end us, mean wavefronts resident
+        at once, wavefronts) of the latest edge-cost launch, or None when nothing was recorded."""
+        a, b, c, n = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
+        if self._lib.emp_edge_probe(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)) != 0:
+            return None
+        return float(a.value), float(b.value), float(c.value), int(n.value)
 
     def sweep_probe_spans(self):
         """With option "sweep_clock_probe" on: (us between the first and the last wavefront START of a sweep launch, us from
@@ -1080,13 +1087,30 @@ class Planner:
         return c
 
     def obs_cost(self, square_d, w_collision, danger_dis=4, safe_dis=6):
-        """ref cal_obs_cost: square_d (n,10) -> cost (n,)."""
+        """ref cal_obs_cost: square_d (n, samples) -> cost (n,); 10 samples per lattice edge in the DP, any count here."""
         a = self._args(square_d)
-        n = int(square_d.shape[0])
+        n, m = int(square_d.shape[0]), int(square_d.shape[1])
         c, cp = a.out((n,), np.float64)
-        self._check(self._lib.emp_obs_cost(self._h, n, float(w_collision), float(danger_dis), float(safe_dis),
-                                           a.inp(square_d, np.float64, (n, 10)), cp, a.where))
+        self._check(self._lib.emp_obs_cost_n(self._h, n, m, float(w_collision), float(danger_dis), float(safe_dis),
+                                             a.inp(square_d, np.float64, (n, m)), cp, a.where))
         return c
+
+    def free_edge_costs(self, edges, obs_s, obs_l, n_obs, w_collision=1e12, w_smooth=(300.0, 1000.0, 5000.0), w_ref=20.0):
+        """ref cal_start_cost / cal_neighbor_cost for free edges: edges (n, 8) = start s, l, dl, ddl, span, end l, sample_s, 0;
+        obstacles per edge obs_s, obs_l (n, max_obs), n_obs (n,) -> cost (n,)."""
+        a = self._args(edges)
+        n = int(edges.shape[0])
+        mo = int(obs_s.shape[1]) if obs_s is not None else 0
+        c, cp = a.out((n,), np.float64)
+        w3 = (C.c_double * 3)(*[float(v) for v in w_smooth])
+        self._check(self._lib.emp_free_edge_costs(
+            self._h, n, mo, a.inp(edges, np.float64, (n, 8)), a.inp(obs_s, np.float64, (n, mo)) if mo else None,
+            a.inp(obs_l, np.float64, (n, mo)) if mo else None, a.inp(n_obs, np.int32, (n,)) if mo else None,
+            float(w_collision), w3, float(w_ref), cp, a.where))
+        return c
+
+
+Planner.set_option.__doc__ += "\n        Options: " + ", ".join(f'"{k}"' for k in L.OPTIONS) + "."
 
 
 def st_grid():

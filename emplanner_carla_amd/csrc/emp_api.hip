@@ -136,6 +136,9 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // path QP: 0.75 of the roofline against 0.61)
     if (tiled && tiled_elems(d) * sizeof(double) > ((size_t)256 << 20) && wpb < 4) wpb = 4;
     if (eb_env) wpb = eb_env / 64;
+    // (the rule above prices a two-wavefront block; a wide table with wide obstacle rows - 32 rows, 254+ obstacle slots: one block
+    // of sixteen wavefronts per CU - may not hold sixteen per-wavefront scratch areas: fewer wavefronts, not a refusal)
+    while (wpb > 1 && lds_fixed + (size_t)wpb * lds_wave > 160 * 1024) --wpb;
     const int eb = wpb * 64;
     lds = lds_fixed + (size_t)wpb * lds_wave;
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "edge-cost block too large for the LDS");
@@ -166,11 +169,12 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
      : d.row == 12 ? (m32 ? K<T, 12, M32> : K<T, 12, M64>)                                                            \
      : d.row == 5 ? (m32 ? K<T, 5, M32> : K<T, 5, M64>)                                                               \
                   : (m32 ? K<T, 0, M32> : K<T, 0, M64>))
-    auto kern = ring ? (tiled ? EMP_EDGE_PICK(dp_edge_ring_kernel, true) : EMP_EDGE_PICK(dp_edge_ring_kernel, false))
-                     : (tiled ? EMP_EDGE_PICK(dp_edge_kernel, true) : EMP_EDGE_PICK(dp_edge_kernel, false));
+    auto kern_ring = tiled ? EMP_EDGE_PICK(dp_edge_ring_kernel, true) : EMP_EDGE_PICK(dp_edge_ring_kernel, false);
+    auto kern = tiled ? EMP_EDGE_PICK(dp_edge_kernel, true) : EMP_EDGE_PICK(dp_edge_kernel, false);
 #undef EMP_EDGE_PICK
     if (lds > 48 * 1024)
-        EMP_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EMP_HIP(ctx, hipFuncSetAttribute(ring ? (const void*)kern_ring : (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
     // EMP_OPT_EDGE_AFTER_ENRICH (staged pipeline): the edge kernel starts behind the previous call's densification kernel,
     // so that the path QP that follows it on the back queue is dispatched BEFORE this kernel's sixteen-wavefront blocks
     // take the compute units (emp_plan_cycle)
@@ -178,9 +182,29 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->edge_wait, 0));
         ctx->edge_wait = nullptr;
     }
+    if (ring && ctx->opt[EMP_OPT_EDGE_CLOCK_PROBE]) {          // measurement: two reference ticks per wavefront of this launch
+        const size_t waves_total = (size_t)grid.x * grid.y * wpb;
+        const int grc = grow_buffer(ctx, ctx->edge_probe, waves_total * 2 * sizeof(unsigned long long));
+        if (grc) return grc;
+        if (!ctx->edge_probe_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->edge_probe_done, hipEventDisableTiming));
+        ctx->edge_probe_waves = (long)waves_total;
+        {
+            KernelTimer t(ctx, "dp_edge");
+            hipLaunchKernelGGL(kern_ring, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
+                               cols_per_chunk, (unsigned long long*)ctx->edge_probe.p);
+        }
+        EMP_LAUNCH_CHECK(ctx);
+        EMP_HIP(ctx, hipEventRecord(ctx->edge_probe_done, ctx->stream));
+        return EMP_OK;
+    }
     KernelTimer t(ctx, "dp_edge");
-    hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
-                       cols_per_chunk);
+    if (ring) {
+        hipLaunchKernelGGL(kern_ring, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
+                           cols_per_chunk, (unsigned long long*)nullptr);
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
+                           cols_per_chunk);
+    }
     EMP_LAUNCH_CHECK(ctx);
     return EMP_OK;
 }
@@ -470,6 +494,8 @@ void emp_destroy(emp_ctx* ctx) {
     for (void* hp : ctx->pinned) (void)hipHostFree(hp);
     if (ctx->clock_probe.p) (void)hipFree(ctx->clock_probe.p);
     if (ctx->clock_probe_done) (void)hipEventDestroy(ctx->clock_probe_done);
+    if (ctx->edge_probe.p) (void)hipFree(ctx->edge_probe.p);
+    if (ctx->edge_probe_done) (void)hipEventDestroy(ctx->edge_probe_done);
     if (ctx->sweep_marker) (void)hipEventDestroy(ctx->sweep_marker);
     for (auto& kv : ctx->pair_tables)
         if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
@@ -684,6 +710,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_EDGE_AFTER_ENRICH:
         case EMP_OPT_SWEEP_MARKER:
         case EMP_OPT_EDGE_FORM:
+        case EMP_OPT_EDGE_CLOCK_PROBE:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
@@ -724,6 +751,26 @@ double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_
     if (mean_wave_us) *mean_wave_us = ticks_r / (double)waves / 100.0;      // 100 MHz reference
     if (max_wave_us) *max_wave_us = longest / 100.0;
     return ticks_c / ticks_r * 100.0;
+}
+
+int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* mean_resident_waves, int32_t* waves) {
+    if (!ctx || !ctx->edge_probe.p || !ctx->edge_probe_done || ctx->edge_probe_waves <= 0) return EMP_ERR_INVALID;
+    if (hipEventSynchronize(ctx->edge_probe_done) != hipSuccess) return EMP_ERR_HIP;
+    std::vector<unsigned long long> h((size_t)ctx->edge_probe_waves * 2);
+    if (hipMemcpy(h.data(), ctx->edge_probe.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return EMP_ERR_HIP;
+    unsigned long long first = ~0ull, last = 0;
+    double sum = 0.0;
+    for (long w = 0; w < ctx->edge_probe_waves; ++w) {
+        first = std::min(first, h[2 * w]);
+        last = std::max(last, h[2 * w + 1]);
+        sum += (double)(h[2 * w + 1] - h[2 * w]);
+    }
+    const double span = (double)(last - first);
+    if (mean_wave_us) *mean_wave_us = sum / (double)ctx->edge_probe_waves / 100.0;      // 100 MHz reference
+    if (span_us) *span_us = span / 100.0;
+    if (mean_resident_waves) *mean_resident_waves = span > 0 ? sum / span : 0.0;
+    if (waves) *waves = (int32_t)ctx->edge_probe_waves;
+    return EMP_OK;
 }
 
 int emp_sweep_probe_spans(emp_ctx* ctx, double* start_spread_us, double* first_start_to_last_end_us) {
@@ -1651,20 +1698,50 @@ int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* 
     return st.finish();
 }
 
-int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis, const double* square_d,
-                 double* cost, emp_mem where) {
+int emp_obs_cost_n(emp_ctx* ctx, int32_t n, int32_t samples, double w_collision, double danger_dis, double safe_dis,
+                   const double* square_d, double* cost, emp_mem where) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    EMP_REQUIRE(ctx, n >= 0 && square_d && cost, "bad argument");
+    EMP_REQUIRE(ctx, n >= 0 && samples >= 0 && cost && (square_d || (size_t)n * samples == 0), "bad argument");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
     Stage st(ctx, where);
     int rc;
     const double* d_sq;
     double* d_c;
-    if ((rc = st.in(square_d, (size_t)n * 10, &d_sq))) return rc;
+    if ((rc = st.in(square_d, (size_t)n * samples, &d_sq))) return rc;
     if ((rc = st.out(cost, (size_t)n, &d_c))) return rc;
     if (n) {
-        hipLaunchKernelGGL(obs_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, w_collision, danger_dis, safe_dis,
+        hipLaunchKernelGGL(obs_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, samples, w_collision, danger_dis, safe_dis,
                            d_sq, d_c);
+        EMP_LAUNCH_CHECK(ctx);
+    }
+    return st.finish();
+}
+
+int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis, const double* square_d,
+                 double* cost, emp_mem where) {
+    return emp_obs_cost_n(ctx, n, kSamples, w_collision, danger_dis, safe_dis, square_d, cost, where);
+}
+
+int emp_free_edge_costs(emp_ctx* ctx, int32_t n, int32_t max_obs, const double* edges, const double* obs_s, const double* obs_l,
+                        const int32_t* n_obs, double w_collision, const double* w_smooth3, double w_ref, double* cost, emp_mem where) {
+    EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
+    EMP_REQUIRE(ctx, n >= 0 && max_obs >= 0 && edges && w_smooth3 && cost, "bad argument");
+    EMP_REQUIRE(ctx, max_obs == 0 || (obs_s && obs_l && n_obs), "obs_s / obs_l / n_obs are required when max_obs > 0");
+    EMP_HIP(ctx, hipSetDevice(ctx->device));
+    const double w0 = w_smooth3[0], w1 = w_smooth3[1], w2 = w_smooth3[2];      // host memory, like the parameter structs
+    Stage st(ctx, where);
+    int rc;
+    const double *d_e, *d_os, *d_ol;
+    const int* d_n;
+    double* d_c;
+    if ((rc = st.in(edges, (size_t)n * 8, &d_e))) return rc;
+    if ((rc = st.in(obs_s, (size_t)n * max_obs, &d_os))) return rc;
+    if ((rc = st.in(obs_l, (size_t)n * max_obs, &d_ol))) return rc;
+    if ((rc = st.in(n_obs, (size_t)n, &d_n))) return rc;
+    if ((rc = st.out(cost, (size_t)n, &d_c))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(free_edge_cost_kernel, grid1(n, 64), dim3(64), 0, ctx->stream, n, max_obs, d_e, d_os, d_ol, d_n, w_collision,
+                           w0, w1, w2, w_ref, d_c);
         EMP_LAUNCH_CHECK(ctx);
     }
     return st.finish();

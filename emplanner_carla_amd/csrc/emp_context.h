@@ -93,7 +93,7 @@ struct emp_ctx {
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
-    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0};
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0};
     hipEvent_t edge_wait = nullptr;     // EMP_OPT_EDGE_AFTER_ENRICH: what the next edge-cost launch waits for on its stream
     // STAGED: an event the next densification / path-QP launch is asked to signal from its own dispatch (hipExtLaunchKernelGGL's
     // stop event) instead of a marker packet behind it - a marker idles the back queue ~6 us, twice per step; `stop_attached`
@@ -108,6 +108,9 @@ struct emp_ctx {
     // begin / end); probe_launches counts the launches recorded since the option was last switched on
     static constexpr int kProbeSlots = 32;
     Buf clock_probe;
+    Buf edge_probe;                     // EMP_OPT_EDGE_CLOCK_PROBE: [wavefronts of the latest edge launch][2] reference ticks
+    long edge_probe_waves = 0;
+    hipEvent_t edge_probe_done = nullptr;
     int clock_probe_tiles = 0;
     long probe_launches = 0;
     hipEvent_t clock_probe_done = nullptr;

@@ -141,28 +141,34 @@ __device__ __forceinline__ double soft_cost_quotient(double d2) {
 // consecutive samples are `stride` doubles apart.  Against the nested form with the early break (one LDS read, one
 // wait and two exec-mask regions per sample, each nested in the previous one) this issues 3 % more vector
 // instructions and 45 % fewer scalar ones, and the kernel went from 175 to 157 us (profiles/r02_edge_variants.md).
+#ifndef EMP_SCAN_GROUP
+#define EMP_SCAN_GROUP 10          // samples whose distances are formed together (10: all of them first; 5: two halves - ten
+#endif                             // registers fewer in flight, the same operations in the same order)
 __device__ __forceinline__ double obstacle_scan_dense(double s0, const double* t_smp, const double* l_n, int stride,
                                                       double os, double ol, double w_coll) {
-    double d2[kSamples];
-#pragma unroll
-    for (int n = 0; n < kSamples; ++n) {
-        const double d_lon = os - (s0 + t_smp[n]);            // the sample abscissa, ref :493/:566 (rebuilt, not kept: registers)
-        const double d_lat = ol - l_n[n * stride];
-        d2[n] = d_lon * d_lon + d_lat * d_lat;
-    }
     double c = 0.0;
     bool alive = true;
 #pragma unroll
-    for (int n = 0; n < kSamples; ++n) {
-        const bool near = alive & (d2[n] < kSafe2);
-        const bool hard = near & (d2[n] <= kDanger2);
-        if (near & !hard) {
-#if EMP_SOFT_NEWTON_STEPS == 1
-            asm volatile("");          // keeps the wave-level skip branch around the (now short) division block
-#endif
-            c = c + soft_cost_quotient(d2[n]);
+    for (int g = 0; g < kSamples; g += EMP_SCAN_GROUP) {
+        double d2[EMP_SCAN_GROUP];
+#pragma unroll
+        for (int n = 0; n < EMP_SCAN_GROUP; ++n) {
+            const double d_lon = os - (s0 + t_smp[g + n]);        // the sample abscissa, ref :493/:566 (rebuilt, not kept: registers)
+            const double d_lat = ol - l_n[(g + n) * stride];
+            d2[n] = d_lon * d_lon + d_lat * d_lat;
         }
-        alive = alive & !hard;
+#pragma unroll
+        for (int n = 0; n < EMP_SCAN_GROUP; ++n) {
+            const bool near = alive & (d2[n] < kSafe2);
+            const bool hard = near & (d2[n] <= kDanger2);
+            if (near & !hard) {
+#if EMP_SOFT_NEWTON_STEPS == 1
+                asm volatile("");          // keeps the wave-level skip branch around the (now short) division block
+#endif
+                c = c + soft_cost_quotient(d2[n]);
+            }
+            alive = alive & !hard;
+        }
     }
     if (!alive) c = c + w_coll;
     return c;
@@ -362,19 +368,23 @@ struct EdgeRing {                        // per wavefront, in LDS
 };                                       // (the edge's smoothness term is recomputed by the lane that pops the entry: 8 bytes
                                          // per entry less - at 120 x 21 the 60 KB pair table leaves a wavefront 2.4 KB of LDS)
 
-#ifndef EMP_EDGE_RING_ATTR
-#define EMP_EDGE_RING_ATTR
+#ifndef EMP_EDGE_RING_BOUNDS
+#define EMP_EDGE_RING_BOUNDS __launch_bounds__(1024, EMP_EDGE_WAVES)
 #endif
 template <bool TILED, int ROW = 0, typename MASK = unsigned>
-__global__ __launch_bounds__(1024, EMP_EDGE_WAVES) EMP_EDGE_RING_ATTR void dp_edge_ring_kernel(DpDev P, const double* __restrict__ pair_tab,
+__global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* __restrict__ pair_tab,
                                                            const double* __restrict__ obs_s,
                                                            const double* __restrict__ obs_l,
                                                            const int* __restrict__ n_obs,
                                                            const double* __restrict__ start,
                                                            double* __restrict__ start_cost,
-                                                           double* __restrict__ edge, int cols_per_chunk) {
+                                                           double* __restrict__ edge, int cols_per_chunk,
+                                                           unsigned long long* __restrict__ clock_probe = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __builtin_amdgcn_s_setprio(EMP_PRIO_FRONT);
+    // EMP_OPT_EDGE_CLOCK_PROBE (measurement; a scalar branch when off): the constant 100 MHz counter at the wavefront's first and
+    // last instruction - how long a wavefront is resident and how many are resident at once, alone and inside the staged step
+    const unsigned long long probe_r0 = clock_probe ? wall_clock64() : 0;
     constexpr int kMaskBits = (int)sizeof(MASK) * 8;
     const int row = ROW > 0 ? ROW : P.row, rr = row * row;
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
@@ -531,6 +541,11 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) EMP_EDGE_RING_ATTR void dp_ed
     }
     while (cnt[0] > 0) round(0);
     while (cnt[1] > 0) round(1);
+    if (clock_probe && lane == 0) {
+        unsigned long long* o = clock_probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * waves + wave) * 2;
+        o[0] = probe_r0;
+        o[1] = wall_clock64();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1220,14 +1220,14 @@ __global__ void quintic_kernel(int n, const double* __restrict__ bc, double* __r
 }
 
 // ref: cal_obs_cost, path_planning.py:588-609
-__global__ void obs_cost_kernel(int n, double w, double danger, double safe, const double* __restrict__ sq,
+__global__ void obs_cost_kernel(int n, int samples, double w, double danger, double safe, const double* __restrict__ sq,
                                 double* __restrict__ cost) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const double d2a = danger * danger, d2b = safe * safe;
     double c = 0.0;
-    for (int i = 0; i < kSamples; ++i) {
-        const double v = sq[kSamples * t + i];
+    for (int i = 0; i < samples; ++i) {               // the reference loops over whatever it is handed (:601)
+        const double v = sq[(size_t)samples * t + i];
         if (v <= d2a) {
             c = c + w;
             break;
@@ -1236,6 +1236,21 @@ __global__ void obs_cost_kernel(int n, double w, double danger, double safe, con
         }
     }
     cost[t] = c;
+}
+
+// ref: cal_start_cost (path_planning.py:435-514) / cal_neighbor_cost (:517-585) for FREE edges: edges [n][8] = start s, l, dl, ddl,
+// span (end s - start s), end l, sample_s, (unused).  The quintic ends at `end s` (the reference's cal_quintic_coefficient call, :475 / :553) while
+// the ten samples step by sample_s / 10 from the start (:492-493 / :565-566) - the two coincide on the lattice and need not
+// for a caller of the drop-in functions.  Obstacles per edge: obs_s, obs_l [n][max_obs], n_obs [n].
+__global__ void free_edge_cost_kernel(int n, int max_obs, const double* __restrict__ edges, const double* __restrict__ obs_s,
+                                      const double* __restrict__ obs_l, const int* __restrict__ n_obs, double w_coll, double w0,
+                                      double w1, double w2, double w_ref, double* __restrict__ cost) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const double* e = edges + (size_t)t * 8;
+    const Quintic q = quintic_shifted(e[1], e[2], e[3], e[5], e[4]);
+    const int k = max_obs > 0 ? min(max(n_obs[t], 0), max_obs) : 0;
+    cost[t] = segment_cost(q, e[0], e[6], obs_s + (size_t)t * max_obs, obs_l + (size_t)t * max_obs, k, w_coll, w0, w1, w2, w_ref);
 }
 
 }  // namespace emp

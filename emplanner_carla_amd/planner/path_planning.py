@@ -23,24 +23,20 @@ def _sl_arrays(obs_s_list, obs_l_list):
 
 
 def cal_obs_cost(w_cost_collision, square_d, danger_dis=4, safe_dis=6):
-    """ref :588-609."""
+    """ref :588-609 (any number of samples: the reference loops over what it is handed, :601)."""
     sq = np.asarray(square_d, dtype=np.float64).reshape(1, -1)
-    if sq.shape[1] != 10:
-        raise ValueError("cal_obs_cost expects the 10 samples of one lattice edge")
     return float(planner().obs_cost(sq, w_cost_collision, danger_dis, safe_dis)[0])
 
 
-def _edge(obs_s_list, obs_l_list, start, end_l, sample_s, w_cost_collision, w_cost_smooth, w_cost_ref):
-    """One free lattice edge through the edge-cost kernel.  The kernel's start-edge form takes any start state
-    (s, l, dl, ddl) and ends on a lattice row; a 3-row, 1-column lattice with sample_l = |end_l| has rows at
-    exactly +|end_l|, 0, -|end_l|, so the wanted end offset is one of its rows."""
-    sl = abs(end_l) if end_l != 0 else 1.0
-    i = 1 if end_l == 0 else (0 if end_l > 0 else 2)          # rows of a 3-row lattice: +sl, 0, -sl
-    p = dp_params(row=3, col=1, sample_s=sample_s, sample_l=sl, w_collision_cost=w_cost_collision,
-                  w_smooth_cost=w_cost_smooth, w_reference_cost=w_cost_ref)
+def _edge(obs_s_list, obs_l_list, start, end_s, end_l, sample_s, w_cost_collision, w_cost_smooth, w_cost_ref):
+    """One free edge through emp_free_edge_costs: the quintic from the start state (s, l, dl, ddl) to (end_l, 0, 0) at end_s,
+    sampled every sample_s / 10 from the start (ref :475 / :553 and :492-493 / :565-566)."""
     obs_s, obs_l, n = _sl_arrays(obs_s_list, obs_l_list)
-    c0, _ = planner().dp_edge_costs(p, obs_s, obs_l, n, np.asarray([start], dtype=np.float64))
-    return np.array([[c0[0, i]]])                                # the reference returns a 1x1 array
+    # on the lattice end_s IS start_s + sample_s: the span is then sample_s itself, to the last bit, as in the DP kernels
+    span = float(sample_s) if float(end_s) == start[0] + float(sample_s) else float(end_s) - start[0]
+    edge = np.array([[start[0], start[1], start[2], start[3], span, float(end_l), float(sample_s), 0.0]], dtype=np.float64)
+    c = planner().free_edge_costs(edge, obs_s, obs_l, n, w_cost_collision, w_cost_smooth, w_cost_ref)
+    return np.array([[c[0]]])                                       # the reference returns a 1x1 array
 
 
 def cal_start_cost(obs_s_list, obs_l_list, begin_s, begin_l, begin_dl, begin_ddl, cur_node_row, row, sample_s,
@@ -56,9 +52,9 @@ def cal_start_cost(obs_s_list, obs_l_list, begin_s, begin_l, begin_dl, begin_ddl
 
 def cal_neighbor_cost(obs_s_list, obs_l_list, pre_node_s, pre_node_l, cur_node_s, cur_node_l, sample_s,
                       w_cost_collision, w_cost_smooth, w_cost_ref):
-    """ref :517-585 (a neighbour edge is a start edge with zero start derivatives)."""
-    return _edge(obs_s_list, obs_l_list, (pre_node_s, pre_node_l, 0.0, 0.0), float(cur_node_l), sample_s,
-                 w_cost_collision, w_cost_smooth, w_cost_ref)
+    """ref :517-585: the quintic ends at cur_node_s (:553), the samples step by sample_s / 10 from pre_node_s (:565-566)."""
+    return _edge(obs_s_list, obs_l_list, (float(pre_node_s), float(pre_node_l), 0.0, 0.0), float(cur_node_s), float(cur_node_l),
+                 sample_s, w_cost_collision, w_cost_smooth, w_cost_ref)
 
 
 def enrich_DP_s_l(DP_s_list, DP_l_list, plan_start_s, plan_start_l, plan_start_dl, plan_start_ddl, resolution=1):

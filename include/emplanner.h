@@ -209,6 +209,9 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
  *                                                             obstacle rows wider than 64 slots always take the lockstep form
  *   EMP_OPT_EDGE_COLS_PER_WAVE      0        tuning           lattice columns a wavefront of the edge-cost kernel takes; 0: auto
+ *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
+ *                                                             the 100 MHz reference counter at its first and last instruction
+ *                                                             (emp_edge_probe reads the latest launch)
  *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto; 1/2/3: register ring 3/4/8 columns deep;
  *                                                             4/5: nontemporal / plain loads whatever the tensor's size
  *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
@@ -257,7 +260,8 @@ typedef enum emp_option {
     EMP_OPT_SWEEP_MARKER = 12,
     EMP_OPT_EDGE_FORM = 13,
     EMP_OPT_EDGE_COLS_PER_WAVE = 14,
-    EMP_OPT_COUNT = 15
+    EMP_OPT_EDGE_CLOCK_PROBE = 15,
+    EMP_OPT_COUNT = 16
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
@@ -266,6 +270,10 @@ int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
  * last instruction, summed over all their wavefronts (synchronises on the latest launch); optionally (may be NULL) the mean
  * and the longest time a wavefront was resident, in microseconds.  Negative when nothing was recorded. */
 double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_us);
+/* With EMP_OPT_EDGE_CLOCK_PROBE on: the latest edge-cost launch - mean time a wavefront was resident (us), time from the first
+ * wavefront's start to the last one's end (us), mean number of wavefronts resident at once (their ratio x count), wavefronts.
+ * Synchronises on that launch.  Any out pointer may be NULL. */
+int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* mean_resident_waves, int32_t* waves);
 /* The same probe, per launch and averaged over the recorded launches (100 MHz reference ticks, which all wavefronts share):
  * how long after the launch's first wavefront its last wavefront started, and the time from the first wavefront's first
  * instruction to the last wavefront's last - what is left of the launch's event-measured duration is dispatch and
@@ -471,6 +479,16 @@ int emp_quintic_coefficients(emp_ctx* ctx, int32_t n, const double* bc, double* 
 /* ref: cal_obs_cost (path_planning.py:588-609): square_d [n][10] -> cost [n] */
 int emp_obs_cost(emp_ctx* ctx, int32_t n, double w_collision, double danger_dis, double safe_dis,
                  const double* square_d, double* cost, emp_mem where);
+/* ... for any number of samples per row (ABI 10; the reference loops over whatever it is handed, :601): square_d [n][samples] */
+int emp_obs_cost_n(emp_ctx* ctx, int32_t n, int32_t samples, double w_collision, double danger_dis, double safe_dis,
+                   const double* square_d, double* cost, emp_mem where);
+/* ref: cal_start_cost (path_planning.py:435-514) and cal_neighbor_cost (:517-585) for n FREE edges (ABI 10): edges [n][8] =
+ * start s, l, dl, ddl, span, end l, sample_s, 0.  The quintic runs from the start state to (end l, 0, 0) at start s + span (:475 /
+ * :553) while the ten samples step by sample_s / 10 from the start (:492-493 / :565-566): on the lattice span = sample_s, a
+ * caller of the drop-in functions may pass anything.  Obstacles per edge: obs_s, obs_l [n][max_obs], n_obs [n];
+ * w_smooth3 [3] in HOST memory.  cost [n]. */
+int emp_free_edge_costs(emp_ctx* ctx, int32_t n, int32_t max_obs, const double* edges, const double* obs_s, const double* obs_l,
+                        const int32_t* n_obs, double w_collision, const double* w_smooth3, double w_ref, double* cost, emp_mem where);
 
 /* ref: trajectory_index2s (planning_utils.py:758-780): x, y [B][max_pts] -> cumulative chord length [B][max_pts] */
 int emp_trajectory_index2s(emp_ctx* ctx, int32_t B, int32_t max_pts, const double* x, const double* y,

@@ -277,6 +277,29 @@ def function_level(pp, pu):
     dy = pu.cal_dy_obs_deri(np.array([1.0, -2.0, np.nan]), np.array([5.0, 0.0, 1.0]), np.array([1.0, 0.0, 1.0]),
                             np.array([0.1, 0.2, 0.3]), np.array([0.01, -0.02, 0.0]))
     g["dyobs"] = np.stack([a[:4] for a in dy])
+    # (round 5) cal_obs_cost on rows that are NOT ten samples long (the reference loops over whatever it gets, :601), and
+    # cal_neighbor_cost with an end station that is not pre_node_s + sample_s (the quintic ends at cur_node_s, :553, the
+    # samples step by sample_s / 10, :565-566) - what a caller of the drop-in functions may do and the DP never does
+    r2 = np.random.default_rng(20250930)
+    for n in (7, 23):
+        sq = r2.uniform(10.0, 50.0, (5, n))
+        sq[1, n // 2] = 15.0
+        sq[3, 0] = 16.0
+        g[f"obs_sq{n}"] = sq
+        g[f"obs_cost{n}"] = np.array([float(pp.cal_obs_cost(1e12, r.reshape(n, 1))) for r in sq])
+    cases, costs = [], []
+    obs_s, obs_l = [22.0, 31.5, 60.0], [1.0, -2.5, 4.0]
+    for _ in range(12):
+        pre_s = r2.uniform(5.0, 60.0)
+        sample_s = float(r2.choice([2.5, 5.0, 15.0]))
+        span = sample_s * r2.uniform(0.6, 1.7)
+        pre_l, cur_l = r2.uniform(-4, 4), r2.uniform(-4, 4)
+        c = pp.cal_neighbor_cost(obs_s, obs_l, pre_s, pre_l, pre_s + span, cur_l, sample_s, 1e12, [300, 1000, 5000], 20)
+        cases.append([pre_s, pre_l, pre_s + span, cur_l, sample_s])
+        costs.append(float(np.asarray(c).reshape(-1)[0]))
+    g["nbr_general_in"] = np.asarray(cases)
+    g["nbr_general_obs"] = np.array([obs_s, obs_l])
+    g["nbr_general_cost"] = np.asarray(costs)
     return g
 
 

@@ -113,6 +113,16 @@ def test_edge_cost_functions(mods):
     for r, c, c3 in zip(fn["obs_sq"], fn["obs_cost"], fn["obs_cost_w3"]):
         assert pp.cal_obs_cost(1e12, r.reshape(10, 1)) == c
         assert pp.cal_obs_cost(7.5, r.reshape(10, 1), danger_dis=3, safe_dis=5) == c3
+    # rows of any length (the reference loops over what it is handed, :601)
+    for n in (7, 23):
+        for r, c in zip(fn[f"obs_sq{n}"], fn[f"obs_cost{n}"]):
+            assert pp.cal_obs_cost(1e12, r.reshape(n, 1)) == c
+    assert pp.cal_obs_cost(1e12, np.zeros((0, 1))) == 0.0
+    # an end station that is not pre_node_s + sample_s: the quintic ends there (:553), the samples keep stepping by sample_s / 10
+    o = fn["nbr_general_obs"]
+    for (pre_s, pre_l, cur_s, cur_l, ss), c in zip(fn["nbr_general_in"], fn["nbr_general_cost"]):
+        got = pp.cal_neighbor_cost(list(o[0]), list(o[1]), pre_s, pre_l, cur_s, cur_l, ss, *w)
+        assert_rel(got[0, 0], c, RTOL, "cal_neighbor_cost with a free end station")
 
 
 def test_function_level_vectors(mods):

@@ -30,7 +30,16 @@ CHUNK = 16 if os.environ.get("SWEEP_DP_CFG") == "cfg5" else 256     # scenes per
 ST_CHUNK = 32
 N_ST = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 N_FE = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
-START_AHEAD = float(os.environ.get("SWEEP_START_AHEAD", "2.0"))   # scenes.make_scene: 2.0 puts the planning start ON reference-line node 6
+START_AHEAD = float(os.environ.get("SWEEP_START_AHEAD", "2.7"))   # scenes.BENCH_START_AHEAD; 2.0 puts the planning start ON reference-line node 6
+GEOMETRY = os.environ.get("SWEEP_GEOMETRY", "gentle")            # "survey": scenes.survey_geometry_kwargs per seed (arc radii 150-1000 m,
+                                                                 # the survey layout on odd seeds, starts off the nodes on every other pair)
+
+
+def _scene_kw():
+    from emplanner_carla_amd import scenes as S
+    if GEOMETRY == "survey":
+        return dict(per_seed=S.survey_geometry_kwargs)
+    return dict(dist=os.environ.get("SWEEP_SCENE_DIST", "corridor"), start_ahead=START_AHEAD)
 TIE_TOL = 8e-15            # |s - s_map[k]| at or below this: `s_map[idx + 1] < s` (path_planning.py:63) is decided by the last bit
 PARTS = set(os.environ.get("SWEEP_PARTS", "dp,cycle,st,fe").split(","))   # which parts run
 
@@ -45,7 +54,7 @@ def _exact_chunk(lo):
     from emplanner_carla_amd import scenes as S
     from oracle import exact as ex
     cfg = _dp_cfg()
-    b = S.make_batch(range(lo, lo + CHUNK), cfg)
+    b = S.make_batch(range(lo, lo + CHUNK), cfg, start_ahead=START_AHEAD)
     rows, feas, paths = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s, cfg.sample_l,
                                    cfg.sampling_res)
     return lo, rows, feas, [np.asarray(p[0]) for p in paths], [np.asarray(p[1]) for p in paths]
@@ -60,7 +69,7 @@ def _port_scene(seed):
     from emplanner_carla_amd import scenes as S
     from oracle import ref_port as op
     cfg = _cycle_cfg()
-    b = S.make_batch([seed], cfg, dist=os.environ.get("SWEEP_SCENE_DIST", "corridor"), start_ahead=START_AHEAD)
+    b = S.make_batch([seed], cfg, **_scene_kw())
     nk = int(b.n_obs[0])
     try:
         out = op.plan_cycle(b.ref[0], tuple(b.origin_xy[0]), tuple(b.start_xy[0]), tuple(b.start_v[0]), tuple(b.start_a[0]),
@@ -141,7 +150,7 @@ def main():
         infeasible = 0
         with ctx.Pool(NPROC) as pool:
             for lo, xrows, xfeas, xs, xl in pool.imap_unordered(_exact_chunk, range(0, N_DP, CHUNK)):
-                b = S.make_batch(range(lo, lo + CHUNK), cfg)
+                b = S.make_batch(range(lo, lo + CHUNK), cfg, start_ahead=START_AHEAD)
                 rows, mc, st = pl.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
                 ps, pll, ln, st2 = pl.dp_enrich(p, rows, b.sl_start, M)
                 bad["rows"] += int((rows != xrows).any(axis=1).sum())
@@ -162,7 +171,7 @@ def main():
         M = max_path_points(p)
         dist_name = os.environ.get("SWEEP_SCENE_DIST", "corridor")      # corridor (default) | survey | worst: obstacle layout
         seed0 = int(os.environ.get("SWEEP_SEED0", "0"))            # first seed of the cycle part
-        b = S.make_batch(range(seed0, seed0 + N_CY), cfg, dist=dist_name, start_ahead=START_AHEAD)
+        b = S.make_batch(range(seed0, seed0 + N_CY), cfg, **_scene_kw())
         P = b.ref.shape[1]
         r = pl.plan_cycle(p, qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params(), max_pts=M, ref_line=b.ref,
                           n_ref=np.full(N_CY, P, np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy, start_v=b.start_v,
@@ -229,7 +238,8 @@ def main():
                                         err_path_s=float(np.abs(r.path_s[seed, :k] - ps[:k]).max()) if k == len(ps) else None,
                                         worst_point=int(np.unravel_index(np.argmax(err), err.shape)[0])))
                 compared += 1
-        report["cycle"] = {"config": cfg.name, "scene_dist": dist_name, "first_seed": seed0, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
+        report["cycle"] = {"config": cfg.name, "scene_dist": dist_name if GEOMETRY != "survey" else "corridor (even seeds) / survey (odd seeds)",
+                           "geometry": GEOMETRY + (": arc radii 150-1000 m (SURVEY 8d), scenes.survey_geometry_kwargs" if GEOMETRY == "survey" else ": arc radii 1500-6000 m"), "first_seed": seed0, "scenes": N_CY, "fully_planned_and_compared": compared, "outcome_mismatch": outcome,
                            "dp_feasibility_mismatch": feas_bad, "length_mismatch": length, "start_ahead": START_AHEAD,
                            "worst_error_over_survey_rule": worst_rule,
                            "survey_rule": "|a - b| <= max(1e-6 |b|, 1e-9) on x, y, theta, kappa of every trajectory point (SURVEY.md 8d); the ratio must stay <= 1",
