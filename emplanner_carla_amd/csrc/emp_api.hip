@@ -18,7 +18,7 @@ constexpr int kMaxTiledRow = 32;       // the tiled kernels (scenes packed into 
 
 static int make_dp_dev(emp_ctx* ctx, const emp_dp_params* p, int B, int max_obs, DpDev* d) {
     EMP_REQUIRE(ctx, p != nullptr, "dp params are NULL");
-    EMP_REQUIRE(ctx, p->row >= 1 && p->row <= kMaxWideRow, "row must be in [1, 256]");
+    EMP_REQUIRE(ctx, p->row >= 1 && p->row <= kMaxWideRow, "row must be in [1, 1024]");
     EMP_REQUIRE(ctx, p->col >= 1 && p->col <= 255 * 16, "col must be in [1, 4080]");
     EMP_REQUIRE(ctx, B >= 0, "negative batch");
     EMP_REQUIRE(ctx, max_obs >= 0 && max_obs <= 256, "max_obs must be in [0, 256]");
@@ -78,7 +78,7 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
         EMP_REQUIRE(ctx, d.B <= 0x7fffffff && d.col - 1 <= 65535, "batch or lattice too large for the wide-row edge kernel's grid");
         KernelTimer t(ctx, "dp_edge");
-        hipLaunchKernelGGL(dp_edge_wide_kernel, dim3(d.B, d.col > 1 ? d.col - 1 : 1), dim3(((d.row + 63) / 64) * 64), 0, ctx->stream,
+        hipLaunchKernelGGL(dp_edge_wide_kernel, dim3(d.B, d.col > 1 ? d.col - 1 : 1), dim3(std::min(((d.row + 63) / 64) * 64, 256)), 0, ctx->stream,
                            d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge);
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
@@ -214,11 +214,11 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     if (d.B == 0) return EMP_OK;
     if (wide(d)) {          // more than 32 rows: one block per scene, predecessors in device memory
         emp_ctx::Buf& pre = ctx->named["dp_wide_pre_" + std::to_string(ctx->active_lane)];
-        const int grc = grow_buffer(ctx, pre, (size_t)d.B * d.col * d.row);
+        const int grc = grow_buffer(ctx, pre, (size_t)d.B * d.col * d.row * sizeof(unsigned short));
         if (grc) return grc;
         KernelTimer t(ctx, "dp_sweep");
-        hipLaunchKernelGGL(dp_sweep_wide_kernel, dim3(d.B), dim3(((d.row + 63) / 64) * 64), 2 * (size_t)d.row * sizeof(double),
-                           ctx->stream, d, start_cost, edge, n_obs, (unsigned char*)pre.p, rows, min_cost, status);
+        hipLaunchKernelGGL(dp_sweep_wide_kernel, dim3(d.B), dim3(std::min(((d.row + 63) / 64) * 64, 256)), 2 * (size_t)d.row * sizeof(double),
+                           ctx->stream, d, start_cost, edge, n_obs, (unsigned short*)pre.p, rows, min_cost, status);
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
     }

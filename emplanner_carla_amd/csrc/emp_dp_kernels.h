@@ -776,7 +776,8 @@ __global__ __launch_bounds__(64 * WPB) void dp_sweep_kernel(DpDev P, const doubl
 // bit-identical to what the tiled kernels would compute - with the edge tensor in the canonical layout
 // [B][col-1][i][k] (k fastest): correctness for every `row` up to kMaxWideRow, not speed (the reference's own
 // default is 12 rows; BASELINE's widest lattice has 21).
-constexpr int kMaxWideRow = 256;       // a predecessor index is one byte
+constexpr int kMaxWideRow = 1024;      // (round 5: predecessors of the wide sweep are 16-bit; until round 4 a byte, 256 rows.  The pair
+                                       // table is 15 row^2 doubles - 126 MB at 1024 rows - and the tensor (col - 1) row^2 doubles per scene)
 
 // grid = (B, max(col - 1, 1)), block = row rounded up to a wavefront (<= 256 threads): thread i costs the `row` edges
 // from column j-1 into row i of column j; pair table, sample offsets and obstacles are read from device memory.
@@ -784,33 +785,36 @@ __global__ __launch_bounds__(256) void dp_edge_wide_kernel(DpDev P, const double
                                                            const double* __restrict__ obs_s, const double* __restrict__ obs_l,
                                                            const int* __restrict__ n_obs, const double* __restrict__ start,
                                                            double* __restrict__ start_cost, double* __restrict__ edge) {
-    const int row = P.row, rr = P.row * P.row;
-    const int b = blockIdx.x, j = 1 + blockIdx.y, i = threadIdx.x;
-    if (i >= row) return;
+    const int row = P.row;
+    const size_t rr = (size_t)P.row * P.row;
+    const int b = blockIdx.x, j = 1 + blockIdx.y;
     const int nob = min(max(n_obs[b], 0), P.max_obs);
     const double* my_obs_s = obs_s + (size_t)b * P.max_obs;
     const double* my_obs_l = obs_l + (size_t)b * P.max_obs;
-    if (blockIdx.y == 0 && start_cost != nullptr) {      // start edges (column 0), ref :306-318
-        const double ps = start[b * 4 + 0], pl = start[b * 4 + 1], pdl = start[b * 4 + 2], pddl = start[b * 4 + 3];
-        const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, i, P.sample_l), P.sample_s);
-        start_cost[(size_t)b * row + i] = segment_cost(q, ps, P.sample_s, my_obs_s, my_obs_l, nob, P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+    for (int i = threadIdx.x; i < row; i += blockDim.x) {   // beyond 256 rows a thread takes several destination rows
+        if (blockIdx.y == 0 && start_cost != nullptr) {      // start edges (column 0), ref :306-318
+            const double ps = start[b * 4 + 0], pl = start[b * 4 + 1], pdl = start[b * 4 + 2], pddl = start[b * 4 + 3];
+            const Quintic q = quintic_shifted(pl, pdl, pddl, lattice_l(row, i, P.sample_l), P.sample_s);
+            start_cost[(size_t)b * row + i] = segment_cost(q, ps, P.sample_s, my_obs_s, my_obs_l, nob, P.w_coll, P.w0, P.w1, P.w2, P.w_ref);
+        }
+        if (j >= P.col) continue;
+        const double* t_smp = pair_tab + (size_t)kTableFields * rr;
+        double* out = edge + (size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + (size_t)i * row;
+        dp_edge_column(P, j, i, start[b * 4 + 0], nob, pair_tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) { out[k] = cost; });
     }
-    if (j >= P.col) return;
-    const double* t_smp = pair_tab + (size_t)kTableFields * rr;
-    double* out = edge + (size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr + (size_t)i * row;
-    dp_edge_column(P, j, i, start[b * 4 + 0], nob, pair_tab, t_smp, my_obs_s, my_obs_l, [&](int k, double cost) { out[k] = cost; });
 }
 
 // One block per scene, thread i = destination row (rows beyond the block size are taken in strides); the cost front
-// of the previous column lives in LDS (two buffers), predecessors in device memory `pre` [B][col][row] bytes.  The
+// of the previous column lives in LDS (two buffers), predecessors in device memory `pre` [B][col][row] 16-bit.  The
 // arithmetic of dp_sweep_kernel's generic path: cand = (front[k] + e) (+ 10000 on the penalty rows), strict '<' with k
 // ascending from (+inf, predecessor 1), first-minimum terminal, bypass without obstacles (ref :301-363).
 __global__ __launch_bounds__(256) void dp_sweep_wide_kernel(DpDev P, const double* __restrict__ start_cost,
                                                             const double* __restrict__ edge, const int* __restrict__ n_obs,
-                                                            unsigned char* __restrict__ pre, double* __restrict__ rows_out,
+                                                            unsigned short* __restrict__ pre, double* __restrict__ rows_out,
                                                             double* __restrict__ min_cost_out, int* __restrict__ status_out) {
     extern __shared__ double front_lds[];                 // [2][row]
-    const int row = P.row, rr = P.row * P.row;
+    const int row = P.row;
+    const size_t rr = (size_t)P.row * P.row;
     const int b = blockIdx.x;
     const double INF = __builtin_inf();
     double* cur = front_lds;
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(256) void dp_sweep_wide_kernel(DpDev P, const doubl
         cur[i] = c;
     }
     __syncthreads();
-    unsigned char* my_pre = pre + (size_t)b * P.col * row;
+    unsigned short* my_pre = pre + (size_t)b * P.col * row;
     for (int j = 1; j < P.col; ++j) {
         const double* ej = edge + (size_t)b * (P.col - 1) * rr + (size_t)(j - 1) * rr;
         for (int i = threadIdx.x; i < row; i += blockDim.x) {
@@ -837,7 +841,7 @@ __global__ __launch_bounds__(256) void dp_sweep_wide_kernel(DpDev P, const doubl
                 }
             }
             nxt[i] = best;
-            my_pre[(size_t)j * row + i] = (unsigned char)arg;
+            my_pre[(size_t)j * row + i] = (unsigned short)arg;
         }
         __syncthreads();
         double* t = cur;

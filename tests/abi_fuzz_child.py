@@ -49,7 +49,7 @@ def dp(pp=p, nB=B, mo=MO, os_=obs_s, ol_=obs_l, no=n_obs, s0=start, mode=1, r=ro
 
 assert dp() == 0
 clean = rows.copy()
-for field, bad in (("row", 0), ("row", -3), ("row", 257), ("col", 0), ("col", -1), ("col", 5000), ("sample_s", 0.0),
+for field, bad in (("row", 0), ("row", -3), ("row", 1025), ("col", 0), ("col", -1), ("col", 5000), ("sample_s", 0.0),
                    ("sample_s", -2.5), ("sample_l", 0.0), ("sampling_res", 0.0)):
     pp = dp_params_from_cfg(cfg)
     setattr(pp, field, bad)

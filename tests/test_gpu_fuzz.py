@@ -112,9 +112,10 @@ def test_cycle_vs_port_on_random_lattices(planner, i, geometry):
     assert compared >= 1 or cfg.n_obs >= 9 or geometry != "gentle"
 
 
-@pytest.mark.parametrize("row", [33, 80, 200])
+@pytest.mark.parametrize("row", [33, 80, 200, 257, 600])
 def test_wide_lattice_edge_tensor_bit_exact_and_layout(planner, row):
-    """More than 32 rows: the generic kernels' edge tensor equals oracle/exact.py bit for bit, the 'tiled' layout IS the
+    """More than 32 rows (up to 1024 since round 5: 16-bit predecessors; threads take several rows beyond 256): the generic
+    kernels' edge tensor equals oracle/exact.py bit for bit, the 'tiled' layout IS the
     canonical one there, the single-kernel DP mode falls back to the two-kernel form, and the sweep entry point consumes
     the tensor the edge entry point produced."""
     from emplanner_carla_amd import _lib as L
@@ -141,7 +142,7 @@ def test_wide_lattice_edge_tensor_bit_exact_and_layout(planner, row):
         sel = b.n_obs > 0                                  # the sweep entry point knows no bypass
         np.testing.assert_array_equal(r2[sel], rows[sel])
     with pytest.raises(Exception):
-        planner.dp_plan(dp_params_from_cfg(S.LatticeConfig("too_wide", row=257, col=3, sample_s=5.0, sample_l=0.05, sampling_res=2,
+        planner.dp_plan(dp_params_from_cfg(S.LatticeConfig("too_wide", row=1025, col=3, sample_s=5.0, sample_l=0.0125, sampling_res=2,
                                                            n_obs=0, n_ref=30)), b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
 
 
