@@ -279,12 +279,16 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     switch (d.row) {
         case 5: EMP_SWEEP_AUTO(5, 2); break;
         case 9:
-            if (variant == 1) EMP_SWEEP(9, 3, 1);
+            // (round 5: three columns in flight instead of two.  Alone the two are within noise of each other - 0.72-0.77 of the
+            // peak either way; beside the previous batch's Cartesian tail, where the sweep runs since EMP_OPT_SWEEP_EXCLUSIVE
+            // defaults to 0, the deeper ring holds 0.67-0.68 where the shallow one holds 0.65: six A/B pairs, tools/step_ab.sh)
+            if (variant == 1) EMP_SWEEP_AUTO(9, 2);
             else if (variant == 2) EMP_SWEEP(9, 4, 1);
             else if (variant == 3) EMP_SWEEP(9, 8, 1);
-            else if (variant == 4) EMP_SWEEP_NT(9, 2, 1, true);
-            else if (variant == 5) EMP_SWEEP_NT(9, 2, 1, false);
-            else EMP_SWEEP_AUTO(9, 2);
+            else if (variant == 4) EMP_SWEEP_NT(9, 3, 1, true);
+            else if (variant == 5) EMP_SWEEP_NT(9, 3, 1, false);
+            else if (nt) EMP_SWEEP_NT(9, 2, 1, true);         // from DRAM (32768 scenes) the shallow ring keeps 0.697 against 0.692
+            else EMP_SWEEP_NT(9, 3, 1, false);
             break;
         case 12: EMP_SWEEP_AUTO(12, 2); break;
         case 21: EMP_SWEEP_AUTO(21, 3); break;

@@ -212,8 +212,9 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
  *                                                             the 100 MHz reference counter at its first and last instruction
  *                                                             (emp_edge_probe reads the latest launch)
- *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto; 1/2/3: register ring 3/4/8 columns deep;
- *                                                             4/5: nontemporal / plain loads whatever the tensor's size
+ *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto (register ring 3 columns deep since round 5);
+ *                                                             1/2/3: ring 2/4/8 columns deep; 4/5: nontemporal / plain loads
+ *                                                             whatever the tensor's size
  *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
  *   EMP_OPT_ST_ORDER                1        tuning           speed DP: 1 heaviest scenes first, 0 input order (same results)
  *   EMP_OPT_SWEEP_EXCLUSIVE         0        tuning           staged pipeline, what the HBM-bound sweep of call k may run beside:
