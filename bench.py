@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--start-ahead", type=float, default=2.7,
                     help="planning start, metres ahead of the ego (scenes.BENCH_START_AHEAD = 2.7: off the reference-line nodes; 2.0 "
                          "puts it ON node 6 in three scenes of four - the batch rounds 1-4 benchmarked)")
+    ap.add_argument("--input-batches", type=int, default=0,
+                    help="resident input batches the steps rotate through (different scenes every step); 0 = 4 up to 8192 scenes per "
+                         "GPU, else 1")
     ap.add_argument("--arcs", choices=["gentle", "survey"], default="gentle",
                     help="arc radii of the reference lines: gentle = U(1500, 6000) m (default), survey = SURVEY 8(d)'s U(150, 1000) m")
     ap.add_argument("--latency", action="store_true", help="BASELINE configs[1]: one scene, synchronous calls")
@@ -288,16 +291,22 @@ def main():
     total = B * world
     start, count = emp_dist.shard_range(total, rank, world)
     scene_kw = scene_kwargs(args)
-    batch = S.make_batch(range(start, start + count), cfg, **scene_kw)
-    P = batch.ref.shape[1]
+    # DIFFERENT SCENES EVERY STEP: --input-batches resident batches (default 4 up to 8192 scenes per GPU, else 1), step i plans
+    # batch i mod n.  Batch b holds seeds [b * total, (b + 1) * total): batch 0 is the one the parity tests and sweeps cover.
+    n_in = args.input_batches if args.input_batches > 0 else (4 if B <= 8192 else 1)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-    inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(count, P, np.int32)), origin_xy=t(batch.origin_xy),
-                  start_xy=t(batch.start_xy), start_v=t(batch.start_v), start_a=t(batch.start_a),
-                  obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
-    st_inputs = None
-    if wide:    # the S-T half of configs[4]: 16 dynamic-obstacle slots per scene (reference speed_planning_test.py:38-188)
-        dyn = S.make_dynamic_batch(range(start, start + count), 16)
-        st_inputs = [t(a) for a in dyn[:4]], t(dyn[4])
+    inputs_ring, st_ring = [], []
+    for ib in range(n_in):
+        lo = ib * total + start
+        batch = S.make_batch(range(lo, lo + count), cfg, **scene_kw)
+        P = batch.ref.shape[1]
+        inputs_ring.append(dict(ref_line=t(batch.ref), n_ref=t(np.full(count, P, np.int32)), origin_xy=t(batch.origin_xy),
+                                start_xy=t(batch.start_xy), start_v=t(batch.start_v), start_a=t(batch.start_a),
+                                obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs)))
+        if wide:    # the S-T half of configs[4]: 16 dynamic-obstacle slots per scene (reference speed_planning_test.py:38-188)
+            dyn = S.make_dynamic_batch(range(lo, lo + count), 16)
+            st_ring.append(([t(a) for a in dyn[:4]], t(dyn[4])))
+    step_no = [0]
     torch.cuda.synchronize()
 
     pl = Planner(dev_index)
@@ -331,12 +340,14 @@ def main():
         # event: output allocation on the first; for N > 1 the records are packed on the stream on which the cycle's
         # results become complete (the step's lane when pipelined) and gathered over RCCL on a stream of its own, so that
         # the gather of step k overlaps the steps behind it.
+        ib = step_no[0] % n_in
+        step_no[0] += 1
         with torch.cuda.stream(ts):
-            res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs)
+            res = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs_ring[ib])
             if wide:      # the S-T half reads nothing of the cycle: it need not wait for the cycles in flight
                 pl.set_fence(False)
-                sets = pl.st_graph(*st_inputs[0])
-                pl.speed_dp(sdp, *sets, st_inputs[1], tables=False)
+                sets = pl.st_graph(*st_ring[ib][0])
+                pl.speed_dp(sdp, *sets, st_ring[ib][1], tables=False)
                 pl.set_fence(True)
         return sg.submit(res) if with_gather[0] else res, res
 
@@ -504,10 +515,17 @@ def main():
         legs["tight_corridor_leg"] = secondary_leg(pl, torch, S.CFG2, 4096, 10, 20, device, dict(tight, dist="corridor"))
         legs["host_io_leg"] = host_io_leg(pl, torch, S.CFG2, 4096, 60, scene_kw)
 
-    # outcome statistics of the last step (sanity: the work was really done); every rank looks at its own shard and the
-    # fractions are averaged over the ranks
-    stl = res.status.cpu().numpy()
-    ok_frac = float(((stl & ~1) == 0).mean())
+    # outcome statistics (sanity: the work was really done): the planned fraction of every input batch the steps rotate through
+    # (one more pass each, untimed); every rank looks at its own shard and the fractions are averaged over the ranks
+    fence()
+    pl.set_timing(False)
+    oks = []
+    for ib in range(n_in):
+        with torch.cuda.stream(ts):
+            r_ib = pl.plan_cycle(p, q, sp, max_pts=M, mode=mode, **inputs_ring[ib])
+        fence()
+        oks.append(float(((r_ib.status.cpu().numpy() & ~1) == 0).mean()))
+    ok_frac = float(np.mean(oks))
     if world > 1:
         okt = torch.tensor([ok_frac * count, float(count)], dtype=torch.float64, device=device)
         dist.all_reduce(okt)
@@ -626,7 +644,9 @@ def main():
                                    + ": full planning cycle per scene (projection, S-L DP, path QP, Frenet->Cartesian, "
                                      "smoothing QP, heading/kappa)" + (", then generate_st_graph + the S-T speed DP" if wide else "")
                                    + ", inputs resident in HBM" + gather_note,
-                       "scenes_per_gpu": count, "total_scenes": total, "lattice": f"col={cfg.col} x row={cfg.row}",
+                       "scenes_per_gpu": count, "total_scenes": total, "input_batches": n_in,
+                       "input_batches_note": "step i plans resident batch i mod input_batches: different scenes every step",
+                       "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
                        "scene_dist": args.scene_dist, "start_ahead_m": args.start_ahead, "arc_radii_m": list(scene_kw["radius_range"]),
                        "ref_line_points": int(P), "dp_mode": args.dp_mode,

@@ -58,9 +58,14 @@ if os.path.exists(trace_csv):
     except Exception:
         pass
     diag = 2 + min(steps, 5)
-    if untimed is not None and len(sw) == untimed + steps + diag:
+    extra = 0              # round 5: one more untimed pass per input batch behind the diagnostic pass (planned fractions)
+    try:
+        extra = int(json.loads(line)["config"].get("input_batches", 0))
+    except Exception:
+        pass
+    if untimed is not None and len(sw) == untimed + steps + diag + extra:
         dur = [(e - b) / 1e3 for b, e in sw]
-        timed, alone = dur[untimed:untimed + steps], dur[-min(steps, 5):]
+        timed, alone = dur[untimed:untimed + steps], dur[untimed + steps + 2:untimed + steps + diag]
         region = {"launches_in_trace": len(sw), "untimed": untimed, "timed_mean_us": sum(timed) / len(timed),
                   "timed_min_us": min(timed), "timed_max_us": max(timed), "alone_mean_us": sum(alone) / len(alone),
                   "all_mean_us": sum(dur) / len(dur)}
