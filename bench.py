@@ -504,6 +504,35 @@ def main():
                             "Cartesian tail: the HBM-bound kernel at its best, for two more barrier packets on the front queue"}
             except Exception as exc:
                 legs["exclusive_sweep_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # (a') the throughput-first form: three batches in flight on three lanes, every kernel overlapping whatever the other
+        # lanes run - the step ~9 % shorter, the sweep no longer on its own (its launches last twice as long)
+        try:
+            fence()
+            pl.set_timing(False)
+            pl.set_pipeline(3)
+            for _ in range(30):
+                step()
+            fence()
+            pl.set_timing(True, only="dp_sweep")
+            l0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            l_el = time.perf_counter() - l0
+            l_sweep = pl.kernel_ms("dp_sweep")
+            pl.set_timing(False)
+            pl.set_pipeline(0)
+            l_bytes = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * count
+            legs["lanes3_leg"] = {
+                "pipeline": "3 lanes (emp_set_pipeline(3))", "batches_in_flight": 3, "steps": args.steps,
+                "ms_per_step": round(l_el / args.steps * 1e3, 4), "all_scenes_cycles_per_s": round(total * args.steps / l_el, 1),
+                "sweep_mean_launch_us": round(l_sweep * 1e3, 2),
+                "sweep_frac": round(l_bytes / (l_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "each batch runs its six kernels in order on a stream of its own, three batches deep: no cross-queue waits, "
+                        "more overlap, a shorter step - and the HBM-bound sweep shares the chip with two edge-cost kernels.  The "
+                        "headline stays in the staged form, where the sweep's bandwidth is a property of the kernel"}
+        except Exception as exc:
+            legs["lanes3_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
         legs["gather_path_leg"] = gather_path_leg(pl, torch, emp_dist, S.CFG2, 4096, max(args.steps, 20), device, scene_kw)
         legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device, scene_kw)
         legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, scene_kw, speed=True)

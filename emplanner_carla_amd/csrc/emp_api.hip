@@ -6,6 +6,12 @@
 #include <algorithm>
 
 #include "emp_context.h"
+#ifndef EMP_QP_LDS_PAD
+#define EMP_QP_LDS_PAD 0       // development: the same for a path-QP wavefront
+#endif
+#ifndef EMP_EDGE_LDS_PAD
+#define EMP_EDGE_LDS_PAD 0     // development: extra (unused) dynamic LDS per edge-cost block, to measure what LDS room is worth
+#endif
 #include "emp_dp_kernels.h"
 #include "emp_st_kernels.h"
 #include "emp_st_backend_kernels.h"
@@ -87,12 +93,12 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // ([S][mask width] doubles, emp_dp_kernels.h: box_dx2)
     // EMP_OPT_EDGE_FORM: 0 (default) the work-ring kernel (emp_dp_kernels.h dp_edge_ring_kernel: edges with obstacles in reach are
     // queued per wavefront and scanned one entry per lane), 1 the lockstep kernel of rounds 1-4 - bit-identical tensors.  The ring
-    // form needs every obstacle of a row inside one 64-bit mask and the column index inside 16 bits; anything else is lockstep.
-    const bool ring = ctx->opt[EMP_OPT_EDGE_FORM] == 0 && d.max_obs <= 64 && d.col <= 65535;
+    // form needs every obstacle of a row inside one 64-bit mask and the column index inside 15 bits; anything else is lockstep.
+    const bool ring = ctx->opt[EMP_OPT_EDGE_FORM] == 0 && d.max_obs <= 64 && d.col <= kRingMaxCol;
     const bool m32 = d.max_obs <= 32;          // every obstacle of a row fits a 32-bit reach mask
-    const size_t lds_fixed = ring ? ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + 64) * sizeof(double)
-                                  : ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kTableTail) * sizeof(double);
-    const size_t lds_wave = ring ? 2 * (size_t)d.S * d.max_obs * sizeof(double) + (m32 ? sizeof(EdgeRing<unsigned>) : sizeof(EdgeRing<unsigned long long>))
+    const size_t lds_fixed = (ring ? ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + ((d.S + 1) & ~1)) * sizeof(double)
+                                   : ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kTableTail) * sizeof(double)) + EMP_EDGE_LDS_PAD;
+    const size_t lds_wave = ring ? 2 * (size_t)d.S * d.max_obs * sizeof(double) + (size_t)edge_ring_bytes(d.max_obs)
                                  : (size_t)d.S * (d.max_obs <= 32 ? d.max_obs : (d.max_obs < 64 ? d.max_obs : 64)) * sizeof(double);
     size_t lds = lds_fixed + 2 * lds_wave;        // the block-size rule below prices a two-wavefront block; the launch its own
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
@@ -116,16 +122,18 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         // as the LDS allows).  Small blocks matter in the staged step, where a block must find all its slots free at once beside
         // the previous batch's path-QP wavefronts: at 40 x 9 two-wavefront blocks give 0.241 ms per step, three 0.258, four 0.266,
         // eight 0.293 - although ALONE the kernel is fastest with four (profiles/r05_edge/README.md)
+        // (LDS is allocated in 1280-byte granules, 128 of them a CU)
+        auto blocks_per_cu = [](size_t l) { return (size_t)128 / ((l + 1279) / 1280); };
         int best = 0;
         for (int w = 2; w <= 16; ++w) {
             const size_t l = lds_fixed + (size_t)w * lds_wave;
             if (l > 160 * 1024) break;
-            best = std::max(best, (int)std::min<size_t>((160 * 1024 / l) * w, 20));
+            best = std::max(best, (int)std::min<size_t>(blocks_per_cu(l) * w, 20));
         }
         for (int w = 2; w <= 16; ++w) {
             const size_t l = lds_fixed + (size_t)w * lds_wave;
             if (l > 160 * 1024) break;
-            if ((int)std::min<size_t>((160 * 1024 / l) * w, 20) >= std::min(best, 16)) {
+            if ((int)std::min<size_t>(blocks_per_cu(l) * w, 20) >= std::min(best, 16)) {
                 wpb = w;
                 break;
             }
@@ -1061,8 +1069,9 @@ static int dev_cycle_qp(emp_ctx* ctx, int B, int max_pts, int max_obs, const QpD
     const bool pair_form = ctx->opt[EMP_OPT_PATH_QP_FORM] == 1;
     if (cap <= 66 && !pair_form) {                                    // 8 (4) scenes per wavefront on groups of 8 (16) lanes
         const int gp = cap <= 34 ? 8 : 16;
-        const size_t words = cap <= 26 ? path_qp_words_rows<8, 3>() : cap <= 34 ? path_qp_words_rows<8, 4>() : path_qp_words_rows<16, 4>();
-        const size_t per_wave = (size_t)(64 / gp) * ((size_t)5 * cap + 4 * (size_t)max_obs + words) * sizeof(double);
+        const size_t words = cap <= 26 ? cycle_qp_group_words<8, 3>(cap, max_obs) : cap <= 34 ? cycle_qp_group_words<8, 4>(cap, max_obs)
+                                                                                                : cycle_qp_group_words<16, 4>(cap, max_obs);
+        const size_t per_wave = (size_t)(64 / gp) * words * sizeof(double) + EMP_QP_LDS_PAD;
         auto kern = cap <= 26 ? cycle_qp_rows_kernel<8, 3> : cap <= 34 ? cycle_qp_rows_kernel<8, 4> : cycle_qp_rows_kernel<16, 4>;
         if ((rc = set_lds(ctx, kern, per_wave))) return rc;
         const int spw = 64 / gp;

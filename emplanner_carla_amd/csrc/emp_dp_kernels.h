@@ -361,12 +361,16 @@ __global__ __launch_bounds__(1024, EMP_EDGE_WAVES) void dp_edge_kernel(DpDev P, 
 // Capacity: a ring never holds more than 63 left-over + 64 pushed entries = 127 < kRingSlots.
 constexpr int kRingSlots = 128;
 
-template <typename MASK>
-struct EdgeRing {                        // per wavefront, in LDS
-    unsigned code[2][kRingSlots];        // (j << 16) | (k << 8) | owner lane
-    MASK mask[2][kRingSlots];            // obstacles of the owner's scene that passed the box test (ascending bit = ascending m)
-};                                       // (the edge's smoothness term is recomputed by the lane that pops the entry: 8 bytes
-                                         // per entry less - at 120 x 21 the 60 KB pair table leaves a wavefront 2.4 KB of LDS)
+// Per wavefront, in LDS: code[2][kRingSlots] (32 bits an entry: column j << 17 | source row k << 12 | obstacle m << 6 | owner
+// lane - the one-obstacle ring's entry IS its obstacle, it has no mask) and, for the several-obstacle ring only, one mask per
+// slot as wide as the scene's obstacle count needs (1, 2, 4 or 8 bytes: ascending bit = ascending m).  The edge's smoothness
+// term is recomputed by the lane that pops the entry.  LDS is what decides how many edge blocks sit beside the previous batch's
+// path-QP wavefronts in the staged step (allocated in 1280-byte granules, 128 a CU): the 40 x 9 lattice's two-wavefront block
+// is 14.4 KB = 12 granules, six of them fit beside two path-QP wavefronts (profiles/r05_edge/README.md 8).
+EMP_HD constexpr int edge_ring_mask_bytes(int max_obs) { return max_obs <= 8 ? 1 : max_obs <= 16 ? 2 : max_obs <= 32 ? 4 : 8; }
+EMP_HD constexpr int edge_ring_bytes(int max_obs) { return 2 * kRingSlots * 4 + kRingSlots * edge_ring_mask_bytes(max_obs); }
+// the code's fields: 32 rows (5 bits of k), 64 obstacles, 64 lanes, columns below 2^15
+constexpr int kRingMaxCol = 32767;
 
 #ifndef EMP_EDGE_RING_BOUNDS
 #define EMP_EDGE_RING_BOUNDS __launch_bounds__(1024, EMP_EDGE_WAVES)
@@ -391,9 +395,10 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     double* t_obs_s = lds + kTableFields * rr;          // [S][max_obs]
     double* t_obs_l = t_obs_s + P.S * P.max_obs;
     double* t_ps = t_obs_l + P.S * P.max_obs;           // [S] plan_start_s of the tile's scenes (S <= 64)
-    double* box_all = t_ps + 64;                        // per wavefront: [2][S][max_obs] lateral reach band of each obstacle in its column
+    double* box_all = t_ps + ((P.S + 1) & ~1);          // per wavefront: [2][S][max_obs] lateral reach band of each obstacle in its column
     const int waves = (int)(blockDim.x >> 6);
-    EdgeRing<MASK>* rings = reinterpret_cast<EdgeRing<MASK>*>(box_all + (size_t)waves * 2 * P.S * P.max_obs);
+    unsigned char* rings = reinterpret_cast<unsigned char*>(box_all + (size_t)waves * 2 * P.S * P.max_obs);
+    const int mask_bytes = edge_ring_mask_bytes(P.max_obs);
     const double* t_smp = pair_tab + kTableFields * rr; // sample offsets through the kernel argument: scalar registers
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
@@ -436,7 +441,20 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     const double* my_obs_l = t_obs_l + sl * P.max_obs;
     double* my_lo = box_all + ((size_t)(2 * wave) * P.S + sl) * P.max_obs;
     double* my_hi = my_lo + (size_t)P.S * P.max_obs;
-    EdgeRing<MASK>& R = rings[wave];
+    unsigned* r_code = reinterpret_cast<unsigned*>(rings + (size_t)wave * edge_ring_bytes(P.max_obs));   // [2][kRingSlots]
+    unsigned char* r_mask = reinterpret_cast<unsigned char*>(r_code + 2 * kRingSlots);                     // [kRingSlots] of mask_bytes
+    auto put_mask = [&](int slot, MASK v) {
+        if (mask_bytes == 1) r_mask[slot] = (unsigned char)v;
+        else if (mask_bytes == 2) reinterpret_cast<unsigned short*>(r_mask)[slot] = (unsigned short)v;
+        else if (mask_bytes == 4) reinterpret_cast<unsigned*>(r_mask)[slot] = (unsigned)v;
+        else reinterpret_cast<unsigned long long*>(r_mask)[slot] = (unsigned long long)v;
+    };
+    auto get_mask = [&](int slot) -> MASK {
+        if (mask_bytes == 1) return (MASK)r_mask[slot];
+        if (mask_bytes == 2) return (MASK) reinterpret_cast<const unsigned short*>(r_mask)[slot];
+        if (mask_bytes == 4) return (MASK) reinterpret_cast<const unsigned*>(r_mask)[slot];
+        return (MASK) reinterpret_cast<const unsigned long long*>(r_mask)[slot];
+    };
     int head[2] = {0, 0}, cnt[2] = {0, 0};                   // wave-uniform ring state
 
     auto store_edge = [&](int j, int k, int owner, double cost) {
@@ -452,9 +470,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
         const int n = min(cnt[c], 64);
         if (lane < n) {
             const int slot = (head[c] + lane) & (kRingSlots - 1);
-            const unsigned code = R.code[c][slot];
-            MASK rest = R.mask[c][slot];
-            const int owner = (int)(code & 63u), k = (int)((code >> 8) & 255u), j = (int)(code >> 16);
+            const unsigned code = r_code[c * kRingSlots + slot];
+            const int owner = (int)(code & 63u), k = (int)((code >> 12) & 31u), j = (int)(code >> 17);
             const int so = owner / row, io = owner - so * row;
             const int p = k * row + io;
             const double s0 = t_ps[so] + (double)j * P.sample_s;            // ref :330 pre_node_s
@@ -463,10 +480,10 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
             const double* o_l = t_obs_l + so * P.max_obs;
             double coll = 0.0;
             if (c == 0) {                                                     // exactly one obstacle in reach
-                const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
+                const int m = (int)((code >> 6) & 63u);
                 coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, o_s[m], o_l[m], P.w_coll);
             } else {
-                for (; rest; rest &= rest - 1) {                              // ascending m, as the reference
+                for (MASK rest = get_mask(slot); rest; rest &= rest - 1) {                              // ascending m, as the reference
                     const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
                     coll = coll + obstacle_scan_dense(s0, t_smp, &tab[p], rr, o_s[m], o_l[m], P.w_coll);
                 }
@@ -527,8 +544,9 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
                 const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0));
                 if (pass != 0) {
                     const int slot = ((one ? head[0] + cnt[0] : head[1] + cnt[1]) + before) & (kRingSlots - 1);
-                    R.code[c][slot] = ((unsigned)j << 16) | ((unsigned)k << 8) | (unsigned)lane;
-                    R.mask[c][slot] = pass;
+                    const int m1 = (kMaskBits == 32 ? __ffs((int)pass) : __ffsll((long long)pass)) - 1;
+                    r_code[c * kRingSlots + slot] = ((unsigned)j << 17) | ((unsigned)k << 12) | ((unsigned)(one ? m1 : 0) << 6) | (unsigned)lane;
+                    if (!one) put_mask(slot, pass);
                 }
                 cnt[0] += __popcll(b1);
                 cnt[1] += __popcll(b2);

@@ -426,9 +426,10 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                 EMP_QP_DEBUG_ROWS("R it %d rd %.3e rp %.3e mu %.3e zmax %.3e -> state %d acc %d\n", iters, rd_max, rp_max, mu, zmax, state, (int)acceptable);
             }
         }
-        if (run && acc_now) {                                 // remember the iterate the fallback exits return
-#pragma unroll
-            for (int r = 0; r < R; ++r) keep[base + r] = Q.u[base + r];
+        if (run && acc_now) {                                 // remember the iterate the fallback exits return (the problem's own
+#pragma unroll                                                // unknowns only: `keep` shares the coefficient slots, whose entries past N stay 0)
+            for (int r = 0; r < R; ++r)
+                if ((mmask >> r) & 1u) keep[base + r] = Q.u[base + r];
         }
         const bool go = state == 1;
         // ---- 3: factorisation
@@ -570,10 +571,12 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
     return state;
 }
 
-// doubles of LDS one problem of path_qp_group_rows<GP, R> needs: GP R + 4 coefficient slots (n + 2 of them are used), the
-// solver's arrays at capacity GP R and the last acceptable iterate
+// doubles of LDS one problem of path_qp_group_rows<GP, R> needs: GP R + 4 coefficient slots (n + 2 of them are used) and the
+// solver's arrays at capacity GP R
+// (round 5: the last acceptable iterate lives in the coefficient slots 3 .. GP R + 2, which hold nothing between the set-up - it
+// reads the three fixed start coefficients only - and the read-out that fills them from the final iterate: GP R doubles less)
 template <int GP, int R>
-__host__ __device__ constexpr int path_qp_words_rows() { return (GP * R + 4) + PathRangeQp::words_fast(GP * R, GP * R) + GP * R; }
+__host__ __device__ constexpr int path_qp_words_rows() { return (GP * R + 4) + PathRangeQp::words_fast(GP * R, GP * R); }
 
 // ---------------------------------------------------------------------------------------------
 // Path QP on one group of GP lanes (64 / GP scenes per wavefront); n <= GP R + 2 stations (GP = 8: R = 3: 26, R = 4: 34;
@@ -622,7 +625,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
     __syncthreads();
     ok = rc == 0;
     const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;
-    const int rs = path_qp_solve_rows<GP, R>(Q, gl, ok && Q.N > 0, cap_it, lds + kCc + PathRangeQp::words_fast(GP * R, GP * R));
+    const int rs = path_qp_solve_rows<GP, R>(Q, gl, ok && Q.N > 0, cap_it, cc + 3);
     if (ok && Q.N > 0) {
         *iters_out = Q.iters;
         if (rs && (debug_stage < 10 || !EMP_DEV_HOOKS)) rc = rs;   // a failed solve is never masked in a product build

@@ -589,6 +589,12 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 // dynamic LDS (doubles), per group: 5*cap + 4*max_obs + path_qp_words(cap)  (G = 32: + path_qp_words_pair() instead)
 // ---------------------------------------------------------------------------------------------
 // R > 0: eight scenes per wavefront (G = 8), R stations per lane (emp_qp_rows.h; cap <= 8 R + 2 stations).
+// doubles of LDS per group (scene)
+template <int G, int R = 0>
+__host__ __device__ constexpr int cycle_qp_group_words(int cap, int max_obs) {
+    if (R > 0) return path_qp_words_rows<(R > 0 ? G : 8), (R > 0 ? R : 3)>() + (4 * max_obs <= 4 * G * R ? 0 : 4 * max_obs);
+    return 5 * cap + 4 * max_obs + (G == 32 ? path_qp_words_pair() : path_qp_words(cap));
+}
 template <int G, int R = 0>
 __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, int cap, const QpDev& Q,
                                                            const double* __restrict__ dp_s,
@@ -607,16 +613,37 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
     const int b = blockIdx.x * GPW + grp;
     const bool present = b < B;
     static_assert(R == 0 || G == 8 || G == 16, "the rows solver runs on groups of 8 or 16 lanes");
-    const int per_group = 5 * cap + 4 * max_obs + (R > 0 ? path_qp_words_rows<(R > 0 ? G : 8), (R > 0 ? R : 3)>() : G == 32 ? path_qp_words_pair() : path_qp_words(cap));
+    const int per_group = cycle_qp_group_words<G, R>(cap, max_obs);
     double* lds = lds_all + (size_t)grp * per_group;
     const size_t o = (size_t)(present ? b : 0) * max_pts;
-    double* sd = lds;                 // decimated station s   [cap]
-    double* ld = sd + cap;            // decimated DP l        [cap]
-    double* lmin = ld + cap;          // [cap]
-    double* lmax = lmin + cap;        // [cap]
-    double* ql = lmax + cap;          // QP result l           [cap]
-    double* otab = ql + cap;          // per obstacle: lo, hi, below, bound   [4*max_obs]
-    double* qmem = otab + 4 * max_obs;
+    double* sd = lds;                 // decimated station s   [cap]  (rows form: see below)
+    double *ld, *lmin, *lmax, *ql, *otab, *qmem;
+    if constexpr (R > 0) {
+        // Rows form (round 5): a path-QP wavefront's LDS - eight scenes - is what bounds how many edge-cost blocks of the NEXT
+        // batch fit on its CU (measured: +1.2 us per staged step for every KB a QP wavefront holds, profiles/r05_edge/README.md 8).
+        // The arrays that are dead once the QP is set up live inside solver arrays that are not written before its first
+        // iteration: sd, ld, lmin, lmax in tmp | wgt (2 capS F + 4 F >= 4 cap: the station abscissae are re-read from device memory
+        // for the midpoints at the end), the QP's result ql - written after the last iteration - in rhs | dua (2 capN >= cap), the
+        // obstacle table in P.  Same values, same arithmetic; 5 cap + 4 max_obs doubles per scene less.
+        constexpr int capN = G * R, capS = G * R, kCc = G * R + 4;
+        qmem = lds;
+        double* qbase = qmem + kCc;                       // PathRangeQp::bind_fast(qbase, capN, capS, ...): P q u rhs dua c lo hi tmp wgt
+        ql = qbase + capN * 4 + capN * 2;                 // rhs | dua
+        sd = qbase + capN * 4 + capN * 4 + capS * 2 * 3;  // tmp | wgt | slack: sd, ld, lmin, lmax (4 cap <= 2 capS F + 4 F)
+        ld = sd + cap;
+        lmin = ld + cap;
+        lmax = lmin + cap;
+        // the obstacle table is dead before the QP is set up: it lives where the Hessian band P will be written (4 capN doubles),
+        // or behind the group's other arrays when the obstacle rows are wider than that
+        otab = 4 * max_obs <= 4 * capN ? qbase : qmem + path_qp_words_rows<G, R>();
+    } else {
+        ld = sd + cap;                // decimated DP l        [cap]
+        lmin = ld + cap;              // [cap]
+        lmax = lmin + cap;            // [cap]
+        ql = lmax + cap;              // QP result l           [cap]
+        otab = ql + cap;              // per obstacle: lo, hi, below, bound   [4*max_obs]
+        qmem = otab + 4 * max_obs;
+    }
     const int ne = present ? dp_len[b] : 0;
     const int dec = Q.decimate > 0 ? Q.decimate : 1;
     const int n = (ne + dec - 1) / dec;                                            // len(x[::dec])
@@ -685,24 +712,26 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         double* ps = path_s + o;
         double* pl = path_l + o;
         int plen = 0;
+        // station abscissa i: from LDS, or - rows form, where the solver has overwritten it - from the DP path again
+        auto sd_at = [&](int i) { return (R > 0 && Q.use_qp) ? dp_s[o + (size_t)i * dec] : sd[i]; };
         if (live) {
             if (Q.midpoint) {                                                      // ref test_9.py:204-210
                 for (int i = gl; i <= n; i += G) {
                     if (i == 0) {
-                        ps[0] = sd[0];
+                        ps[0] = sd_at(0);
                         pl[0] = ql[0];
                     } else if (i == n) {
-                        ps[n] = sd[n - 1];
+                        ps[n] = sd_at(n - 1);
                         pl[n] = ql[n - 1];
                     } else {
-                        ps[i] = (sd[i] + sd[i - 1]) / 2.0;
+                        ps[i] = (sd_at(i) + sd_at(i - 1)) / 2.0;
                         pl[i] = (ql[i] + ql[i - 1]) / 2.0;
                     }
                 }
                 plen = n + 1;
             } else {
                 for (int i = gl; i < n; i += G) {
-                    ps[i] = sd[i];
+                    ps[i] = sd_at(i);
                     pl[i] = ql[i];
                 }
                 plen = n;

@@ -87,6 +87,8 @@ def test_default_run_carries_the_secondary_legs():
     assert d["config"]["start_ahead_m"] == 2.7 and d["config"]["arc_radii_m"] == [1500.0, 6000.0]
     o = d["exclusive_sweep_leg"]
     assert "error" not in o and o["options"] == {"sweep_exclusive": 2} and o["all_scenes_cycles_per_s"] > 1e6 and 0.3 < o["sweep_frac"] < 1.0
+    l3 = d["lanes3_leg"]
+    assert "error" not in l3 and l3["batches_in_flight"] == 3 and l3["all_scenes_cycles_per_s"] > 1e6 and 0.05 < l3["sweep_frac"] < 1.0
     # SURVEY 8(d)'s own geometry, with its slalom layout (the reference refuses nearly everything) and with the corridor layout
     sv, tc = d["survey_leg"], d["tight_corridor_leg"]
     assert "error" not in sv and "error" not in tc, (sv, tc)
