@@ -22,7 +22,10 @@ Other lines (one JSON line per invocation, same keys):
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline      the DP min-plus sweep kernel (HBM bound): algorithmic bytes / mean HIP-event duration of its
-                launches INSIDE the timed region (the only kernel bracketed by events there); `traffic` = HBM bytes
+                launches INSIDE the timed region (the only kernel bracketed by events there).  The timed region runs three
+                batches on three lanes: the sweep shares the chip with two other batches' edge-cost kernels, so `frac` is the
+                schedule's figure; `frac_alone` (diagnostic pass), `staged_leg` and `exclusive_sweep_leg` are the kernel's.
+                `traffic` = HBM bytes
                 per launch from the rocprofv3 PMC passes named in `traffic_source`, or null when no profile of this
                 workload is committed
   cpu_baseline  the reference-structured CPU port (oracle/ref_port.py), one core, bounded sample
@@ -37,10 +40,11 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline_step   the whole step against the chip's vector-issue capacity: sum over the step's kernels of their VALU-busy
                 quad-cycles (committed SQ counter pass, source named) / (1024 SIMDs x clock / 4 x ms_per_step), with the measured
                 cost of a wave64 FP64 instruction (tools/fp64_pipe_bench.hip: 4.3 cycles, not the 4 the counter charges)
-  exclusive_sweep_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
+  staged_leg, exclusive_sweep_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
                 (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them) short secondary measurements after the
-                headline: the sweep held back behind the previous batch's path QP (EMP_OPT_SWEEP_EXCLUSIVE = 2: the sweep's
-                bandwidth at its best, the step 6 % slower); 32768 scenes (the edge tensor streams from HBM instead of the
+                headline: the staged pipeline of rounds 2-5 (two batches, front stage beside back stage: ~9 % longer steps, the
+                sweep beside the Cartesian tail only) and the same with the sweep held back behind the previous batch's path QP
+                (EMP_OPT_SWEEP_EXCLUSIVE = 2: the sweep's bandwidth at its best); 32768 scenes (the edge tensor streams from HBM instead of the
                 Infinity Cache); BASELINE configs[4] (120x21 lattice + S-T speed DP) on 4096 scenes; configs[1] (one scene per
                 synchronous call); SURVEY 8(d)'s own geometry (arc radii 150-1000 m) with its slalom layout and with the
                 corridor layout; the host path (NumPy arrays in and out through the page-locked ring, PCIe included); the
@@ -200,8 +204,39 @@ def scene_kwargs(args):
                 radius_range=S.SURVEY_ARCS if args.arcs == "survey" else S.GENTLE_ARCS)
 
 
+DEFAULT_PIPELINE = "3"      # --pipeline auto: three lanes (see main)
+
 from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, gather_path_leg, host_io_leg, latency_leg,  # noqa: E402
                         roofline_step, secondary_leg)
+
+
+def staged_subprocess_leg(steps, options):
+    """`python bench.py --pipeline staged --no-legs --no-cpu-baseline [--opt ...]` in a fresh process (this one waits, its GPU
+    work fenced): the staged form's step time and its sweep's launches, as that command prints them."""
+    import subprocess
+    t_leg = time.perf_counter()
+    cmd = [sys.executable, os.path.abspath(__file__), "--pipeline", "staged", "--no-legs", "--no-cpu-baseline", "--steps", str(steps),
+           "--warmup", "5"]
+    for k, v in options.items():
+        cmd += ["--opt", f"{k}={v}"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+        if out.returncode != 0:
+            return {"error": f"exit {out.returncode}: {out.stderr[-400:]}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+        d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        return {"pipeline": "staged (emp_set_pipeline(1)), a process of its own", "batches_in_flight": 2, "options": dict(options),
+                "steps": steps, "ms_per_step": d["ms_per_step"], "all_scenes_cycles_per_s": d["all_scenes_cycles_per_s"],
+                "fully_planned_cycles_per_s": d["value"],
+                "sweep_mean_launch_us": d["roofline"]["mean_launch_us"], "sweep_frac": d["roofline"]["frac"],
+                "sweep_frac_alone": d["roofline"]["frac_alone"],
+                "note": ("the sweep of step k waits (stream-side) for the densification and path QP of step k-1 and overlaps only the "
+                         "Cartesian tail: the HBM-bound kernel at its best" if options.get("sweep_exclusive") else
+                         "the headline's form until round 5: longer steps, the HBM-bound sweep beside nothing but the previous batch's "
+                         "Cartesian tail.  In the headline's three lanes the same sweep shares the chip with the edge-cost kernels of "
+                         "two other batches and its launches last about twice as long: that is the schedule, not the kernel"),
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
 
 
 def main():
@@ -225,7 +260,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="auto", help="emp_set_pipeline mode: 'staged' (two batches, back stage of one over "
                     "the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n lanes "
-                    "(a little more throughput, every kernel slower); 'auto' (default) = staged")
+                    "(more overlap: shorter steps, every kernel's own launches longer); 'auto' (default) = 3 lanes")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
     ap.add_argument("--settle-steps", type=int, default=-1, help="untimed steps before the timed region, warm-up included "
                     "(clock settling; 0 = only the --warmup steps; default: ~50 ms of work - 150 steps at 4096 scenes of "
@@ -316,8 +351,13 @@ def main():
     mode = L.EMP_DP_TWO_KERNEL if args.dp_mode == "two_kernel" else L.EMP_DP_FUSED
     # Several batches in flight (include/emplanner.h, emp_set_pipeline).  Every step is a complete pass over the batch;
     # the K timed steps are all finished at the closing fence.
+    # Default: three lanes - each batch runs its kernels in order on a stream of its own, three batches deep.  Until round 5 the
+    # headline was taken in the STAGED form (front stage of batch k+1 beside the back stage of batch k), which keeps the sweep
+    # nearly alone on the chip; lanes are the faster form on every workload measured (4096 scenes 0.220 -> 0.201 ms per step,
+    # 1024 scenes 0.19 -> 0.12, 8192 0.416 -> 0.368, 32768 1.47 -> 1.45, configs[4] the same), so they are what the headline
+    # runs - the staged form and its sweep are the `staged_leg` / `exclusive_sweep_leg` of the same line.
     if args.pipeline == "auto":
-        args.pipeline = "staged"      # (cfg5 until round 3: 2 lanes - the same 6.4 ms per step now, with the sweep at 0.39 instead of 0.71)
+        args.pipeline = DEFAULT_PIPELINE
     pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
     options = {}
     for kv in args.opt:
@@ -471,68 +511,14 @@ def main():
     # and its diagnostic pass; each is a short measurement of its own and never touches the headline's numbers
     legs = {}
     if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096)
-            and args.dp_mode == "two_kernel" and pmode == 1 and args.scene_dist == "corridor"):
-        # (a) the headline's steps with the sweep held back behind the previous batch's densification and path QP: the sweep's
-        # bandwidth at its best (the library's default until round 4), the step ~6 % slower
-        if "sweep_exclusive" not in options:
-            try:
-                fence()
-                pl.set_timing(False)
-                old_excl = pl.get_option("sweep_exclusive")
-                pl.set_option("sweep_exclusive", 2)
-                pl.set_pipeline(1)
-                for _ in range(60):
-                    step()
-                fence()
-                pl.set_timing(True, only="dp_sweep")
-                o0 = time.perf_counter()
-                for _ in range(args.steps):
-                    o_out, o_res = step()
-                fence()
-                o_el = time.perf_counter() - o0
-                o_sweep = pl.kernel_ms("dp_sweep")
-                pl.set_timing(False)
-                pl.set_option("sweep_exclusive", old_excl)
-                pl.set_pipeline(0)
-                o_bytes = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * count
-                legs["exclusive_sweep_leg"] = {
-                    "options": {"sweep_exclusive": 2}, "steps": args.steps, "ms_per_step": round(o_el / args.steps * 1e3, 4),
-                    "all_scenes_cycles_per_s": round(total * args.steps / o_el, 1),
-                    "sweep_mean_launch_us": round(o_sweep * 1e3, 2),
-                    "sweep_frac": round(o_bytes / (o_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "note": "the sweep of step k waits (stream-side) for the densification and path QP of step k-1 and overlaps only the "
-                            "Cartesian tail: the HBM-bound kernel at its best, for two more barrier packets on the front queue"}
-            except Exception as exc:
-                legs["exclusive_sweep_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
-        # (a') the throughput-first form: three batches in flight on three lanes, every kernel overlapping whatever the other
-        # lanes run - the step ~9 % shorter, the sweep no longer on its own (its launches last twice as long)
-        try:
-            fence()
-            pl.set_timing(False)
-            pl.set_pipeline(3)
-            for _ in range(30):
-                step()
-            fence()
-            pl.set_timing(True, only="dp_sweep")
-            l0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            fence()
-            l_el = time.perf_counter() - l0
-            l_sweep = pl.kernel_ms("dp_sweep")
-            pl.set_timing(False)
-            pl.set_pipeline(0)
-            l_bytes = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * count
-            legs["lanes3_leg"] = {
-                "pipeline": "3 lanes (emp_set_pipeline(3))", "batches_in_flight": 3, "steps": args.steps,
-                "ms_per_step": round(l_el / args.steps * 1e3, 4), "all_scenes_cycles_per_s": round(total * args.steps / l_el, 1),
-                "sweep_mean_launch_us": round(l_sweep * 1e3, 2),
-                "sweep_frac": round(l_bytes / (l_sweep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "each batch runs its six kernels in order on a stream of its own, three batches deep: no cross-queue waits, "
-                        "more overlap, a shorter step - and the HBM-bound sweep shares the chip with two edge-cost kernels.  The "
-                        "headline stays in the staged form, where the sweep's bandwidth is a property of the kernel"}
-        except Exception as exc:
-            legs["lanes3_leg"] = {"error": f"{type(exc).__name__}: {exc}"}
+            and args.dp_mode == "two_kernel" and args.pipeline == DEFAULT_PIPELINE and args.scene_dist == "corridor"):
+        # (a) the staged pipeline of rounds 2-5 (two batches: the front stage of one beside the back stage of the other; the sweep
+        # overlaps only the previous batch's Cartesian tail), with the library's default options and with the sweep held back
+        # behind the previous batch's path QP (EMP_OPT_SWEEP_EXCLUSIVE = 2).  Each in a process of its own: which hardware queue
+        # a stream lands on depends on the streams the process created before it, and a staged pipeline set up behind three lane
+        # streams finds its two stages on one queue (0.43 ms a step instead of 0.22) - a fresh process is what a staged user has.
+        legs["staged_leg"] = staged_subprocess_leg(args.steps, {})
+        legs["exclusive_sweep_leg"] = staged_subprocess_leg(args.steps, {"sweep_exclusive": 2})
         legs["gather_path_leg"] = gather_path_leg(pl, torch, emp_dist, S.CFG2, 4096, max(args.steps, 20), device, scene_kw)
         legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device, scene_kw)
         legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, scene_kw, speed=True)
@@ -682,7 +668,7 @@ def main():
                        "batches_in_flight": in_flight, "pipeline": "off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes",
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
-            "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3, speed=wide) if pmode == 1 else None),
+            "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3, speed=wide) if pmode != 0 else None),
             **extra,
             "kernels_ms": kernels,
             "alt_pipeline": alt,

@@ -20,6 +20,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LEG_PIPELINE = 3         # emp_set_pipeline mode of the secondary legs: three lanes, as the headline (bench.DEFAULT_PIPELINE)
 
 
 def committed_profile(kind, **match):
@@ -66,7 +67,7 @@ def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, scene_kw=None,
         p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
         sdp, M = speed_dp_params(), max_path_points(p)
         pl.set_timing(False)
-        pl.set_pipeline(1)
+        pl.set_pipeline(LEG_PIPELINE)
         ts = pl.torch_stream()
 
         def step():
@@ -110,7 +111,7 @@ def secondary_leg(pl, torch, cfg, scenes, steps, untimed, device, scene_kw=None,
         rate = scenes * steps / el
         out = {"workload": f"{scenes} scenes, lattice col={cfg.col} x row={cfg.row}, {cfg.n_obs} obstacles"
                            + (", + generate_st_graph and the S-T speed DP (40x16 grid, 16 dynamic-obstacle slots)" if speed else "")
-                           + "; full planning cycle, inputs resident in HBM, staged pipeline",
+                           + "; full planning cycle, inputs resident in HBM, three lanes",
                "steps": steps, "untimed_steps": untimed, "ms_per_step": round(el / steps * 1e3, 4),
                "fully_planned_cycles_per_s": round(rate * ok, 1), "all_scenes_cycles_per_s": round(rate, 1),
                "scenes_fully_planned_frac": round(ok, 4),
@@ -175,7 +176,7 @@ def latency_leg(pl, torch, device, calls=50, scene_kw=None):
 def host_io_leg(pl, torch, cfg, scenes, steps, scene_kw=None):
     """The host path inside the default run: NumPy arrays in, NumPy arrays out, PCIe included (reference boundary: Python
     lists per request, test_9.py:92-96, 220, 390-395).  Ordinary (pageable) input arrays are copied into the page-locked
-    ring (api.HostRing) with np.copyto, the cycle runs on the staged pipeline with its inputs on a copy stream and its outputs
+    ring (api.HostRing) with np.copyto, the cycle runs on the pipeline (three lanes) with its inputs on a copy stream and its outputs
     on a stream of their own, the results are read from the ring's page-locked output arrays.  Also the synchronous
     EMP_HOST path of rounds 1-4 (pageable arrays staged by the library, one call at a time), and one scene per call."""
     from emplanner_carla_amd import scenes as S
@@ -200,7 +201,7 @@ def host_io_leg(pl, torch, cfg, scenes, steps, scene_kw=None):
             r = pl.plan_cycle(p, q, sp, max_pts=M, **host)
         sync_ms = (time.perf_counter() - t0) / n_sync * 1e3
         in_bytes = sum(a.nbytes for a in host.values())
-        pl.set_pipeline(1)
+        pl.set_pipeline(LEG_PIPELINE)
         ring = pl.host_ring(p, scenes, P, cfg.n_obs, M)
         out_bytes = sum(a.nbytes for a in ring.slots[0].outputs.values())
         none8 = (None,) * 8
@@ -243,7 +244,7 @@ def host_io_leg(pl, torch, cfg, scenes, steps, scene_kw=None):
                               "fully_planned_cycles_per_s": round(scenes / ring_ms * 1e3 * ok, 1),
                               "pcie_gbs_both_directions": round((in_bytes + out_bytes) / ring_ms / 1e6, 1),
                               "how": "pageable NumPy inputs -> np.copyto into a page-locked ring slot -> emp_plan_cycle(EMP_HOST_PINNED) "
-                                     "on the staged pipeline (one H2D copy on the copy stream, one D2H copy on its own stream) -> "
+                                     "three batches deep (one H2D copy on the copy stream, one D2H copy on its own stream) -> "
                                      "results read in place from the slot's page-locked arrays"},
                 "host_ring_inputs_written_in_place": {"ms_per_step": round(inplace_ms, 4),
                                                       "all_scenes_cycles_per_s": round(scenes / inplace_ms * 1e3, 1)},
@@ -263,7 +264,7 @@ def host_io_leg(pl, torch, cfg, scenes, steps, scene_kw=None):
 
 
 def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=None, records="full"):
-    """The per-step code of an N > 1 rank on this one GPU (what `--force-gather-path` runs as a line of its own): the staged
+    """The per-step code of an N > 1 rank on this one GPU (what `--force-gather-path` runs as a line of its own): the
     step + record packing on the result stream + the gather on a stream of its own (the identity without a process group).
     No 2/4/8-GPU node has been available to any round: this leg, the gloo step-loop tests and the shard == slice tests are
     what stands in for the scaling run."""
@@ -276,7 +277,7 @@ def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=No
         p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
         M = max_path_points(p)
         pl.set_timing(False)
-        pl.set_pipeline(1)
+        pl.set_pipeline(LEG_PIPELINE)
         ts = pl.torch_stream()
         sg = emp_dist.StepGather(p.col, M, scenes, planner=pl, fields=records, device=device, dst=0, timing=True)
 
@@ -321,7 +322,7 @@ def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=No
         pl.set_pipeline(0)
         complete = bool(sg.unpack(out)["status"].shape[0] == scenes)
         bytes_dp = (8 * (cfg.row + (cfg.col - 1) * cfg.row ** 2) + 4 * cfg.row * cfg.col + 4 * cfg.col) * scenes
-        return {"workload": f"{scenes} scenes on ONE GPU through the N > 1 per-step code: staged cycle, {records} records packed on the "
+        return {"workload": f"{scenes} scenes on ONE GPU through the N > 1 per-step code: three lanes, {records} records packed on the "
                             "result stream, gather to rank 0 on its own stream (identity: one process)",
                 "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "ms_per_step_without_pack_and_gather": round(nog / steps * 1e3, 4),
                 "all_scenes_cycles_per_s": round(scenes * steps / el, 1),

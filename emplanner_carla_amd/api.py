@@ -421,6 +421,7 @@ class Planner:
                           "queues and serialise (emplanner_carla_amd._lib.configure_hw_queues() before HIP initialises)",
                           RuntimeWarning, stacklevel=2)
         self._check(self._lib.emp_set_pipeline(self._h, m))
+        self._torch_lane_streams = {}            # the library destroys the streams the new mode does not use
         self.pipe_mode = m
         self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)       # batches that overlap on the GPU
         self._retain = max(int(self._lib.emp_pipeline_depth(self._h)), self.in_flight)     # calls whose outputs stay referenced

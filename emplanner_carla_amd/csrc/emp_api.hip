@@ -98,7 +98,7 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     const bool m32 = d.max_obs <= 32;          // every obstacle of a row fits a 32-bit reach mask
     const size_t lds_fixed = (ring ? ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + ((d.S + 1) & ~1)) * sizeof(double)
                                    : ((size_t)kTableFields * d.row * d.row + 2 * (size_t)d.S * d.max_obs + kTableTail) * sizeof(double)) + EMP_EDGE_LDS_PAD;
-    const size_t lds_wave = ring ? 2 * (size_t)d.S * d.max_obs * sizeof(double) + (size_t)edge_ring_bytes(d.max_obs)
+    const size_t lds_wave = ring ? 2 * (size_t)d.S * d.max_obs * sizeof(double) + (size_t)edge_ring_bytes(d.max_obs) + 4 * (size_t)d.S * sizeof(double)
                                  : (size_t)d.S * (d.max_obs <= 32 ? d.max_obs : (d.max_obs < 64 ? d.max_obs : 64)) * sizeof(double);
     size_t lds = lds_fixed + 2 * lds_wave;        // the block-size rule below prices a two-wavefront block; the launch its own
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the LDS pair table");
@@ -164,6 +164,11 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     int cols_per_chunk = ncol > 0 ? (ncol + chunks - 1) / chunks : 1;
     cols_per_chunk = cols_per_chunk >= wpb ? (cols_per_chunk / wpb) * wpb : wpb;
     chunks = ncol > 0 ? (ncol + cols_per_chunk - 1) / cols_per_chunk : 1;
+    if (ring) {       // the ring form's jerk-factor table: [columns per wavefront][S] per wavefront (priced above with four columns, the most the rule below gives a wavefront)
+        const size_t cpw_final = (size_t)(cols_per_chunk + wpb - 1) / wpb;
+        lds = lds_fixed + (size_t)wpb * (lds_wave - 4 * (size_t)d.S * sizeof(double) + cpw_final * d.S * sizeof(double));
+        EMP_REQUIRE(ctx, lds <= 160 * 1024, "edge-cost block too large for the LDS");
+    }
     dim3 grid(d.tiles, chunks), block(eb);
     const double* pair_tab = nullptr;
     { const int prc = dp_pair_table(ctx, d, &pair_tab); if (prc) return prc; }
@@ -657,6 +662,19 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     EMP_HIP(ctx, (hipError_t)sync_all(ctx));
     const int m = mode < 0 ? 0 : mode;
     const int need = m == EMP_PIPELINE_STAGED ? emp_ctx::kStagedPools : m;
+    // Streams the new mode does not use go away (everything was drained above): a stream holds a share of one of the process's
+    // few hardware queues, and a staged pipeline set up while three lane streams of an earlier mode were still alive found its
+    // front and back stage on one queue - 0.43 ms a step instead of 0.22 (bench.py's staged legs behind the three-lane headline)
+    for (size_t i = 0; i < ctx->lanes.size(); ++i)
+        if (ctx->lanes[i].stream && (m == EMP_PIPELINE_STAGED || (int)i >= m)) {
+            EMP_HIP(ctx, hipStreamDestroy(ctx->lanes[i].stream));
+            ctx->lanes[i].stream = nullptr;
+        }
+    if (m != EMP_PIPELINE_STAGED && ctx->back_stream) {
+        EMP_HIP(ctx, hipStreamDestroy(ctx->back_stream));
+        ctx->back_stream = nullptr;
+        ctx->back_stream_cus = -1;
+    }
     if ((int)ctx->lanes.size() < need) ctx->lanes.resize(need);
     for (int i = 0; i < need; ++i) {
         emp_ctx::Lane& ln = ctx->lanes[i];

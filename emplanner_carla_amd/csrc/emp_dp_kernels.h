@@ -399,6 +399,10 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     const int waves = (int)(blockDim.x >> 6);
     unsigned char* rings = reinterpret_cast<unsigned char*>(box_all + (size_t)waves * 2 * P.S * P.max_obs);
     const int mask_bytes = edge_ring_mask_bytes(P.max_obs);
+    // behind the rings, per wavefront: the jerk factor F of each of its columns, [columns per wavefront][S] - computed once per
+    // (scene, column) in the dense pass, read back by whichever lane pops an entry of that column
+    const int cpw = (cols_per_chunk + waves - 1) / waves;
+    double* f_all = reinterpret_cast<double*>(rings + (size_t)waves * edge_ring_bytes(P.max_obs));
     const double* t_smp = pair_tab + kTableFields * rr; // sample offsets through the kernel argument: scalar registers
     const int tile = blockIdx.x;
     const int tid = threadIdx.x;
@@ -455,6 +459,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
         if (mask_bytes == 4) return (MASK) reinterpret_cast<const unsigned*>(r_mask)[slot];
         return (MASK) reinterpret_cast<const unsigned long long*>(r_mask)[slot];
     };
+    double* f_tab = f_all + (size_t)wave * cpw * P.S;
+    const float inv_waves = 1.0f / (float)waves;
     int head[2] = {0, 0}, cnt[2] = {0, 0};                   // wave-uniform ring state
 
     auto store_edge = [&](int j, int k, int owner, double cost) {
@@ -475,7 +481,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
             const int so = owner / row, io = owner - so * row;
             const int p = k * row + io;
             const double s0 = t_ps[so] + (double)j * P.sample_s;            // ref :330 pre_node_s
-            const double smooth = tab[kF_BASE * rr + p] + tab[kF_JERK * rr + p] * jerk_unit_sum(t_smp, s0);   // as the dense pass
+            const int it = __float2int_rn((float)(j - j_begin - wave) * inv_waves);       // the wavefront's it-th column (exact: small multiples)
+            const double smooth = tab[kF_BASE * rr + p] + tab[kF_JERK * rr + p] * f_tab[it * P.S + so];       // as the dense pass
             const double* o_s = t_obs_s + so * P.max_obs;
             const double* o_l = t_obs_l + so * P.max_obs;
             double coll = 0.0;
@@ -522,6 +529,7 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
         }
         __builtin_amdgcn_wave_barrier();
         const double F = jerk_unit_sum(t_smp, s0);                      // the column's jerk factor
+        if (live && i == 0) f_tab[((j - j_begin - wave) / waves) * P.S + s] = F;
         for (int k = 0; k < row; ++k) {
             const int p = k * row + i;
             MASK pass = 0;

@@ -20,26 +20,28 @@ def _run(*extra):
 
 
 @pytest.mark.parametrize("extra", [(), ("--no-pipeline",), ("--force-gather-path",), ("--force-gather-path", "--no-pipeline"),
-                                   ("--pipeline", "3"), ("--pipeline", "2", "--force-gather-path"), ("--alt-pipeline", "3")])
+                                   ("--pipeline", "staged"), ("--pipeline", "2", "--force-gather-path"), ("--alt-pipeline", "staged")])
 def test_bench_line(extra):
     d = _run(*extra)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["dtype"] == "f64" and d["vs_baseline"] is None
-    lanes = int(extra[extra.index("--pipeline") + 1]) if "--pipeline" in extra else 0
+    pipe = extra[extra.index("--pipeline") + 1] if "--pipeline" in extra else "3"       # bench.DEFAULT_PIPELINE
+    lanes = 0 if pipe == "staged" else int(pipe)
     # (lane mode overlaps the sweep with other batches' edge kernels: it takes two to three times as long there)
     assert d["value"] > 1e6 and (0.05 if lanes else 0.3) < d["roofline"]["frac"] < 1.0 and d["roofline"]["bound"] == "hbm"
     assert 0.8 < d["scenes_fully_planned_frac"] < 0.95
     # `value` is the fully planned rate: scenes per step x planned fraction / step time
     assert abs(d["value"] - d["all_scenes_cycles_per_s"] * d["scenes_fully_planned_frac"]) <= 1e-3 * d["value"]
     assert abs(d["all_scenes_cycles_per_s"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 2e-3 * d["all_scenes_cycles_per_s"]
-    assert d["roofline"]["frac_alone"] > 0.3 and len(d["roofline"]["launch_us_min_median_max"]) == 3
+    # (with the gather path the diagnostic pass still packs and gathers every step: the "alone" sweep has the copy kernels beside it)
+    assert d["roofline"]["frac_alone"] > (0.15 if "--force-gather-path" in extra else 0.3) and len(d["roofline"]["launch_us_min_median_max"]) == 3
     assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else lanes or 2)
     assert d["config"]["pipeline"] == ("off" if "--no-pipeline" in extra else f"{lanes} lanes" if lanes else "staged")
-    if "--alt-pipeline" in extra:      # the second timed region, in lane mode
+    if "--alt-pipeline" in extra:      # the second timed region, in the staged form
         alt = d["alt_pipeline"]
-        assert alt["pipeline"] == "3 lanes" and alt["all_scenes_cycles_per_s"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
+        assert alt["pipeline"] == "staged" and alt["all_scenes_cycles_per_s"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
     else:
         assert d["alt_pipeline"] is None
 
@@ -87,8 +89,11 @@ def test_default_run_carries_the_secondary_legs():
     assert d["config"]["start_ahead_m"] == 2.7 and d["config"]["arc_radii_m"] == [1500.0, 6000.0]
     o = d["exclusive_sweep_leg"]
     assert "error" not in o and o["options"] == {"sweep_exclusive": 2} and o["all_scenes_cycles_per_s"] > 1e6 and 0.3 < o["sweep_frac"] < 1.0
-    l3 = d["lanes3_leg"]
-    assert "error" not in l3 and l3["batches_in_flight"] == 3 and l3["all_scenes_cycles_per_s"] > 1e6 and 0.05 < l3["sweep_frac"] < 1.0
+    # the headline runs three lanes; the staged form of rounds 2-5 is a leg in a process of its own, its sweep nearly alone
+    sl = d["staged_leg"]
+    assert d["config"]["pipeline"] == "3 lanes" and d["roofline_step"] is not None
+    assert "error" not in sl and sl["batches_in_flight"] == 2 and sl["options"] == {} and sl["all_scenes_cycles_per_s"] > 1e6
+    assert 0.3 < sl["sweep_frac"] < 1.0 and sl["sweep_frac"] > d["roofline"]["frac"]
     # SURVEY 8(d)'s own geometry, with its slalom layout (the reference refuses nearly everything) and with the corridor layout
     sv, tc = d["survey_leg"], d["tight_corridor_leg"]
     assert "error" not in sv and "error" not in tc, (sv, tc)
@@ -106,14 +111,16 @@ def test_default_run_carries_the_secondary_legs():
     gp = d["gather_path_leg"]
     assert "error" not in gp, gp
     assert gp["records_complete"] is True and gp["doubles_per_scene"] == 179 and gp["bytes_sent_per_rank_and_step"] == 4096 * 179 * 8
-    assert gp["ms_per_step"] > 0 and gp["ms_per_step_without_pack_and_gather"] > 0 and gp["pack_kernel_us"] > 0 and 0.1 < gp["sweep_frac"] < 1.0
+    assert gp["ms_per_step"] > 0 and gp["ms_per_step_without_pack_and_gather"] > 0 and gp["pack_kernel_us"] > 0 and 0.05 < gp["sweep_frac"] < 1.0
     g = d["dram_leg"]
     assert "error" not in g, g
-    assert g["ms_per_step"] > 4 * d["ms_per_step"] and 0.4 < g["sweep"]["frac"] < 1.0 and g["sweep"]["algorithmic_bytes_per_launch"] == 26944 * 32768
+    # (three lanes: the sweep streams its 883 MB from DRAM beside two other batches' edge kernels; alone it keeps its bandwidth)
+    assert g["ms_per_step"] > 4 * d["ms_per_step"] and 0.15 < g["sweep"]["frac"] < 1.0 and g["sweep"]["frac_alone"] > 0.4
+    assert g["sweep"]["algorithmic_bytes_per_launch"] == 26944 * 32768
     assert 0.8 < g["scenes_fully_planned_frac"] < 0.95
     c = d["cfg5_leg"]
     assert "error" not in c, c
-    assert c["speed_dp_us"] > 100 and 0.3 < c["sweep"]["frac"] < 1.0 and c["all_scenes_cycles_per_s"] > 1e5
+    assert c["speed_dp_us"] > 100 and 0.15 < c["sweep"]["frac"] < 1.0 and c["all_scenes_cycles_per_s"] > 1e5
     lat = d["latency_leg"]
     assert "error" not in lat and 0.05 < lat["ms_per_cycle_median"] < 5.0 and lat["calls"] == 50
 
@@ -135,8 +142,8 @@ def test_bench_two_ranks_without_gather_separates_compute_scaling():
     assert d["n_gpus"] == 2 and d["gather"]["mode"] == "none" and d["rccl_world_size"] == 2 and d["value"] > 1e4
 
 
-@pytest.mark.parametrize("extra", [("--gather", "rank0"), ("--gather", "all", "--records", "trajectory"), ("--pipeline", "3")],
-                         ids=["gather_rank0", "all_gather_trajectory", "three_lanes"])
+@pytest.mark.parametrize("extra", [("--gather", "rank0"), ("--gather", "all", "--records", "trajectory"), ("--pipeline", "staged")],
+                         ids=["gather_rank0", "all_gather_trajectory", "staged"])
 def test_bench_two_ranks_on_one_gpu(extra):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks on the
     one GPU and gloo instead of RCCL (EMP_BENCH_BACKEND: RCCL refuses two ranks on a device): shards, the per-step pack on
