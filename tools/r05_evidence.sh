@@ -6,11 +6,12 @@ mkdir -p gpurun_out/r05e
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05e/bench_default_s20.json 2> gpurun_out/r05e/bench_default_s20.err
 python bench.py > gpurun_out/r05e/bench_default.json 2> gpurun_out/r05e/bench_default.err
-python bench.py --opt sweep_exclusive=2 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_exclusive_sweep.json 2>/dev/null
+python bench.py --pipeline staged --opt sweep_exclusive=2 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_exclusive_sweep.json 2>/dev/null
 python bench.py --opt edge_form=1 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_lockstep_edge.json 2>/dev/null
 python bench.py --start-ahead 2.0 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_on_node_batch.json 2>/dev/null
 python bench.py --no-pipeline --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_one_batch.json 2>/dev/null
-python bench.py --pipeline 3 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_lanes3.json 2>/dev/null
+python bench.py --pipeline staged --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_staged.json 2>/dev/null
+python bench.py --pipeline 6 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_lanes6.json 2>/dev/null
 python bench.py --force-gather-path --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_gather_path.json 2>/dev/null
 python bench.py --latency > gpurun_out/r05e/bench_latency.json 2>/dev/null
 python bench.py --config cfg5 --steps 20 --warmup 3 > gpurun_out/r05e/bench_cfg5.json 2> gpurun_out/r05e/bench_cfg5.err
