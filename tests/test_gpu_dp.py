@@ -252,13 +252,14 @@ def test_soft_cost_quotient_is_ieee_division_on_its_whole_range(tmp_path):
 
 @pytest.mark.parametrize("shape", [(9, 40, 2.5, 1.5, 8, 8, 45), (21, 30, 1.0, 0.6, 16, 16, 11), (12, 6, 15.0, 1.5, 3, 3, 17),
                                    (5, 20, 5.0, 1.0, 0, 1, 25), (7, 11, 4.5, 1.0, 6, 40, 19), (9, 12, 2.5, 1.5, 40, 40, 15),
-                                   (9, 9, 2.5, 1.5, 70, 70, 9), (3, 5, 7.5, 1.5, 2, 2, 43), (32, 4, 5.0, 0.4, 5, 5, 5)],
+                                   (9, 9, 2.5, 1.5, 70, 70, 9), (3, 5, 7.5, 1.5, 2, 2, 43), (32, 4, 5.0, 0.4, 5, 5, 5), (9, 10, 2.5, 1.5, 24, 24, 15)],
                          ids=lambda s: f"{s[1]}x{s[0]}_{s[4]}of{s[5]}obs")
 def test_edge_ring_form_is_bit_identical_to_the_lockstep_form(planner, shape):
     """EMP_OPT_EDGE_FORM: the work-ring edge kernel (default; emp_dp_kernels.h dp_edge_ring_kernel) against the lockstep kernel
     of rounds 1-4, both layouts: compiled and generic row counts, ragged last tiles, 32- and 64-bit obstacle masks, obstacle rows
     wider than a mask (the ring form then hands over to the lockstep kernel), no obstacles at all, one tile's worth of scenes and
-    fewer.  Obstacles are packed densely (several per metre) so that the multi-obstacle ring fills as well."""
+    fewer.  Obstacles are packed densely (several per metre) so that the multi-obstacle ring fills as well; the obstacle counts
+    cover every width of the ring's mask (1, 2, 4 and 8 bytes: up to 8, 16, 32 and 64 obstacle slots)."""
     from emplanner_carla_amd import _lib as L
     from emplanner_carla_amd.api import dp_params
     row, col, ss, sl, n_obs, max_obs, B = shape
