@@ -164,7 +164,7 @@ def main():
         report["dp"] = {"config": cfg.name, "scenes": N_DP, "mismatching": bad, "dp_infeasible_scenes": infeasible, "seconds": round(time.time() - t0, 1)}
         print("DP  ", json.dumps(report["dp"]), flush=True)
     # ---- whole cycle against the port (SWEEP_CYCLE_CFG = cfg2 (default) | default | cfg1 picks the lattice)
-    if "cycle" in PARTS:
+    if "cycle" in PARTS and N_CY > 0:
         t0 = time.time()
         cfg = _cycle_cfg()
         p = dp_params_from_cfg(cfg)
