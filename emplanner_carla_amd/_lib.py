@@ -42,9 +42,10 @@ EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 # emp_option (include/emplanner.h): per-context tuning / A-B / test-hook values - the library reads no environment variable
 OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
            "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9,
-           "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15}
+           "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15,
+           "lane_edge_order": 16}
 #: the values a fresh context holds (everything else is 0)
-OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1}
+OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1, "lane_edge_order": 2}
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2

@@ -210,6 +210,12 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         EMP_HIP(ctx, hipEventRecord(ctx->edge_probe_done, ctx->stream));
         return EMP_OK;
     }
+    // EMP_OPT_LANE_EDGE_ORDER (lane mode): this edge kernel starts when the previous call's, on another lane, is done - the
+    // lanes' FP64-bound kernels take turns instead of running two or three at a time, and the HBM-bound sweep behind each of them
+    // has one of them beside it, not two (measured: include/emplanner.h).  Pure ordering: results do not depend on it.
+    const int leo = ctx->opt[EMP_OPT_LANE_EDGE_ORDER];
+    const bool ordered = ctx->pipe_mode >= 2 && ctx->active_lane >= 0 && (leo == 1 || (leo == 2 && d.B >= 4096));
+    if (ordered && ctx->lane_edge_done) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_edge_done, 0));
     KernelTimer t(ctx, "dp_edge");
     if (ring) {
         hipLaunchKernelGGL(kern_ring, grid, block, lds, ctx->stream, d, pair_tab, obs_s, obs_l, n_obs, start, start_cost, edge,
@@ -219,6 +225,12 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
                            cols_per_chunk);
     }
     EMP_LAUNCH_CHECK(ctx);
+    if (ordered) {
+        emp_ctx::Lane& ln = ctx->lanes[ctx->active_lane];
+        if (!ln.ev_edge) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_edge, hipEventDisableTiming));
+        ctx->lane_edge_done = ln.ev_edge;
+        EMP_HIP(ctx, hipEventRecord(ctx->lane_edge_done, ctx->stream));
+    }
     return EMP_OK;
 }
 
@@ -497,6 +509,7 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_in) (void)hipEventDestroy(ln.ev_in);
         if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
         if (ln.ev_front) (void)hipEventDestroy(ln.ev_front);
+        if (ln.ev_edge) (void)hipEventDestroy(ln.ev_edge);
         if (ln.ev_tail) (void)hipEventDestroy(ln.ev_tail);
         if (ln.ev_qp) (void)hipEventDestroy(ln.ev_qp);
         if (ln.ev_enrich) (void)hipEventDestroy(ln.ev_enrich);
@@ -711,6 +724,7 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         ctx->back_stream_cus = want_cus;
     }
     for (auto& ln : ctx->lanes) ln.done_valid = ln.qp_valid = ln.enrich_valid = false;       // everything was drained above
+    ctx->lane_edge_done = nullptr;
     ctx->pipe_mode = m;
     ctx->lane = 0;
     return EMP_OK;
@@ -742,6 +756,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_EDGE_FORM:
         case EMP_OPT_EDGE_CLOCK_PROBE:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
+        case EMP_OPT_LANE_EDGE_ORDER:
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
         case EMP_OPT_SWEEP_VARIANT: ok = value >= 0 && value <= 5; break;

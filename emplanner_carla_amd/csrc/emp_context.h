@@ -67,6 +67,7 @@ struct emp_ctx {
         uint64_t ticket = 0;            // emp_cycle_ticket of the lane's latest cycle
         hipEvent_t ev_qp = nullptr;     // STAGED: end of the cycle's path QP on the back stream (EMP_OPT_SWEEP_EXCLUSIVE = 2)
         hipEvent_t ev_enrich = nullptr; // STAGED: end of the cycle's densification kernel on the back stream (EMP_OPT_EDGE_AFTER_ENRICH)
+        hipEvent_t ev_edge = nullptr;   // LANES: end of the cycle's edge-cost kernel (EMP_OPT_LANE_EDGE_ORDER)
         bool done_valid = false, qp_valid = false, enrich_valid = false;
         std::vector<Buf> pool;
     };
@@ -93,8 +94,9 @@ struct emp_ctx {
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
-    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0};
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 2};
     hipEvent_t edge_wait = nullptr;     // EMP_OPT_EDGE_AFTER_ENRICH: what the next edge-cost launch waits for on its stream
+    hipEvent_t lane_edge_done = nullptr; // EMP_OPT_LANE_EDGE_ORDER: recorded behind the latest edge-cost launch of a lane-mode call (a lane's ev_edge)
     // STAGED: an event the next densification / path-QP launch is asked to signal from its own dispatch (hipExtLaunchKernelGGL's
     // stop event) instead of a marker packet behind it - a marker idles the back queue ~6 us, twice per step; `stop_attached`
     // says whether the launcher did (it does not while the kernel carries timing events)

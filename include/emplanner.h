@@ -182,7 +182,7 @@ int emp_pipeline_depth(emp_ctx* ctx);
  * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
 int emp_set_fence(emp_ctx* ctx, int enabled);
 
-/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE: version 10) ---------------------------------------------------------------------------------------
+/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE, EMP_OPT_LANE_EDGE_ORDER: version 10) ---------------------------------------------------------------------------------------
  * The library reads NO environment variable.  Everything that used to be an EMP_* environment switch of the development
  * builds is a per-context option here, set by the host program before the calls it should affect (a change takes effect
  * at the next call; EMP_OPT_BACK_STREAM_CUS at the next emp_set_pipeline).  Unknown options and values out of range are
@@ -209,6 +209,15 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
  *                                                             obstacle rows wider than 64 slots always take the lockstep form
  *   EMP_OPT_EDGE_COLS_PER_WAVE      0        tuning           lattice columns a wavefront of the edge-cost kernel takes; 0: auto
+ *   EMP_OPT_LANE_EDGE_ORDER         2        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
+ *                                                             when the previous call's - on another lane - is done, so that at most
+ *                                                             one of them runs at a time and the sweep that follows one has a single
+ *                                                             edge kernel beside it instead of two (one stream-side wait per call);
+ *                                                             0 = lanes are not ordered among each other; 2 (default) = 1 for calls
+ *                                                             of 4096 scenes and more, where it measured faster or equal (32 768
+ *                                                             scenes of the 40 x 9 lattice: 1.47 -> 1.36 ms per step, the sweep at
+ *                                                             0.53 of the HBM peak instead of 0.31; 4096: the same step, 0.43
+ *                                                             instead of 0.36), 0 below (1024 scenes: 0.116 against 0.121 ms)
  *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
  *                                                             the 100 MHz reference counter at its first and last instruction
  *                                                             (emp_edge_probe reads the latest launch)
@@ -262,7 +271,8 @@ typedef enum emp_option {
     EMP_OPT_EDGE_FORM = 13,
     EMP_OPT_EDGE_COLS_PER_WAVE = 14,
     EMP_OPT_EDGE_CLOCK_PROBE = 15,
-    EMP_OPT_COUNT = 16
+    EMP_OPT_LANE_EDGE_ORDER = 16,
+    EMP_OPT_COUNT = 17
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);

@@ -745,6 +745,45 @@ def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner, opti
             planner.set_option(k, v)
 
 
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_lane_edge_order_changes_no_result(planner, order):
+    """EMP_OPT_LANE_EDGE_ORDER (lane mode: the edge-cost kernel of a call waits for the previous call's, which ran on another
+    lane): consecutive calls on DIFFERENT batches on three lanes, with the sweep's timing events on as in bench.py, equal the
+    plain calls bit for bit under every value (2, the default, orders calls of 4096 scenes and more - both sizes are run)."""
+    import torch
+    cfg = S.CFG2
+    p, q, sp = _params(cfg)
+    dev = torch.device("cuda:0")
+    old = planner.get_option("lane_edge_order")
+    try:
+        for n in (1024, 4096):
+            batches = []
+            for k in range(5):
+                b = S.make_batch(range(7000 + 5000 * k, 7000 + 5000 * k + n), cfg, **BENCH)
+                batches.append({kk: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for kk, v in _host_inputs(b).items()})
+            torch.cuda.synchronize()
+            plain = []
+            for ins in batches:
+                r = planner.plan_cycle(p, q, sp, **ins)
+                planner.synchronize()
+                plain.append({k: getattr(r, k).cpu().numpy() for k in OUTPUTS})
+            planner.set_option("lane_edge_order", order)
+            planner.set_pipeline(3)
+            planner.set_timing(True, only="dp_sweep")
+            for rep in range(2):
+                with torch.cuda.stream(planner.torch_stream()):
+                    res = [planner.plan_cycle(p, q, sp, **ins) for ins in batches]
+                planner.synchronize()
+                for k, r in enumerate(res):
+                    _assert_same(plain[k], {kk: getattr(r, kk).cpu().numpy() for kk in OUTPUTS}, f"{n} scenes, lane call {k}, round {rep}")
+            planner.set_timing(False)
+            planner.set_pipeline(False)
+    finally:
+        planner.set_timing(False)
+        planner.set_pipeline(False)
+        planner.set_option("lane_edge_order", old)
+
+
 def test_measurement_entry_points_of_the_sweep(planner):
     """emp_kernel_samples (the per-launch durations behind emp_kernel_ms) and the in-kernel clock probe
     (EMP_OPT_SWEEP_CLOCK_PROBE: emp_sweep_clock_mhz, emp_sweep_probe_spans) on staged steps of 2048 scenes: one sample per

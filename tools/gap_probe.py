@@ -15,9 +15,12 @@ inputs = dict(ref_line=t(batch.ref), n_ref=t(np.full(B, P, np.int32)), origin_xy
               start_v=t(batch.start_v), start_a=t(batch.start_a), obs_xy=t(batch.obs_xy), n_obs=t(batch.n_obs))
 p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
 M = max_path_points(p); pl = Planner(0)
+pipe = 1                                     # pipeline=N: N lanes instead of the staged form
 for kv in sys.argv[1:]:                      # name=value options (emp_set_option) before the pipeline is set up
-    k, v = kv.split("="); pl.set_option(k, int(v))
-pl.set_pipeline(1); ts = pl.torch_stream()
+    k, v = kv.split("=")
+    if k == "pipeline": pipe = int(v)
+    else: pl.set_option(k, int(v))
+pl.set_pipeline(pipe); ts = pl.torch_stream()
 def step():
     with torch.cuda.stream(ts):
         return pl.plan_cycle(p, q, sp, max_pts=M, mode=L.EMP_DP_TWO_KERNEL, **inputs)
