@@ -45,7 +45,7 @@ OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "
            "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15,
            "lane_edge_order": 16}
 #: the values a fresh context holds (everything else is 0)
-OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1, "lane_edge_order": 2}
+OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1}
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2

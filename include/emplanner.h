@@ -209,15 +209,17 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
  *                                                             obstacle rows wider than 64 slots always take the lockstep form
  *   EMP_OPT_EDGE_COLS_PER_WAVE      0        tuning           lattice columns a wavefront of the edge-cost kernel takes; 0: auto
- *   EMP_OPT_LANE_EDGE_ORDER         2        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
+ *   EMP_OPT_LANE_EDGE_ORDER         0        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
  *                                                             when the previous call's - on another lane - is done, so that at most
  *                                                             one of them runs at a time and the sweep that follows one has a single
  *                                                             edge kernel beside it instead of two (one stream-side wait per call);
- *                                                             0 = lanes are not ordered among each other; 2 (default) = 1 for calls
- *                                                             of 4096 scenes and more, where it measured faster or equal (32 768
- *                                                             scenes of the 40 x 9 lattice: 1.47 -> 1.36 ms per step, the sweep at
- *                                                             0.53 of the HBM peak instead of 0.31; 4096: the same step, 0.43
- *                                                             instead of 0.36), 0 below (1024 scenes: 0.116 against 0.121 ms)
+ *                                                             2 = 1 for calls of 4096 scenes and more; 0 (default) = lanes are not
+ *                                                             ordered among each other.  Worth setting for big batches of ordinary
+ *                                                             scenes (32 768 scenes of the 40 x 9 lattice: 1.47 -> 1.36 ms per step,
+ *                                                             the sweep at 0.53 of the HBM peak instead of 0.31; 4096: the same step,
+ *                                                             0.42 instead of 0.36) - and NOT where the edge kernel is most of a
+ *                                                             call (every obstacle beside the same columns: 0.18 -> 0.23 ms), which
+ *                                                             is why it is not the default
  *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
  *                                                             the 100 MHz reference counter at its first and last instruction
  *                                                             (emp_edge_probe reads the latest launch)

@@ -749,7 +749,7 @@ def test_staged_handoff_holds_when_the_sweep_carries_timing_events(planner, opti
 def test_lane_edge_order_changes_no_result(planner, order):
     """EMP_OPT_LANE_EDGE_ORDER (lane mode: the edge-cost kernel of a call waits for the previous call's, which ran on another
     lane): consecutive calls on DIFFERENT batches on three lanes, with the sweep's timing events on as in bench.py, equal the
-    plain calls bit for bit under every value (2, the default, orders calls of 4096 scenes and more - both sizes are run)."""
+    plain calls bit for bit under every value (0 is the default; 2 orders calls of 4096 scenes and more - both sizes are run)."""
     import torch
     cfg = S.CFG2
     p, q, sp = _params(cfg)

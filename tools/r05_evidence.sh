@@ -25,6 +25,8 @@ python bench.py --start-ahead 2.0 --no-cpu-baseline --no-legs > gpurun_out/r05e/
 python bench.py --no-pipeline --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_one_batch.json 2>/dev/null
 python bench.py --pipeline staged --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_staged.json 2>/dev/null
 python bench.py --pipeline 6 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_lanes6.json 2>/dev/null
+python bench.py --opt lane_edge_order=1 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_lane_edge_order.json 2>/dev/null
+python bench.py --opt lane_edge_order=1 --scenes-per-gpu 32768 --steps 30 --warmup 5 --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_32768_lane_edge_order.json 2>/dev/null
 python bench.py --force-gather-path --no-cpu-baseline --no-legs > gpurun_out/r05e/bench_gather_path.json 2>/dev/null
 python bench.py --latency > gpurun_out/r05e/bench_latency.json 2>/dev/null
 python bench.py --config cfg5 --steps 20 --warmup 3 > gpurun_out/r05e/bench_cfg5.json 2> gpurun_out/r05e/bench_cfg5.err
