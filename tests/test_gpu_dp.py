@@ -196,6 +196,27 @@ def test_cfg5_wide_lattice_matches_exact_oracle(planner):
         assert np.array_equal(ps[i, :121], np.asarray(xs)) and np.array_equal(pl[i, :121], np.asarray(xl))
 
 
+def test_cfg5_dp_of_96_scenes_is_bit_exact(planner):
+    """The driver-run share of tools/parity_sweep.py's configs[4] DP sweep (profiles/r05_parity_sweep_dp_cfg5.json: 2048 scenes on
+    the host cores of the GPU box): 96 benchmark scenes of the 120 x 21 lattice with 16 obstacles - 32 tiles of the work-ring
+    edge kernel with its 2-byte ring masks, the 21-row sweep, the densification - rows, feasibility and every densified path
+    point against oracle/exact.py bit for bit."""
+    cfg = S.CFG5
+    B = 96
+    b = S.make_batch(range(3000, 3000 + B), cfg, start_ahead=S.BENCH_START_AHEAD)
+    p = _params(cfg)
+    rows, mc, st = planner.dp_plan(p, b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start)
+    xrows, xfeas, xpaths = ex.dp_plan(b.sl_obs_s, b.sl_obs_l, b.n_obs, b.sl_start, cfg.row, cfg.col, cfg.sample_s,
+                                      cfg.sample_l, cfg.sampling_res, chunk=8)
+    assert np.array_equal(rows, xrows) and np.array_equal(st == 1, ~xfeas)
+    assert 0 < int((st == 1).sum()) < B              # both outcomes occur
+    from emplanner_carla_amd.api import max_path_points
+    ps, pl, ln, st2 = planner.dp_enrich(p, rows, b.sl_start, max_path_points(p))
+    for i in np.nonzero(xfeas)[0]:
+        xs, xl = xpaths[i]
+        assert ln[i] == len(xs) and np.array_equal(ps[i, :ln[i]], np.asarray(xs)) and np.array_equal(pl[i, :ln[i]], np.asarray(xl)), i
+
+
 @pytest.mark.parametrize("cfg,B", [(S.CFG2, 4096), (S.CFG_DEFAULT, 1000), (S.CFG5, 40),
                                    (S.LatticeConfig("odd_7x11", row=7, col=11, sample_s=3.0, sample_l=1.2, sampling_res=1, n_obs=5), 333),
                                    (S.LatticeConfig("one_column", row=9, col=1, sample_s=2.5, sample_l=1.5, sampling_res=1, n_obs=3), 20),
