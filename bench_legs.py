@@ -165,9 +165,30 @@ def latency_leg(pl, torch, device, calls=50, scene_kw=None):
             pl.synchronize()
             lat.append((time.perf_counter() - t0) * 1e3)
         lat = np.sort(np.asarray(lat))
+        # the same calls as one hipGraph (EMP_OPT_CYCLE_GRAPH): same inputs' memory, the first result's arrays written again
+        graph = None
+        try:
+            pl.set_option("cycle_graph", 1)
+            ref = {k: getattr(r, k).clone() for k in ("traj", "traj_len", "status", "path_l", "dp_rows")}
+            for _ in range(10):
+                r = pl.plan_cycle(p, q, sp, max_pts=M, out=r, **dev)
+                pl.synchronize()
+            glat = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                r = pl.plan_cycle(p, q, sp, max_pts=M, out=r, **dev)
+                pl.synchronize()
+                glat.append((time.perf_counter() - t0) * 1e3)
+            glat = np.sort(np.asarray(glat))
+            same = all(bool(torch.equal(getattr(r, k), v)) for k, v in ref.items())
+            graph = {"ms_per_cycle_mean": round(float(glat.mean()), 4), "ms_per_cycle_median": round(float(np.median(glat)), 4),
+                     "ms_per_cycle_p95": round(float(glat[int(0.95 * (calls - 1))]), 4), "results_equal_the_plain_calls": same}
+        finally:
+            pl.set_option("cycle_graph", 0)
         return {"workload": "BASELINE configs[1]: one scene, 40x9 lattice, 8 obstacles, one synchronous call per cycle, inputs resident in HBM",
                 "calls": calls, "ms_per_cycle_mean": round(float(lat.mean()), 4), "ms_per_cycle_median": round(float(np.median(lat)), 4),
                 "ms_per_cycle_p95": round(float(lat[int(0.95 * (calls - 1))]), 4), "scene_status": int(r.status.cpu().numpy()[0]),
+                "as_one_hipgraph": graph,
                 "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
     except Exception as exc:
         return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}

@@ -43,7 +43,7 @@ EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
 OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
            "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9,
            "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15,
-           "lane_edge_order": 16}
+           "lane_edge_order": 16, "cycle_graph": 17}
 #: the values a fresh context holds (everything else is 0)
 OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1}
 
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "emp_set_option": (C.c_int, [_vp, _i32, _i32]),
     "emp_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
     "emp_sweep_clock_mhz": (_f64, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
+    "emp_cycle_graph_replays": (C.c_int64, [_vp]),
     "emp_edge_probe": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i32)]),
     "emp_sweep_probe_spans": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),

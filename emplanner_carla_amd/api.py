@@ -206,7 +206,14 @@ class _Args:
         self.keep.append(a)
         return C.c_void_p(a.ctypes.data)
 
-    def out(self, shape, dtype):
+    def out(self, shape, dtype, into=None):
+        if into is not None:             # the caller's own output array of an earlier call (plan_cycle(out=...)): same memory again
+            if tuple(into.shape) != tuple(shape):
+                raise ValueError(f"out: expected shape {tuple(shape)}, got {tuple(into.shape)}")
+            if self.torch:
+                self.outs.append(into)
+                return into, C.c_void_p(into.data_ptr())
+            return into, C.c_void_p(into.ctypes.data)
         if self.torch:
             td = {np.float64: self.t.float64, np.int32: self.t.int32}[dtype]
             # empty, not zeros: a fill kernel on torch's stream would race with ours; the library zero-fills
@@ -452,6 +459,10 @@ class Planner:
         mean_us, max_us = C.c_double(0.0), C.c_double(0.0)
         mhz = float(self._lib.emp_sweep_clock_mhz(self._h, C.byref(mean_us), C.byref(max_us)))
         return None if mhz < 0 else (mhz, float(mean_us.value), float(max_us.value))
+
+    def cycle_graph_replays(self) -> int:
+        """Option "cycle_graph": how many plan_cycle calls of this planner were one hipGraphLaunch (emp_cycle_graph_replays)."""
+        return int(self._lib.emp_cycle_graph_replays(self._h))
 
     def edge_probe(self):
         """With option "edge_clock_probe" on: (mean wavefront residence us, first start to last end us, mean wavefronts resident
@@ -970,11 +981,15 @@ class Planner:
         self._check(self._lib.emp_wait_cycle(self._h, int(calls_back)))
 
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
-                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None, slot=None) -> CycleResult:
+                   start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None, slot=None,
+                   out: "CycleResult" = None) -> CycleResult:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
         of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169.
         ``slot``: a ``HostRing`` slot whose page-locked arrays ARE the inputs (the array arguments are then ignored) and
-        receive the outputs - with a pipeline set the call returns before they are there (``slot.wait()``)."""
+        receive the outputs - with a pipeline set the call returns before they are there (``slot.wait()``).
+        ``out``: the ``CycleResult`` of an earlier call with the same sizes - its arrays are written again instead of new ones
+        being allocated.  With the same inputs' memory too, consecutive calls have one signature, which is what option
+        "cycle_graph" (EMP_OPT_CYCLE_GRAPH: the call's launches replayed as one hipGraph) needs."""
         if slot is not None:
             return self._plan_cycle_pinned(p, q, sp, slot, mode)
         a = self._args(ref_line, origin_xy)
@@ -998,7 +1013,7 @@ class Planner:
                                 ("path_s", (B, M), np.float64), ("path_l", (B, M), np.float64),
                                 ("path_len", (B,), np.int32), ("traj", (B, M + 1, 4), np.float64),
                                 ("traj_len", (B,), np.int32), ("status", (B,), np.int32)):
-            arr, ptr = a.out(shape, dt)
+            arr, ptr = a.out(shape, dt, getattr(out, name) if out is not None else None)
             res[name] = arr
             setattr(io, name, ptr)
         self._check(self._lib.emp_plan_cycle(self._h, C.byref(p), C.byref(q), C.byref(sp), B, P, mo, M, int(mode),

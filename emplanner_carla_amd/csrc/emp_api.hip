@@ -69,6 +69,7 @@ static int dp_pair_table(emp_ctx* ctx, const DpDev& d, const double** out) {
     if (!pt.valid || memcmp(key, pt.key, sizeof(key)) != 0) {
         hipLaunchKernelGGL(dp_pair_table_kernel, dim3(1), dim3(256), 0, ctx->stream, d, (double*)tb.p);
         EMP_LAUNCH_CHECK(ctx);
+        ++ctx->alloc_gen;                 // (a captured cycle graph does not carry this launch: EMP_OPT_CYCLE_GRAPH)
         memcpy(pt.key, key, sizeof(key));
         pt.valid = true;
     }
@@ -275,7 +276,15 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
                                                    : (const void*)dp_sweep_kernel<R, PD, WPB, NT, true>,    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
         hipEvent_t stop_ev = t.stop ? t.stop : ctx->front_stop;                                             \
-        if (defer) {                                                                                        \
+        if (ctx->capturing && defer) {      /* a stream capture records plain launches only */              \
+            hipLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT, false>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                               ctx->stream, d, start_cost, edge, n_obs, rows, min_cost, status, ctx->bt_pre, ctx->bt_term, probe); \
+            ctx->bt_deferred = true;                                                                        \
+        } else if (ctx->capturing) {                                                                        \
+            hipLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
+                               ctx->stream, d, start_cost, edge, n_obs, rows, min_cost, status,             \
+                               (unsigned char*)nullptr, (int*)nullptr, probe);                              \
+        } else if (defer) {                                                                                 \
             hipExtLaunchKernelGGL((dp_sweep_kernel<R, PD, WPB, NT, false>), dim3((d.tiles + (WPB) - 1) / (WPB)), dim3(64 * (WPB)), lds, \
                                   ctx->stream, t.start, stop_ev, 0, d, start_cost, edge, n_obs, rows, min_cost, status, \
                                   ctx->bt_pre, ctx->bt_term, probe);                                        \
@@ -516,6 +525,7 @@ void emp_destroy(emp_ctx* ctx) {
         if (ln.ev_host) (void)hipEventDestroy(ln.ev_host);
         if (ln.stream) (void)hipStreamDestroy(ln.stream);
     }
+    if (ctx->cycle_graph) (void)hipGraphExecDestroy(ctx->cycle_graph);
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
@@ -755,6 +765,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_SWEEP_MARKER:
         case EMP_OPT_EDGE_FORM:
         case EMP_OPT_EDGE_CLOCK_PROBE:
+        case EMP_OPT_CYCLE_GRAPH:
         case EMP_OPT_SWEEP_CLOCK_PROBE: ok = value == 0 || value == 1; break;
         case EMP_OPT_LANE_EDGE_ORDER:
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
@@ -1508,6 +1519,61 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
     }
     if (piped) lane.ln->host_valid = false;
+    // EMP_OPT_CYCLE_GRAPH: one batch at a time on device pointers - the third consecutive call with one signature is captured,
+    // the following ones are one hipGraphLaunch.  The signature is everything a launch argument is made of; the context's
+    // allocation count says whether a temporary or a lattice table moved or changed since the capture.
+    struct CaptureGuard {
+        emp_ctx* c;
+        bool active = false;
+        ~CaptureGuard() {
+            if (!active) return;            // (an early return inside the captured region: end the capture, keep nothing)
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(c->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            c->capturing = false;
+        }
+    } capture{ctx};
+    const bool graph_ok = ctx->opt[EMP_OPT_CYCLE_GRAPH] == 1 && pmode == 0 && where == EMP_DEVICE && B > 0 && !ctx->timing &&
+                          !ctx->opt[EMP_OPT_SWEEP_CLOCK_PROBE] && !ctx->opt[EMP_OPT_EDGE_CLOCK_PROBE];
+    if (graph_ok) {
+        std::vector<unsigned long long> key;
+        auto add = [&](const void* ptr, size_t bytes) {
+            const unsigned char* b8 = (const unsigned char*)ptr;
+            for (size_t o = 0; o < bytes; o += 8) {
+                unsigned long long w = 0;
+                memcpy(&w, b8 + o, std::min<size_t>(8, bytes - o));
+                key.push_back(w);
+            }
+        };
+        const long long sizes[5] = {B, max_ref, max_obs, max_pts, (long long)mode};
+        add(sizes, sizeof(sizes));
+        add(p, sizeof(*p));
+        add(q, sizeof(*q));
+        add(sp, sizeof(*sp));
+        add(io, sizeof(*io));
+        add(ctx->opt, sizeof(ctx->opt));
+        if (ctx->cycle_graph && key == ctx->cycle_graph_key && ctx->alloc_gen == ctx->cycle_graph_gen) {
+            EMP_HIP(ctx, hipGraphLaunch(ctx->cycle_graph, ctx->stream));
+            ++ctx->cycle_graph_replays;
+            return EMP_OK;
+        }
+        if (ctx->cycle_graph) {             // another signature, or the buffers moved: the graph is stale
+            (void)hipGraphExecDestroy(ctx->cycle_graph);
+            ctx->cycle_graph = nullptr;
+        }
+        ctx->cycle_seen = (key == ctx->cycle_seen_key) ? ctx->cycle_seen + 1 : 1;
+        ctx->cycle_seen_key = key;
+        if (ctx->cycle_seen >= 3) {         // the two calls before this one allocated and built whatever this signature needs
+            ctx->cycle_graph_gen = ctx->alloc_gen;
+            EMP_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+            capture.active = true;
+            ctx->capturing = true;
+        }
+    } else if (ctx->cycle_graph) {
+        (void)hipGraphExecDestroy(ctx->cycle_graph);
+        ctx->cycle_graph = nullptr;
+        ctx->cycle_seen = 0;
+    }
     Stage st(ctx, where, piped, pinned);
     const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
     const int *d_nr, *d_no;
@@ -1679,8 +1745,28 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipEventSynchronize(ctx->ev_host_last));
         return EMP_OK;
     }
+    if (capture.active) {
+        hipGraph_t g = nullptr;
+        capture.active = false;
+        ctx->capturing = false;
+        EMP_HIP(ctx, hipStreamEndCapture(ctx->stream, &g));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        EMP_HIP(ctx, ie);
+        if (ctx->alloc_gen != ctx->cycle_graph_gen) {      // something was allocated or rebuilt inside the capture after all
+            (void)hipGraphExecDestroy(exec);
+            ctx->cycle_seen = 0;
+            return emp::fail(ctx, EMP_ERR_HIP, "EMP_OPT_CYCLE_GRAPH: the context's buffers changed inside a capture");
+        }
+        ctx->cycle_graph = exec;
+        ctx->cycle_graph_key = ctx->cycle_seen_key;
+        EMP_HIP(ctx, hipGraphLaunch(exec, ctx->stream));       // the captured launches have not run yet: this is the call's work
+    }
     return st.finish();
 }
+
+int64_t emp_cycle_graph_replays(emp_ctx* ctx) { return ctx ? (int64_t)ctx->cycle_graph_replays : -1; }
 
 uint64_t emp_cycle_ticket(emp_ctx* ctx) { return ctx ? ctx->cycle_calls : 0; }
 

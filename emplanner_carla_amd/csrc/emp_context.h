@@ -94,7 +94,15 @@ struct emp_ctx {
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
-    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0};
+    // EMP_OPT_CYCLE_GRAPH: the launches of one emp_plan_cycle call as an executable graph, the call signature it belongs to, how
+    // often that signature has been seen in a row, and the allocation count (grow_buffer) it was captured under
+    hipGraphExec_t cycle_graph = nullptr;
+    std::vector<unsigned long long> cycle_graph_key, cycle_seen_key;
+    int cycle_seen = 0;
+    long long cycle_graph_replays = 0;
+    unsigned long long alloc_gen = 0, cycle_graph_gen = 0;
+    bool capturing = false;             // launchers avoid what a stream capture cannot record (hipExtLaunchKernelGGL)
     hipEvent_t edge_wait = nullptr;     // EMP_OPT_EDGE_AFTER_ENRICH: what the next edge-cost launch waits for on its stream
     hipEvent_t lane_edge_done = nullptr; // EMP_OPT_LANE_EDGE_ORDER: recorded behind the latest edge-cost launch of a lane-mode call (a lane's ev_edge)
     // STAGED: an event the next densification / path-QP launch is asked to signal from its own dispatch (hipExtLaunchKernelGGL's
@@ -182,6 +190,7 @@ inline int grow_buffer(emp_ctx* ctx, emp_ctx::Buf& b, size_t bytes) {
     const size_t want = bytes + bytes / 4;
     EMP_HIP(ctx, hipMalloc(&b.p, want));
     b.bytes = want;
+    ++ctx->alloc_gen;
     return EMP_OK;
 }
 

@@ -182,7 +182,7 @@ int emp_pipeline_depth(emp_ctx* ctx);
  * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
 int emp_set_fence(emp_ctx* ctx, int enabled);
 
-/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE, EMP_OPT_LANE_EDGE_ORDER: version 10) ---------------------------------------------------------------------------------------
+/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE, EMP_OPT_LANE_EDGE_ORDER, EMP_OPT_CYCLE_GRAPH: version 10) ---------------------------------------------------------------------------------------
  * The library reads NO environment variable.  Everything that used to be an EMP_* environment switch of the development
  * builds is a per-context option here, set by the host program before the calls it should affect (a change takes effect
  * at the next call; EMP_OPT_BACK_STREAM_CUS at the next emp_set_pipeline).  Unknown options and values out of range are
@@ -220,6 +220,14 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             0.42 instead of 0.36) - and NOT where the edge kernel is most of a
  *                                                             call (every obstacle beside the same columns: 0.18 -> 0.23 ms), which
  *                                                             is why it is not the default
+ *   EMP_OPT_CYCLE_GRAPH             0        tuning           1: emp_plan_cycle on device pointers, one batch at a time (no pipeline): the
+ *                                                             THIRD consecutive call with the same sizes, parameters, options and
+ *                                                             pointers captures its six launches into a hipGraph, every further one
+ *                                                             replays it with one hipGraphLaunch (the callers that plan one scene or a
+ *                                                             few per call over and over, BASELINE configs[1]: launch latency is a
+ *                                                             fifth of such a cycle).  Same kernels, same arguments: same bits.  Any
+ *                                                             change of an argument, of an option or of the context's buffers drops
+ *                                                             the graph; emp_set_timing and the clock probes bypass it
  *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
  *                                                             the 100 MHz reference counter at its first and last instruction
  *                                                             (emp_edge_probe reads the latest launch)
@@ -274,7 +282,8 @@ typedef enum emp_option {
     EMP_OPT_EDGE_COLS_PER_WAVE = 14,
     EMP_OPT_EDGE_CLOCK_PROBE = 15,
     EMP_OPT_LANE_EDGE_ORDER = 16,
-    EMP_OPT_COUNT = 17
+    EMP_OPT_CYCLE_GRAPH = 17,
+    EMP_OPT_COUNT = 18
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
@@ -287,6 +296,8 @@ double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_
  * wavefront's start to the last one's end (us), mean number of wavefronts resident at once (their ratio x count), wavefronts.
  * Synchronises on that launch.  Any out pointer may be NULL. */
 int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* mean_resident_waves, int32_t* waves);
+/* EMP_OPT_CYCLE_GRAPH: how many emp_plan_cycle calls of this context were served by replaying a captured graph (-1: ctx is NULL). */
+int64_t emp_cycle_graph_replays(emp_ctx* ctx);
 /* The same probe, per launch and averaged over the recorded launches (100 MHz reference ticks, which all wavefronts share):
  * how long after the launch's first wavefront its last wavefront started, and the time from the first wavefront's first
  * instruction to the last wavefront's last - what is left of the launch's event-measured duration is dispatch and

@@ -123,6 +123,8 @@ def test_default_run_carries_the_secondary_legs():
     assert c["speed_dp_us"] > 100 and 0.15 < c["sweep"]["frac"] < 1.0 and c["all_scenes_cycles_per_s"] > 1e5
     lat = d["latency_leg"]
     assert "error" not in lat and 0.05 < lat["ms_per_cycle_median"] < 5.0 and lat["calls"] == 50
+    g = lat["as_one_hipgraph"]
+    assert g["results_equal_the_plain_calls"] is True and 0.05 < g["ms_per_cycle_median"] < 5.0
 
 
 def test_bench_two_ranks_without_gather_separates_compute_scaling():

@@ -820,3 +820,71 @@ def test_path_qp_at_its_size_limits(planner, col, max_pts, stations):
         assert_rel(r.traj[i, :m, :3], np.asarray(want["trajectory"], dtype=np.float64)[:, :3], RTOL, f"scene {i} trajectory")
         compared += 1
     assert compared >= 10 and at_size >= 8
+
+
+@pytest.mark.gpu
+def test_cycle_graph_replays_the_same_bits():
+    """EMP_OPT_CYCLE_GRAPH: consecutive emp_plan_cycle calls with one signature (same sizes, parameters, options, input and
+    output memory) are captured into a hipGraph at the third call and replayed from the fourth on.  The graph carries pointers,
+    not data: new scene contents in the same input tensors must give the plain path's results for THOSE scenes bit for bit; a
+    call with another signature (other tensors, another batch size, another parameter) drops the graph and is itself correct; so
+    is the call after a different entry point has used the context in between."""
+    import torch
+    from emplanner_carla_amd import scenes as S
+    from emplanner_carla_amd.api import Planner, dp_params_from_cfg, max_path_points, qp_params, smooth_params
+    cfg = S.CFG2
+    p, q, sp = dp_params_from_cfg(cfg), qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width), smooth_params()
+    M = max_path_points(p)
+    fields = ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status")
+
+    def host(seeds):
+        b = S.make_batch(seeds, cfg, start_ahead=S.BENCH_START_AHEAD)
+        return dict(ref_line=b.ref, n_ref=np.full(len(seeds), b.ref.shape[1], np.int32), origin_xy=b.origin_xy, start_xy=b.start_xy,
+                    start_v=b.start_v, start_a=b.start_a, obs_xy=b.obs_xy, n_obs=b.n_obs)
+
+    plain, pl = Planner(0), Planner(0)
+    try:
+        def expect(h):
+            r = plain.plan_cycle(p, q, sp, max_pts=M, **h)
+            return {k: np.asarray(getattr(r, k)) for k in fields}
+
+        def same(r, e, what):
+            for k in fields:
+                assert np.array_equal(getattr(r, k).cpu().numpy(), e[k], equal_nan=True), (what, k)
+
+        pl.set_option("cycle_graph", 1)
+        replays = 0
+        for n in (1, 5, 64):
+            sets = [host(range(100 * n + 7 * k, 100 * n + 7 * k + n)) for k in range(6)]
+            dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sets[0].items()}
+            out = None
+            for k, h in enumerate(sets):                       # calls 0-1 plain, call 2 captured, calls 3-5 replayed
+                for name, v in h.items():
+                    dev[name].copy_(torch.from_numpy(np.ascontiguousarray(v)))
+                torch.cuda.synchronize()
+                out = pl.plan_cycle(p, q, sp, max_pts=M, out=out, **dev)
+                pl.synchronize()
+                same(out, expect(h), f"{n} scenes, call {k}")
+            assert pl.cycle_graph_replays() - replays == 3, "calls 3, 4 and 5 must have been graph replays"
+            replays = pl.cycle_graph_replays()
+            # another entry point in between (its temporaries come from the same pool), then the same signature again
+            pl.frenet_project(sets[0]["ref_line"], sets[0]["n_ref"], sets[0]["origin_xy"], sets[0]["start_xy"], sets[0]["start_v"],
+                              sets[0]["start_a"], sets[0]["obs_xy"], sets[0]["n_obs"])
+            out = pl.plan_cycle(p, q, sp, max_pts=M, out=out, **dev)
+            pl.synchronize()
+            same(out, expect(sets[-1]), f"{n} scenes, after another entry point")
+            # another parameter value: a new signature
+            q2 = qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width)
+            q2.w_dl = q.w_dl * 2.0
+            r2 = pl.plan_cycle(p, q2, sp, max_pts=M, out=out, **dev)
+            pl.synchronize()
+            e2 = plain.plan_cycle(p, q2, sp, max_pts=M, **sets[-1])
+            assert np.array_equal(r2.traj.cpu().numpy(), np.asarray(e2.traj), equal_nan=True)
+            # fresh output tensors: a new signature again
+            r3 = pl.plan_cycle(p, q, sp, max_pts=M, **dev)
+            pl.synchronize()
+            same(r3, expect(sets[-1]), f"{n} scenes, fresh outputs")
+            replays = pl.cycle_graph_replays()
+    finally:
+        pl.close()
+        plain.close()
