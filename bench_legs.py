@@ -183,8 +183,24 @@ def latency_leg(pl, torch, device, calls=50, scene_kw=None):
             same = all(bool(torch.equal(getattr(r, k), v)) for k, v in ref.items())
             graph = {"ms_per_cycle_mean": round(float(glat.mean()), 4), "ms_per_cycle_median": round(float(np.median(glat)), 4),
                      "ms_per_cycle_p95": round(float(glat[int(0.95 * (calls - 1))]), 4), "results_equal_the_plain_calls": same}
+            # ... and with the path-QP kernel form that is shorter on a single scene's critical path (EMP_OPT_PATH_QP_FORM = 1:
+            # result-affecting at the 2e-9 level, hence an option and never chosen from the batch size)
+            pl.set_option("path_qp_form", 1)
+            for _ in range(10):
+                r = pl.plan_cycle(p, q, sp, max_pts=M, out=r, **dev)
+                pl.synchronize()
+            flat = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                r = pl.plan_cycle(p, q, sp, max_pts=M, out=r, **dev)
+                pl.synchronize()
+                flat.append((time.perf_counter() - t0) * 1e3)
+            worst = float((r.traj - ref["traj"]).abs().max().item())
+            graph["with_path_qp_form_1"] = {"ms_per_cycle_median": round(float(np.median(flat)), 4),
+                                            "max_abs_trajectory_difference_to_the_default_form": worst}
         finally:
             pl.set_option("cycle_graph", 0)
+            pl.set_option("path_qp_form", 0)
         return {"workload": "BASELINE configs[1]: one scene, 40x9 lattice, 8 obstacles, one synchronous call per cycle, inputs resident in HBM",
                 "calls": calls, "ms_per_cycle_mean": round(float(lat.mean()), 4), "ms_per_cycle_median": round(float(np.median(lat)), 4),
                 "ms_per_cycle_p95": round(float(lat[int(0.95 * (calls - 1))]), 4), "scene_status": int(r.status.cpu().numpy()[0]),
