@@ -40,7 +40,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline_step   the whole step against the chip's vector-issue capacity: sum over the step's kernels of their VALU-busy
                 quad-cycles (committed SQ counter pass, source named) / (1024 SIMDs x clock / 4 x ms_per_step), with the measured
                 cost of a wave64 FP64 instruction (tools/fp64_pipe_bench.hip: 4.3 cycles, not the 4 the counter charges)
-  staged_leg, exclusive_sweep_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
+  staged_leg, exclusive_sweep_leg, rccl_gather_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
                 (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them) short secondary measurements after the
                 headline: the staged pipeline of rounds 2-5 (two batches, front stage beside back stage: ~9 % longer steps, the
                 sweep beside the Cartesian tail only) and the same with the sweep held back behind the previous batch's path QP
@@ -48,7 +48,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                 Infinity Cache); BASELINE configs[4] (120x21 lattice + S-T speed DP) on 4096 scenes; configs[1] (one scene per
                 synchronous call); SURVEY 8(d)'s own geometry (arc radii 150-1000 m) with its slalom layout and with the
                 corridor layout; the host path (NumPy arrays in and out through the page-locked ring, PCIe included); the
-                per-step code of an N > 1 rank (record packing + gather streams) on this one GPU
+                per-step code of an N > 1 rank (record packing + gather streams) on this one GPU - without a process group
+                (gather_path_leg: the identity) and, in a process of its own, with a one-rank ProcessGroupNCCL whose dist.gather is a
+                real RCCL call every step (rccl_gather_leg)
 """
 from __future__ import annotations
 
@@ -210,6 +212,33 @@ from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, gather_
                         roofline_step, secondary_leg)
 
 
+def rccl_gather_subprocess_leg(steps):
+    """`python bench.py --force-gather-path --one-rank-rccl --no-legs --no-cpu-baseline` in a fresh process, as a rank of an
+    N > 1 run is: the headline's step with its records packed and gathered to rank 0 by RCCL (one rank: the identity, through
+    ProcessGroupNCCL) on the gather stream, every step."""
+    import subprocess
+    t_leg = time.perf_counter()
+    cmd = [sys.executable, os.path.abspath(__file__), "--force-gather-path", "--one-rank-rccl", "--no-legs", "--no-cpu-baseline",
+           "--steps", str(steps), "--warmup", "5"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.abspath(__file__)))
+        if out.returncode != 0:
+            return {"error": f"exit {out.returncode}: {out.stderr[-400:]}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+        d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        g = d["gather"]
+        return {"workload": "the headline's step with every step's records packed on the result stream and gathered to rank 0 by RCCL "
+                            "on the gather stream - a process group of ONE rank (all a one-GPU box allows), a process of its own",
+                "backend": g.get("backend"), "world_size_seen_by_the_process_group": g.get("world_size_seen_by_the_process_group"),
+                "steps": steps, "ms_per_step": d["ms_per_step"], "ms_per_step_without_pack_and_gather": g.get("ms_per_step_without_pack_and_gather"),
+                "all_scenes_cycles_per_s": d["all_scenes_cycles_per_s"], "gather_ms_on_its_stream": g.get("gather_ms_on_its_stream"),
+                "gather_hidden_behind_compute_frac": g.get("gather_hidden_behind_compute_frac"),
+                "records_complete_on_rank0": g.get("records_complete_on_rank0"), "doubles_per_scene": g.get("doubles_per_scene"),
+                "sweep_frac": d["roofline"]["frac"], "pipeline": d["config"]["pipeline"],
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
 def staged_subprocess_leg(steps, options):
     """`python bench.py --pipeline staged --no-legs --no-cpu-baseline [--opt ...]` in a fresh process (this one waits, its GPU
     work fenced): the staged form's step time and its sweep's launches, as that command prints them."""
@@ -262,6 +291,8 @@ def main():
                     "the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n lanes "
                     "(more overlap: shorter steps, every kernel's own launches longer); 'auto' (default) = 3 lanes")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
+    ap.add_argument("--one-rank-rccl", action="store_true", help="with --force-gather-path on one GPU: a one-rank ProcessGroupNCCL, "
+                    "so that every step's gather is a real RCCL call (rccl_gather_leg of the default run)")
     ap.add_argument("--settle-steps", type=int, default=-1, help="untimed steps before the timed region, warm-up included "
                     "(clock settling; 0 = only the --warmup steps; default: ~50 ms of work - 150 steps at 4096 scenes of "
                     "config 2, fewer for bigger steps)")
@@ -293,7 +324,12 @@ def main():
         return latency_main(args)
 
     from emplanner_carla_amd import _lib as L
-    L.configure_hw_queues(8)          # lane mode: a hardware queue per stream; must precede HIP's initialisation (_lib.py)
+    # lane mode: a hardware queue per stream; must precede HIP's initialisation (_lib.py).  Twelve since round 5: three lanes, the
+    # main stream, the gather stream and torch's fit into eight - until RCCL brings its own streams (N > 1): a one-rank
+    # ProcessGroupNCCL with an all_gather per step beside three lanes measured 0.243 ms per step on 8 queues, 0.211 on 12 or 16 or
+    # 24 (staged: 0.227 either way; without the collective 0.197 whatever the count) - tools/rccl_lanes_probe.py.  Not more than
+    # needed: the queues are the GPU's, and two processes of 16 on ONE GPU (the two-rank test) ran four times slower than of 12
+    L.configure_hw_queues(12)
     import torch
     import torch.distributed as dist
     from emplanner_carla_amd import dist as emp_dist
@@ -313,12 +349,41 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # RCCL prints a version banner on the process's C stdout when its first communicator comes up; rank 0's stdout is ONE JSON
+    # line, so file descriptor 1 points at stderr while a process group initialises
+    class _StdoutToStderr:
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        def __exit__(self, *exc):
+            import ctypes
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+    pg_one = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
-        else:
-            dist.init_process_group(backend=backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+                dist.barrier()
+            else:
+                dist.init_process_group(backend=backend)
+    elif args.one_rank_rccl:
+        # a process group of ONE rank on the real backend: the per-step gather below is then an RCCL dist.gather (the identity,
+        # through ProcessGroupNCCL, its streams and its kernels) - what a one-GPU box can exercise of the N > 1 exchange
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        with _StdoutToStderr():
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+            dist.barrier()
+        pg_one = True
 
     wide = args.config == "cfg5"
     cfg = S.CFG5 if wide else S.CFG2
@@ -372,7 +437,7 @@ def main():
     sg = None
     if gather_path:      # the per-step result exchange (emplanner_carla_amd/dist.py StepGather): pack on the result stream,
         sg = emp_dist.StepGather(p.col, M, total, planner=pl, fields=args.records, device=device,     # gather on its own
-                                 dst=0 if args.gather == "rank0" else None, timing=True)
+                                 dst=0 if args.gather == "rank0" else None, timing=True, alone_too=pg_one)
     with_gather = [gather_path]
 
     def step():
@@ -455,8 +520,8 @@ def main():
             nog = float(el2.item())
         with_gather[0] = True
         ms_with, ms_without = elapsed / args.steps * 1e3, nog / args.steps * 1e3
-        diag = {"backend": (dist.get_backend() if world > 1 else "none (one process)"),
-                "world_size_seen_by_the_process_group": (dist.get_world_size() if world > 1 else 1),
+        diag = {"backend": (dist.get_backend() if (world > 1 or pg_one) else "none (one process)"),
+                "world_size_seen_by_the_process_group": (dist.get_world_size() if (world > 1 or pg_one) else 1),
                 "ms_per_step_per_rank": [round(v, 4) for v in per_rank],
                 "ms_per_step_min_max_over_ranks": [round(min(per_rank), 4), round(max(per_rank), 4)],
                 "ms_per_step_without_pack_and_gather": round(ms_without, 4),
@@ -519,6 +584,7 @@ def main():
         # streams finds its two stages on one queue (0.43 ms a step instead of 0.22) - a fresh process is what a staged user has.
         legs["staged_leg"] = staged_subprocess_leg(args.steps, {})
         legs["exclusive_sweep_leg"] = staged_subprocess_leg(args.steps, {"sweep_exclusive": 2})
+        legs["rccl_gather_leg"] = rccl_gather_subprocess_leg(max(args.steps, 20))
         legs["gather_path_leg"] = gather_path_leg(pl, torch, emp_dist, S.CFG2, 4096, max(args.steps, 20), device, scene_kw)
         legs["dram_leg"] = secondary_leg(pl, torch, S.CFG2, 32768, 10, 12, device, scene_kw)
         legs["cfg5_leg"] = secondary_leg(pl, torch, S.CFG5, 4096, 4, 4, device, scene_kw, speed=True)
@@ -699,6 +765,9 @@ def main():
     pl.close()
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif pg_one:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -79,17 +79,18 @@ def unpack_records(rec, col: int, max_pts: int, path_cap: int | None = None, fie
     return out
 
 
-def gather_records(local, total: int, group=None, dst: int | None = None):
+def gather_records(local, total: int, group=None, dst: int | None = None, alone_too: bool = False):
     """Collect every rank's records in scene order.  ``local`` is this rank's (count, width) matrix for the block
     ``shard_range(total, rank, world)``.
 
     ``dst`` = None: all ranks receive the (total, width) matrix (``all_gather``; equal shards use one
     ``all_gather_into_tensor``, ragged shards are padded to the largest block).  ``dst`` = r: a gather - only rank r
     receives the matrix, the others send their block and get None (what BASELINE's "RCCL gather" asks for: on N GPUs
-    rank r takes in (N - 1) blocks per step and nobody else takes in anything)."""
+    rank r takes in (N - 1) blocks per step and nobody else takes in anything).  ``alone_too``: issue the collective even in a
+    process group of ONE rank (the identity, but through RCCL: what a one-GPU box can exercise of the N > 1 path)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not alone_too):
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_range(total, r, world)[1] for r in range(world)]
@@ -134,13 +135,14 @@ class StepGather:
     streams and ``planner`` may be any object with ``pack_records`` or None (torch packing)."""
 
     def __init__(self, col: int, max_pts: int, total: int, planner=None, fields: str = "full", dst: int | None = 0,
-                 group=None, device=None, depth: int = 3, timing: bool = False):
+                 group=None, device=None, depth: int = 3, timing: bool = False, alone_too: bool = False):
         self.col, self.max_pts, self.total = int(col), int(max_pts), int(total)
         self.cap = path_capacity(max_pts)
         self.planner, self.fields, self.dst, self.group, self.depth = planner, fields, dst, group, int(depth)
         self.width = record_width(col, max_pts, self.cap, fields)
         self.in_flight = []
         self.stream = None
+        self.alone_too = bool(alone_too)  # the collective even in a one-rank process group (gather_records)
         self.timing = bool(timing)       # event pairs around every gather on its stream (``gather_ms``)
         self.timed = []
         if device is not None and getattr(device, "type", "cpu") == "cuda":
@@ -151,7 +153,7 @@ class StepGather:
         import torch
         if self.stream is None:                          # CPU tensors: everything is synchronous
             rec = pack_records(res, self.col, self.max_pts, path_cap=self.cap, planner=self.planner, fields=self.fields)
-            out = gather_records(rec, self.total, group=self.group, dst=self.dst)
+            out = gather_records(rec, self.total, group=self.group, dst=self.dst, alone_too=self.alone_too)
             self.in_flight.append((rec, out, None))
             if len(self.in_flight) > self.depth:
                 self.in_flight.pop(0)
@@ -165,7 +167,7 @@ class StepGather:
             if self.timing:
                 began = torch.cuda.Event(enable_timing=True)
                 began.record(self.stream)
-            out = gather_records(rec, self.total, group=self.group, dst=self.dst)
+            out = gather_records(rec, self.total, group=self.group, dst=self.dst, alone_too=self.alone_too)
             done = torch.cuda.Event(enable_timing=self.timing)
             done.record(self.stream)
             if self.timing:

@@ -107,6 +107,11 @@ def test_default_run_carries_the_secondary_legs():
     # figures themselves are bench.py's default run: profiles/r05_bench_default.json)
     assert h["host_ring"]["all_scenes_cycles_per_s"] > h["synchronous_pageable_path"]["all_scenes_cycles_per_s"] > 1e5
     assert 0.05 < h["one_scene_host_latency_ms"] < 5.0
+    # the N > 1 per-step code with a real (one-rank) RCCL process group, in a process of its own
+    rg = d["rccl_gather_leg"]
+    assert "error" not in rg, rg
+    assert rg["backend"] == "nccl" and rg["world_size_seen_by_the_process_group"] == 1 and rg["records_complete_on_rank0"] is True
+    assert rg["doubles_per_scene"] == 179 and rg["ms_per_step"] > 0 and rg["gather_ms_on_its_stream"]["count"] > 0
     # the N > 1 per-step code on this one GPU
     gp = d["gather_path_leg"]
     assert "error" not in gp, gp
