@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -418,3 +419,61 @@ def roofline_step(cfg, count, scene_dist, ms_per_step, speed=False):
                     "16.2), measured by tools/fp64_pipe_bench.hip - the second figure scales by that.  What is left is ordering: the "
                     "front queue's kernels wait for each other (projection -> edge costs -> sweep), the path QP is one wavefront "
                     "per two SIMDs and as long as its slowest scene"}
+
+
+_BENCH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")     # the legs below run it in processes of their own
+def rccl_gather_subprocess_leg(steps):
+    """`python bench.py --force-gather-path --one-rank-rccl --no-legs --no-cpu-baseline` in a fresh process, as a rank of an
+    N > 1 run is: the headline's step with its records packed and gathered to rank 0 by RCCL (one rank: the identity, through
+    ProcessGroupNCCL) on the gather stream, every step."""
+    import subprocess
+    t_leg = time.perf_counter()
+    cmd = [sys.executable, _BENCH, "--force-gather-path", "--one-rank-rccl", "--no-legs", "--no-cpu-baseline",
+           "--steps", str(steps), "--warmup", "5"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(_BENCH))
+        if out.returncode != 0:
+            return {"error": f"exit {out.returncode}: {out.stderr[-400:]}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+        d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        g = d["gather"]
+        return {"workload": "the headline's step with every step's records packed on the result stream and gathered to rank 0 by RCCL "
+                            "on the gather stream - a process group of ONE rank (all a one-GPU box allows), a process of its own",
+                "backend": g.get("backend"), "world_size_seen_by_the_process_group": g.get("world_size_seen_by_the_process_group"),
+                "steps": steps, "ms_per_step": d["ms_per_step"], "ms_per_step_without_pack_and_gather": g.get("ms_per_step_without_pack_and_gather"),
+                "all_scenes_cycles_per_s": d["all_scenes_cycles_per_s"], "gather_ms_on_its_stream": g.get("gather_ms_on_its_stream"),
+                "gather_hidden_behind_compute_frac": g.get("gather_hidden_behind_compute_frac"),
+                "records_complete_on_rank0": g.get("records_complete_on_rank0"), "doubles_per_scene": g.get("doubles_per_scene"),
+                "sweep_frac": d["roofline"]["frac"], "pipeline": d["config"]["pipeline"],
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
+def staged_subprocess_leg(steps, options):
+    """`python bench.py --pipeline staged --no-legs --no-cpu-baseline [--opt ...]` in a fresh process (this one waits, its GPU
+    work fenced): the staged form's step time and its sweep's launches, as that command prints them."""
+    import subprocess
+    t_leg = time.perf_counter()
+    cmd = [sys.executable, _BENCH, "--pipeline", "staged", "--no-legs", "--no-cpu-baseline", "--steps", str(steps),
+           "--warmup", "5"]
+    for k, v in options.items():
+        cmd += ["--opt", f"{k}={v}"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(_BENCH))
+        if out.returncode != 0:
+            return {"error": f"exit {out.returncode}: {out.stderr[-400:]}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+        d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        return {"pipeline": "staged (emp_set_pipeline(1)), a process of its own", "batches_in_flight": 2, "options": dict(options),
+                "steps": steps, "ms_per_step": d["ms_per_step"], "all_scenes_cycles_per_s": d["all_scenes_cycles_per_s"],
+                "fully_planned_cycles_per_s": d["value"],
+                "sweep_mean_launch_us": d["roofline"]["mean_launch_us"], "sweep_frac": d["roofline"]["frac"],
+                "sweep_frac_alone": d["roofline"]["frac_alone"],
+                "note": ("the sweep of step k waits (stream-side) for the densification and path QP of step k-1 and overlaps only the "
+                         "Cartesian tail: the HBM-bound kernel at its best" if options.get("sweep_exclusive") else
+                         "the headline's form until round 5: longer steps, the HBM-bound sweep beside nothing but the previous batch's "
+                         "Cartesian tail.  In the headline's three lanes the same sweep shares the chip with the edge-cost kernels of "
+                         "two other batches and its launches last about twice as long: that is the schedule, not the kernel"),
+                "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
