@@ -317,8 +317,11 @@ def main():
     # ---- the metric's lattice on SURVEY.md 8(d)'s own geometry (arc radii 150-1000 m, half of the scenes with the
     # survey's slalom layout, half of them started off the reference-line nodes), and the first scenes of the
     # benchmark batch (gentle arcs, corridor layout, start off the nodes: scenes.BENCH_START_AHEAD)
+    # ... and its first scenes with the "worst" obstacle layout (every obstacle within reach of the same columns: edges with
+    # several obstacles in reach at once - the several-obstacle ring of the edge kernel against the reference itself)
     for tag, kw in (("tight", dict(per_seed=S.survey_geometry_kwargs)),
-                    ("bench", dict(scene_kw=dict(start_ahead=S.BENCH_START_AHEAD)))):
+                    ("bench", dict(scene_kw=dict(start_ahead=S.BENCH_START_AHEAD))),
+                    ("worst", dict(scene_kw=dict(start_ahead=S.BENCH_START_AHEAD, dist="worst")))):
         res = cycles_for(pp, pu, S.CFG2, list(range(32)), **kw)
         np.savez_compressed(os.path.join(outdir, f"cycle_{S.CFG2.name}_{tag}.npz"), **res)
         st = res["status"]

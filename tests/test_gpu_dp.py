@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6
 GOLD = [(S.CFG1, "cycle_cfg1_20x5_0obs.npz"), (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz"),
         (S.CFG2, "cycle_cfg2_40x9_8obs.npz"), (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz"),
-        (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz")]
+        (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz"), (S.CFG2, "cycle_cfg2_40x9_8obs_worst.npz")]
 
 
 @pytest.fixture(scope="module")

@@ -42,6 +42,7 @@ CYCLES = [(S.CFG1, "cycle_cfg1_20x5_0obs.npz", {}),
           (S.CFG2, "cycle_cfg2_40x9_8obs.npz", {}),
           (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz", {}),       # SURVEY 8(d)'s geometry: arc radii 150-1000 m
           (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz", {}),       # first scenes of the benchmark batch (start off the nodes)
+          (S.CFG2, "cycle_cfg2_40x9_8obs_worst.npz", {}),       # the same seeds, every obstacle beside the same columns
           (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t7.npz", dict(decimate=1, use_qp=True, midpoint=False)),
           (S.CFG_DEFAULT, "cycle_default_6x12_3obs_t6.npz", dict(decimate=1, use_qp=False, midpoint=False))]
 
@@ -95,7 +96,8 @@ def test_faithful_port_full_cycle(cfg, fname, mode):
                                        (S.CFG_DEFAULT, "cycle_default_6x12_3obs.npz"),
                                        (S.CFG2, "cycle_cfg2_40x9_8obs.npz"),
                                        (S.CFG2, "cycle_cfg2_40x9_8obs_tight.npz"),
-                                       (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz")])
+                                       (S.CFG2, "cycle_cfg2_40x9_8obs_bench.npz"),
+                                       (S.CFG2, "cycle_cfg2_40x9_8obs_worst.npz")])
 def test_exact_oracle_dp_index_exact(cfg, fname):
     """Closed-form DP == reference DP: rows index-exact on every golden scene, s exact, l 1e-6."""
     g = load_golden(fname)

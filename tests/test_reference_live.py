@@ -27,7 +27,7 @@ pytestmark = pytest.mark.skipif(not ref_loader.reference_available(),
 #: generator script -> the fixtures it writes
 GENERATORS = {
     "make_golden.py": ["cycle_cfg1_20x5_0obs.npz", "cycle_default_6x12_3obs.npz", "cycle_cfg2_40x9_8obs.npz",
-                       "cycle_cfg2_40x9_8obs_tight.npz", "cycle_cfg2_40x9_8obs_bench.npz",
+                       "cycle_cfg2_40x9_8obs_tight.npz", "cycle_cfg2_40x9_8obs_bench.npz", "cycle_cfg2_40x9_8obs_worst.npz",
                        "cycle_default_6x12_3obs_t7.npz", "cycle_default_6x12_3obs_t6.npz", "edges.npz", "functions.npz",
                        "qp_formulation.npz"],
     "make_golden_speed.py": ["speed.npz"],
