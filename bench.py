@@ -582,6 +582,13 @@ def main():
                     "alone_mean_launch_us": (round(kernels["dp_sweep"] * 1e3, 2) if "dp_sweep" in kernels else None)}
         if alt and alt["sweep_mean_launch_us"] > 0:
             alt["sweep_roofline_frac"] = round(bytes_dp / (alt["sweep_mean_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if roof is not None and pmode >= 2:
+            # `frac` above is the kernel inside THIS schedule (lanes: two other batches' edge-cost kernels write their tensors
+            # through the caches the sweep reads its own from); the same kernel in the schedules that leave it (nearly) alone,
+            # measured by the legs of this very run, next to it - null when the legs did not run
+            roof["frac_is"] = "the sweep inside the lane schedule; the kernel's own figures are frac_alone and the two below"
+            roof["frac_in_the_staged_form"] = (legs.get("staged_leg") or {}).get("sweep_frac")
+            roof["frac_held_back_in_the_staged_form"] = (legs.get("exclusive_sweep_leg") or {}).get("sweep_frac")
         # Secondary figures from the diagnostic pass (event-bracketed kernels; not part of the timed region):
         # the edge-cost kernel against the FP64 vector peak with SURVEY.md 8(d)'s ALGORITHMIC flop count next to what
         # the committed SQ counter profile says was executed (obstacles out of reach are skipped at run time and
