@@ -212,6 +212,44 @@ from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, gather_
                         rccl_gather_subprocess_leg, roofline_step, secondary_leg, staged_subprocess_leg)
 
 
+def self_launch_argv(argv, n, port, python=None):
+    """The command a bare `python bench.py --gpus N ...` (N > 1, no WORLD_SIZE in the environment) re-executes itself as: the
+    driver's own multi-rank form, one process per GPU under torch.distributed.run on the loopback address, `argv` (sys.argv[1:])
+    passed through unchanged."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and nobody having launched the ranks: launch them (reference test_9.py:225-227 is its
+    only process split - a planner process beside the driver; here N planner processes, one per GPU).  Rank 0's ONE JSON line is
+    passed through on stdout, everything else the children print goes to stderr; the exit code is torch.distributed.run's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = self_launch_argv(argv, args.gpus, port)
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            lines.append(ln.rstrip())
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 1
+        print("[bench] the ranks exited without a JSON line", file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +257,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["cfg2", "cfg5"], default="cfg2", help="cfg2 = BASELINE configs[2]/[3] (default); cfg5 = configs[4]")
     ap.add_argument("--scenes-per-gpu", type=int, default=0, help="default 4096")
+    ap.add_argument("--total-scenes", type=int, default=0,
+                    help="STRONG scaling: this many scenes in all, sharded contiguously over the ranks (BASELINE configs[3] as "
+                         "written: --total-scenes 32768 = 16384 / 8192 / 4096 per GPU at 2 / 4 / 8); the line then says "
+                         "\"scaling\": \"strong\".  Default 0 = weak scaling at --scenes-per-gpu per GPU")
     ap.add_argument("--scene-dist", choices=["corridor", "survey", "worst"], default="corridor")
     ap.add_argument("--start-ahead", type=float, default=2.7,
                     help="planning start, metres ahead of the ego (scenes.BENCH_START_AHEAD = 2.7: off the reference-line nodes; 2.0 "
@@ -266,6 +308,8 @@ def main():
     args = ap.parse_args()
     if args.latency:
         return latency_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args, sys.argv[1:])
 
     from emplanner_carla_amd import _lib as L
     # lane mode: a hardware queue per stream; must precede HIP's initialisation (_lib.py).  Twelve since round 5: three lanes, the
@@ -290,6 +334,9 @@ def main():
     # device, gloo moves CUDA tensors through the host - so that the whole multi-rank step loop can be exercised on a
     # one-GPU box; tests/test_gpu_bench.py.  The driver's runs never set it.)
     backend = os.environ.get("EMP_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"[bench] {world} ranks on {torch.cuda.device_count()} visible GPU(s): RCCL wants one device per rank "
+                         f"(--gpus N must not exceed the node's GPUs)")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -331,8 +378,15 @@ def main():
 
     wide = args.config == "cfg5"
     cfg = S.CFG5 if wide else S.CFG2
-    B = args.scenes_per_gpu or 4096
-    total = B * world
+    if args.total_scenes > 0:                         # strong scaling: the total is fixed, a rank's shard shrinks with N
+        if args.scenes_per_gpu:
+            raise SystemExit("--total-scenes and --scenes-per-gpu are two ways of saying the size: give one")
+        total = args.total_scenes
+        B = emp_dist.shard_range(total, 0, world)[1]  # the largest shard (rank 0's)
+    else:
+        B = args.scenes_per_gpu or 4096
+        total = B * world
+    scaling = "strong" if args.total_scenes > 0 else "weak"
     start, count = emp_dist.shard_range(total, rank, world)
     scene_kw = scene_kwargs(args)
     # DIFFERENT SCENES EVERY STEP: --input-batches resident batches (default 4 up to 8192 scenes per GPU, else 1), step i plans
@@ -468,6 +522,8 @@ def main():
                 "world_size_seen_by_the_process_group": (dist.get_world_size() if (world > 1 or pg_one) else 1),
                 "ms_per_step_per_rank": [round(v, 4) for v in per_rank],
                 "ms_per_step_min_max_over_ranks": [round(min(per_rank), 4), round(max(per_rank), 4)],
+                # the destination rank takes in (N - 1) blocks per step on top of its own shard: what that costs it
+                "rank0_extra_ms_over_the_slowest_other_rank": (round(per_rank[0] - max(per_rank[1:]), 4) if len(per_rank) > 1 else None),
                 "ms_per_step_without_pack_and_gather": round(ms_without, 4),
                 "gather_ms_on_its_stream": None if gms is None else {"mean": round(gms[0], 4), "min": round(gms[1], 4), "max": round(gms[2], 4), "count": gms[3]},
                 "gather_hidden_behind_compute_frac": None}
@@ -519,7 +575,7 @@ def main():
     # ---- secondary legs (N = 1, the default workload only): other workloads, observed by the same command, after the headline
     # and its diagnostic pass; each is a short measurement of its own and never touches the headline's numbers
     legs = {}
-    if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096)
+    if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096) and args.total_scenes in (0, 4096)
             and args.dp_mode == "two_kernel" and args.pipeline == DEFAULT_PIPELINE and args.scene_dist == "corridor"):
         # (a) the staged pipeline of rounds 2-5 (two batches: the front stage of one beside the back stage of the other; the sweep
         # overlaps only the previous batch's Cartesian tail), with the library's default options and with the sweep held back
@@ -670,13 +726,14 @@ def main():
             "rccl_world_size": (dist.get_world_size() if world > 1 else None),     # what the process group itself reports
             "process_group_backend": (dist.get_backend() if world > 1 else None),
             "untimed_steps_before_the_timed_region": args.warmup + settle,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]/[3]" if not wide else "BASELINE configs[4]")
                                    + ": full planning cycle per scene (projection, S-L DP, path QP, Frenet->Cartesian, "
                                      "smoothing QP, heading/kappa)" + (", then generate_st_graph + the S-T speed DP" if wide else "")
                                    + ", inputs resident in HBM" + gather_note,
-                       "scenes_per_gpu": count, "total_scenes": total, "input_batches": n_in,
+                       "scenes_per_gpu": count, "total_scenes": total,
+                       "scenes_per_rank": [emp_dist.shard_range(total, r, world)[1] for r in range(world)], "input_batches": n_in,
                        "input_batches_note": "step i plans resident batch i mod input_batches: different scenes every step",
                        "lattice": f"col={cfg.col} x row={cfg.row}",
                        "sample_s": cfg.sample_s, "sample_l": cfg.sample_l, "obstacles": cfg.n_obs,
@@ -723,4 +780,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

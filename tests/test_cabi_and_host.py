@@ -457,3 +457,37 @@ def test_dropin_surface_matches_the_reference_signature_fixture():
                     assert not extra, f"{rel}: {cname} defines {extra}, which the reference lacks"
     assert not problems, "\n".join(problems)
     assert checked >= 45
+
+
+def test_bare_bench_command_relaunches_itself_as_n_ranks(tmp_path):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment must not run ONE rank: it
+    re-executes itself under torch.distributed.run with N processes on the loopback address, passes its own arguments through
+    and prints rank 0's one JSON line.  CPU check of the argv and of the pass-through (a stand-in interpreter prints what it
+    was started with and a line of noise - no GPU, no rendezvous here)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--total-scenes", "32768"]
+    cmd = bench.self_launch_argv(argv, 8, 29123, python="py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == argv
+    # the pass-through: a fake `python` that ignores torch.distributed.run and answers like N ranks would
+    fake = tmp_path / "fakepy"
+    fake.write_text("#!/bin/sh\necho 'NCCL version banner'\necho '{\"n_gpus\": 2, \"argv\": \"'\"$*\"'\", \"ws\": \"'\"$WORLD_SIZE\"'\"}'\n")
+    fake.chmod(0o755)
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; sys.executable = {str(fake)!r}; "
+            f"sys.argv = ['bench.py', '--gpus', '2', '--steps', '3']; sys.exit(bench.main() or 0)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout                        # ONE line on stdout: the banner went to stderr
+    import json
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "--nproc-per-node 2" in d["argv"] and d["argv"].endswith("--gpus 2 --steps 3")
+    assert "NCCL version banner" in out.stderr and "launching 2 ranks" in out.stderr
+    # with WORLD_SIZE set (the driver's own launch) bench.py does NOT relaunch: it goes on to initialise its rank
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:' in src

@@ -200,3 +200,28 @@ def test_rccl_calls_of_the_multi_gpu_path_with_one_rank():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "backend nccl world 1" in out.stdout and "rccl smoke ok" in out.stdout
+
+
+@pytest.mark.parametrize("size", [("--scenes-per-gpu", "1024"), ("--total-scenes", "2051")], ids=["weak", "strong_ragged"])
+def test_bare_command_with_gpus_2_launches_two_ranks(size):
+    """The BARE command - `python bench.py --gpus 2 ...`, no torch.distributed.run, no WORLD_SIZE - must yield a two-rank line:
+    bench.py re-executes itself under torch.distributed.run (gloo here: both ranks share the one GPU).  With --total-scenes the
+    total is fixed and sharded (BASELINE configs[3] as written: strong scaling), ragged shards included."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--settle-steps", "4",
+           "--no-cpu-baseline", *size]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(EMP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]                         # stdout is rank 0's ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["gather"]["records_complete_on_rank0"] is True
+    g = d["gather"]
+    assert len(g["ms_per_step_per_rank"]) == 2 and g["rank0_extra_ms_over_the_slowest_other_rank"] is not None
+    assert 0.0 <= g["gather_hidden_behind_compute_frac"] <= 1.0 and g["world_size_seen_by_the_process_group"] == 2
+    if "--total-scenes" in size:
+        assert d["scaling"] == "strong" and d["config"]["total_scenes"] == 2051 and d["config"]["scenes_per_rank"] == [1026, 1025]
+    else:
+        assert d["scaling"] == "weak" and d["config"]["total_scenes"] == 2048 and d["config"]["scenes_per_rank"] == [1024, 1024]
+    assert d["value"] > 1e4 and 0.8 < d["scenes_fully_planned_frac"] < 0.95
