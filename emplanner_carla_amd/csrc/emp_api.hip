@@ -531,7 +531,7 @@ void emp_destroy(emp_ctx* ctx) {
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->ev_h2d) (void)hipEventDestroy(ctx->ev_h2d);
     if (ctx->ev_host_last) (void)hipEventDestroy(ctx->ev_host_last);
-    for (void* hp : ctx->pinned) (void)hipHostFree(hp);
+    for (auto& hp : ctx->pinned) (void)hipHostFree(hp.p);
     if (ctx->clock_probe.p) (void)hipFree(ctx->clock_probe.p);
     if (ctx->clock_probe_done) (void)hipEventDestroy(ctx->clock_probe_done);
     if (ctx->edge_probe.p) (void)hipFree(ctx->edge_probe.p);
@@ -1487,8 +1487,7 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
             if (!mode) return;
             c->lane = (c->lane + 1) % c->lanes_in_use();
             ++c->cycle_calls;
-            ln = &c->lanes[c->lane];
-            ln->ticket = c->cycle_calls;
+            ln = &c->lanes[c->lane];                 // (ln->ticket changes below, after the host-side wait for the lane's previous call)
             std::swap(c->pool, ln->pool);
             if (mode != EMP_PIPELINE_STAGED) {
                 c->active_lane = c->lane;
@@ -1518,7 +1517,17 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         EMP_HIP(ctx, hipEventRecord(lane.ln->ev_in, lane.main_stream));
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, lane.ln->ev_in, 0));
     }
-    if (piped) lane.ln->host_valid = false;
+    if (piped) {
+        // Only now - the previous occupant's outputs are in its caller's arrays - does the lane stop answering for the previous
+        // ticket: emp_wait_ticket(T) on another thread either still finds the lane under T with its event valid and waits for
+        // the same event, or finds no lane under T, which now MEANS that this thread has waited for T already (the advisor's
+        // round-5 finding: the ticket used to change before the wait, and a waiter in that window returned at once).
+        lane.ln->host_valid = false;
+        lane.ln->ticket = ctx->cycle_calls;
+        // A pinned call's inputs go into the lane's pool over the copy stream.  If the lane's previous occupant was an EMP_DEVICE
+        // cycle there has been no host-side wait for it: the copy stream waits for its kernels instead.
+        if (pinned && !staged && lane.ln->done_valid) EMP_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, lane.ln->ev_done, 0));
+    }
     // EMP_OPT_CYCLE_GRAPH: one batch at a time on device pointers - the third consecutive call with one signature is captured,
     // the following ones are one hipGraphLaunch.  The signature is everything a launch argument is made of; the context's
     // allocation count says whether a temporary or a lattice table moved or changed since the capture.
@@ -1782,9 +1791,10 @@ int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back) {
 
 int emp_wait_ticket(emp_ctx* ctx, uint64_t ticket) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    // Touches nothing a concurrent emp_plan_cycle on another thread changes for THIS ticket's lane: the lane's event exists
-    // since the call that got the ticket, and the lane is not reused before four more calls - whose first act is to wait for
-    // the same event.  A ticket that no lane holds any more has therefore been waited for already.
+    // Reads two atomics per lane (emp_context.h Lane).  The lane's event exists since the call that got the ticket; a call
+    // that takes the lane over waits - on the host - for that same event BEFORE it changes the lane's ticket, so a ticket that no
+    // lane holds any more has been waited for already.  (A waiter that read the old ticket just before it changed waits for the
+    // event as re-recorded by the new call: longer than needed, never shorter.)
     for (auto& ln : ctx->lanes)
         if (ln.ticket == ticket && ln.host_valid && ln.ev_host) {
             const hipError_t e = hipEventSynchronize(ln.ev_host);
@@ -1799,13 +1809,13 @@ int emp_host_alloc(emp_ctx* ctx, uint64_t bytes, void** out) {
     EMP_HIP(ctx, hipSetDevice(ctx->device));
     void* p = nullptr;
     EMP_HIP(ctx, hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault));
-    ctx->pinned.push_back(p);
+    ctx->pinned.push_back({p, (size_t)(bytes ? bytes : 8)});
     *out = p;
     return EMP_OK;
 }
 int emp_host_free(emp_ctx* ctx, void* ptr) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    auto it = std::find(ctx->pinned.begin(), ctx->pinned.end(), ptr);
+    auto it = std::find_if(ctx->pinned.begin(), ctx->pinned.end(), [&](const emp_ctx::Pinned& a) { return a.p == ptr; });
     EMP_REQUIRE(ctx, it != ctx->pinned.end(), "not an emp_host_alloc pointer of this context");
     EMP_HIP(ctx, (hipError_t)sync_all(ctx));
     EMP_HIP(ctx, hipHostFree(ptr));

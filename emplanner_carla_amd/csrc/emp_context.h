@@ -8,12 +8,25 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/emplanner.h"
+
+// an atomic that a std::vector element may hold (copyable: the copy is a plain load / store, made only while no other thread
+// can be looking - emp_set_pipeline resizing the lanes)
+template <typename T>
+struct Shared {
+    std::atomic<T> v;
+    Shared(T x = T()) : v(x) {}
+    Shared(const Shared& o) : v(o.v.load()) {}
+    Shared& operator=(const Shared& o) { v.store(o.v.load()); return *this; }
+    Shared& operator=(T x) { v.store(x, std::memory_order_release); return *this; }
+    operator T() const { return v.load(std::memory_order_acquire); }
+};
 
 struct emp_ctx {
     int device = 0;
@@ -63,8 +76,11 @@ struct emp_ctx {
         hipStream_t stream = nullptr;
         hipEvent_t ev_in = nullptr, ev_front = nullptr, ev_done = nullptr, ev_tail = nullptr;
         hipEvent_t ev_host = nullptr;   // EMP_HOST_PINNED cycles: the lane's latest cycle's outputs have reached the caller's host arrays
-        bool host_valid = false;
-        uint64_t ticket = 0;            // emp_cycle_ticket of the lane's latest cycle
+        // `ticket` and `host_valid` are the two fields emp_wait_ticket reads from ANOTHER thread while a call is in progress:
+        // atomics, and a call that takes the lane over changes them only AFTER its own host-side wait for the previous
+        // occupant's outputs (emp_plan_cycle) - until then the lane still answers for the previous ticket
+        Shared<bool> host_valid{false};
+        Shared<uint64_t> ticket{0};     // emp_cycle_ticket of the lane's latest cycle
         hipEvent_t ev_qp = nullptr;     // STAGED: end of the cycle's path QP on the back stream (EMP_OPT_SWEEP_EXCLUSIVE = 2)
         hipEvent_t ev_enrich = nullptr; // STAGED: end of the cycle's densification kernel on the back stream (EMP_OPT_EDGE_AFTER_ENRICH)
         hipEvent_t ev_edge = nullptr;   // LANES: end of the cycle's edge-cost kernel (EMP_OPT_LANE_EDGE_ORDER)
@@ -78,7 +94,11 @@ struct emp_ctx {
     hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
     hipEvent_t ev_h2d = nullptr;        // the latest call's inputs have arrived
     hipEvent_t ev_host_last = nullptr;  // non-pipelined pinned call: outputs have reached the host
-    std::vector<void*> pinned;          // emp_host_alloc allocations still alive (freed by emp_destroy)
+    struct Pinned {
+        void* p;
+        size_t bytes;
+    };
+    std::vector<Pinned> pinned;         // emp_host_alloc allocations still alive (freed by emp_destroy)
     // STAGED: the event the front stage's LAST kernel (the sweep) is asked to signal when it completes (hipExtLaunchKernelGGL's
     // stop event: no marker packet behind the kernel), and the event that launch did attach - its own timing event when the
     // kernel is being timed, else front_stop, else nullptr (launchers that attach nothing: the caller records an event).
@@ -317,29 +337,47 @@ class Stage {
         void** slot;       // async_host: where the device pointer goes once it is known
     };
     static constexpr uintptr_t kPending = 8;     // non-null placeholder of a deferred pointer (never dereferenced)
-    // device memory for a call's arrays (async_host).  If the host arrays span a block with less than 1/8 of padding, the
-    // device side is one block with the same offsets (inputs: copied at once; outputs: block_out_ remembers it for finish_async).
+    // device memory for a call's arrays (async_host).  ONE device block with the host offsets - and one PCIe copy per direction -
+    // only where that provably touches nothing but the call's own arrays: all of them inside ONE emp_host_alloc allocation of
+    // this context, with at most kBlockGap bytes (alignment padding) between neighbours.  Outputs moved as a block overwrite
+    // that padding (include/emplanner.h, EMP_HOST_PINNED).  Everything else - arrays allocated one by one, a smaller batch at
+    // the head of a bigger slot, foreign data carved between two outputs - is copied array by array.
+    static constexpr size_t kBlockGap = 512;
+    bool one_block(const std::vector<Back>& v, uintptr_t* lo_out, size_t* span_out) const {
+        if (v.size() < 2) return false;
+        std::vector<std::pair<uintptr_t, size_t>> a;
+        for (auto& b : v)
+            if (b.bytes) a.push_back({(uintptr_t)b.host, b.bytes});
+        if (a.size() < 2) return false;
+        std::sort(a.begin(), a.end());
+        const uintptr_t lo = a.front().first;
+        uintptr_t end = lo;
+        for (auto& x : a) {
+            if (x.first < end || x.first - end > kBlockGap) return false;      // overlapping, or more than padding in between
+            end = x.first + x.second;
+        }
+        for (auto& al : ctx_->pinned)
+            if (lo >= (uintptr_t)al.p && end <= (uintptr_t)al.p + al.bytes) {
+                *lo_out = lo;
+                *span_out = end - lo;
+                return true;
+            }
+        return false;
+    }
     int place(std::vector<Back>& v, bool inputs) {
         if (v.empty()) return EMP_OK;
-        uintptr_t lo = ~(uintptr_t)0, hi = 0;
-        size_t sum = 0;
-        for (auto& b : v) {
-            lo = std::min(lo, (uintptr_t)b.host);
-            hi = std::max(hi, (uintptr_t)b.host + b.bytes);
-            sum += b.bytes;
-        }
-        const size_t span = hi - lo;
-        const bool block = v.size() > 1 && span <= sum + sum / 8 + 4096 * v.size();
-        if (block) {
+        uintptr_t lo = 0;
+        size_t span = 0;
+        if (one_block(v, &lo, &span)) {
             void* d = nullptr;
             int rc = pool_get(ctx_, span, &d);
             if (rc) return rc;
             for (auto& b : v) {
-                b.dev = (char*)d + ((uintptr_t)b.host - lo);
+                b.dev = b.bytes ? (char*)d + ((uintptr_t)b.host - lo) : d;
                 *b.slot = b.dev;
             }
             if (inputs) {
-                if (span) EMP_HIP(ctx_, hipMemcpyAsync(d, (void*)lo, span, hipMemcpyHostToDevice, ctx_->copy_stream));
+                EMP_HIP(ctx_, hipMemcpyAsync(d, (void*)lo, span, hipMemcpyHostToDevice, ctx_->copy_stream));
             } else {
                 block_out_ = {(void*)lo, d, span, nullptr};
             }

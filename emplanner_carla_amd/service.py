@@ -116,23 +116,46 @@ class CycleStream:
             with self._lock:
                 ring = self._ring(dp, B, 51, max(int(a["obs_xy"].shape[1]), self.max_static))
             slot = self._take_slot(ring)                                    # may wait for another session's result() - outside the lock
-        with self._lock:
-            pl = self.planner
-            ref, n_ref, match, _, st_ref = pl.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
-            if B == 0:
-                return dict(B=0, st_ref=st_ref, match=match, M=max_path_points(dp), slot=None, ring=None)
-            assert ref.shape[1] == slot.max_ref, "the front end hands over 51-point reference lines (planning_utils.py:244-246)"
-            n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
-            slot.inputs["obs_xy"][:B] = 0.0
-            slot.inputs["obs_xy"][:B, :a["obs_xy"].shape[1]] = a["obs_xy"]
-            slot.load(ref_line=ref, n_ref=n_ref_used, origin_xy=a["veh"], start_xy=a["pred"], start_v=a["v"], start_a=a["a"],
-                      n_obs=a["n_obs"], dyn_dis_speed=a["dyn"])
-            cap, slot.B = slot.B, B
-            try:
-                pl.plan_cycle(dp, qp, sp, None, None, None, None, None, None, None, None, slot=slot)
-            finally:
-                slot.B = cap
-            return dict(B=B, st_ref=st_ref, match=match, M=slot.max_pts, slot=slot, ring=ring)
+        issued = False
+        try:
+            with self._lock:
+                pl = self.planner
+                ref, n_ref, match, _, st_ref = pl.reference_line(sp, a["global_path"], a["n_global"], a["pred"], a["pre_match"])
+                if B == 0:
+                    return dict(B=0, st_ref=st_ref, match=match, M=max_path_points(dp), slot=None, ring=None)
+                if ref.shape[1] != slot.max_ref:
+                    raise ValueError("the front end hands over 51-point reference lines (planning_utils.py:244-246)")
+                n_ref_used = np.where(st_ref == 0, n_ref, 2).astype(np.int32)
+                slot.inputs["obs_xy"][:B] = 0.0
+                slot.inputs["obs_xy"][:B, :a["obs_xy"].shape[1]] = a["obs_xy"]
+                slot.load(ref_line=ref, n_ref=n_ref_used, origin_xy=a["veh"], start_xy=a["pred"], start_v=a["v"], start_a=a["a"],
+                          n_obs=a["n_obs"], dyn_dis_speed=a["dyn"])
+                cap, slot.B = slot.B, B
+                try:
+                    issued = True                    # from here on the slot may carry a ticket: _release waits for it
+                    pl.plan_cycle(dp, qp, sp, None, None, None, None, None, None, None, None, slot=slot)
+                finally:
+                    slot.B = cap
+                return dict(B=B, st_ref=st_ref, match=match, M=slot.max_pts, slot=slot, ring=ring)
+        except BaseException:
+            # a failing request (a refused argument, a HIP error, a shape that does not fit) must not shrink the ring: after
+            # `depth` such requests every session would wait in _take_slot for ever (the advisor's round-5 finding)
+            if slot is not None:
+                self._release(ring, slot, wait=issued)
+            raise
+
+    def _release(self, ring, slot, wait=True):
+        """Hand a slot back to its ring.  ``wait``: a call may have been issued on it - its outputs must have landed (or the call
+        must have failed) before another batch writes the slot's inputs."""
+        try:
+            if wait:
+                slot.wait()
+        except Exception:                        # the wait itself failed: the slot still goes back, the error is the caller's
+            slot._ticket = None
+        finally:
+            with self._free:
+                ring.free.append(slot)
+                self._free.notify_all()
 
     def result(self, h):
         """(reference-line status, match index, CycleResult, max_pts) of a submitted batch, as ``plan_arrays`` returns them."""
@@ -140,11 +163,12 @@ class CycleStream:
         if h["slot"] is None:
             z = np.zeros((0,))
             return h["st_ref"], h["match"], CycleResult(*([z] * 10)), h["M"]
-        h["slot"].wait()                         # emp_wait_ticket: safe beside another thread's submit - the lock is NOT held
-        out = {k: np.array(v[:h["B"]]) for k, v in h["slot"].outputs.items()}
-        with self._free:                         # only now may another batch take the slot
-            h["ring"].free.append(h["slot"])
-            self._free.notify_all()
+        slot, h["slot"] = h["slot"], None        # a handle is consumed once, whatever happens below
+        try:
+            slot.wait()                          # emp_wait_ticket: safe beside another thread's submit - the lock is NOT held
+            out = {k: np.array(v[:h["B"]]) for k, v in slot.outputs.items()}
+        finally:
+            self._release(h["ring"], slot, wait=False)     # only now may another batch take the slot
         return h["st_ref"], h["match"], CycleResult(**out), h["M"]
 
     def plan_arrays(self, a, dp=None, qp=None, sp=None):

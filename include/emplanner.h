@@ -47,7 +47,13 @@ typedef enum emp_error {
  * the outputs are there.  EMP_DEVICE: device memory, used in place; the call returns at once (stream-ordered).
  * EMP_HOST_PINNED (ABI 10): page-locked host memory from emp_host_alloc.  Every entry point accepts it like EMP_HOST;
  * emp_plan_cycle additionally overlaps it (see there): inputs cross PCIe on a copy stream while the previous call computes,
- * outputs come back on a stream of their own, and with a pipeline set the call does not wait for them - emp_wait_cycle does. */
+ * outputs come back on a stream of their own, and with a pipeline set the call does not wait for them - emp_wait_cycle does.
+ * Layout contract of an EMP_HOST_PINNED cycle: the arrays may be any page-locked memory.  Arrays of one direction that lie inside
+ * ONE emp_host_alloc allocation of this context with at most 512 bytes between neighbours (alignment padding) cross PCIe as one
+ * copy; for outputs that copy also writes the padding bytes between them (contents unspecified) - nothing else is ever written.
+ * Any other layout (arrays allocated one by one, a smaller batch at the head of a larger slot, other data carved between two
+ * outputs) is copied array by array.  Within one pipeline do not alternate EMP_DEVICE and EMP_HOST_PINNED cycles faster than the
+ * pipeline depth unless the device-pointer call's inputs may be read late (the library orders the copies, not the caller's writes). */
 typedef enum emp_mem { EMP_HOST = 0, EMP_DEVICE = 1, EMP_HOST_PINNED = 2 } emp_mem;
 
 /* per-scene status bits */
@@ -125,7 +131,9 @@ int emp_wait_cycle(emp_ctx* ctx, int32_t calls_back);
 uint64_t emp_cycle_ticket(emp_ctx* ctx);
 /* Block until the host outputs of the EMP_HOST_PINNED cycle that got `ticket` are in place; a ticket older than the pipeline
  * depth has been waited for by the call that took its pool over: EMP_OK at once.  The ONE entry point that may be called from
- * another thread while a call on this context is in progress (a server thread waits for its batch while another submits). */
+ * another thread while a call on this context is in progress (a server thread waits for its batch while another submits): a pool
+ * keeps answering for its ticket until the call that takes it over has itself waited for that ticket's outputs.  Not beside
+ * emp_set_pipeline or emp_destroy. */
 int emp_wait_ticket(emp_ctx* ctx, uint64_t ticket);
 int emp_device_alloc(emp_ctx* ctx, uint64_t bytes, void** out);
 int emp_device_free(emp_ctx* ctx, void* ptr);

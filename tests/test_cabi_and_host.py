@@ -491,3 +491,88 @@ def test_bare_bench_command_relaunches_itself_as_n_ranks(tmp_path):
     # with WORLD_SIZE set (the driver's own launch) bench.py does NOT relaunch: it goes on to initialise its rank
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:' in src
+
+
+def test_failing_submit_does_not_shrink_the_cycle_stream_ring():
+    """service.CycleStream owns a ring slot from submit() to result().  A request that fails in between - a refused argument,
+    a HIP error, a shape that does not fit - must hand its slot back: the wire server answers the exception with an error
+    frame and KEEPS SERVING, so a leaked slot per failure would leave every session waiting in _take_slot after `depth`
+    failures.  Host logic only: a stand-in planner whose plan_cycle fails on demand."""
+    from emplanner_carla_amd import service
+    from emplanner_carla_amd.api import dp_params
+
+    class Slot:
+        def __init__(self):
+            self.B, self.max_ref, self.max_pts = 8, 51, 32
+            self.inputs = {"obs_xy": np.zeros((8, 4, 2))}
+            self.outputs = {k: np.zeros(8, np.int32) for k in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l",
+                                                                "path_len", "traj", "traj_len", "status")}
+            self._ticket, self.waits, self.use_dyn = None, 0, False
+
+        def load(self, **arrays):
+            return self
+
+        def wait(self):
+            self.waits += 1
+            if self._ticket == "poisoned":
+                self._ticket = None
+                raise RuntimeError("emp_wait_ticket failed")
+            self._ticket = None
+            return self
+
+    class Ring:
+        def __init__(self):
+            self.slots = [Slot() for _ in range(4)]
+
+        def close(self):
+            pass
+
+    class FakePlanner:
+        fail = None
+
+        def set_pipeline(self, mode):
+            pass
+
+        def set_fence(self, on):
+            pass
+
+        def host_ring(self, *a):
+            return Ring()
+
+        def reference_line(self, sp, g, n, pred, pre):
+            if self.fail == "reference_line":
+                raise RuntimeError("front end refused")
+            B = len(n)
+            return np.zeros((B, 51, 4)), np.full(B, 51, np.int32), np.zeros(B, np.int32), None, np.zeros(B, np.int32)
+
+        def plan_cycle(self, *a, slot=None, **kw):
+            if self.fail == "plan_cycle":
+                raise RuntimeError("EMP_REQUIRE: LDS too large for the layout")
+            slot._ticket = "poisoned" if self.fail == "wait" else 7
+
+    pl = FakePlanner()
+    stream = service.CycleStream(pl, capacity=8, max_static=4)
+    a = dict(global_path=np.zeros((2, 60, 4)), n_global=np.full(2, 60, np.int32), pred=np.zeros((2, 2)), veh=np.zeros((2, 2)),
+             v=np.zeros((2, 2)), a=np.zeros((2, 2)), pre_match=np.zeros(2, np.int32), obs_xy=np.zeros((2, 4, 2)),
+             n_obs=np.zeros(2, np.int32), dyn=np.full((2, 2), np.nan))
+    dp = dp_params()
+    ring = None
+    for how in ("reference_line", "plan_cycle") * 5:              # ten failures on a ring of four slots
+        pl.fail = how
+        with pytest.raises(RuntimeError):
+            stream.submit(a, dp=dp)
+        ring = next(iter(stream._rings.values()))
+        assert len(ring.free) == 4, f"a failing submit ({how}) leaked a slot"
+    pl.fail = "wait"                                               # the call is issued, the wait in result() fails
+    for _ in range(6):
+        h = stream.submit(a, dp=dp)
+        assert len(ring.free) == 3
+        with pytest.raises(RuntimeError):
+            stream.result(h)
+        assert len(ring.free) == 4 and h["slot"] is None
+    pl.fail = None
+    for _ in range(6):                                             # and the ring still works
+        st_ref, match, res, M = stream.plan_arrays(a, dp=dp)
+        assert res.status.shape == (2,) and len(ring.free) == 4
+    assert sorted(id(s) for s in ring.free) == sorted(id(s) for s in ring.slots)     # every slot exactly once
+    stream.close()
