@@ -29,6 +29,9 @@
 
 namespace emp {
 
+// (floating-point contraction: see emp_qp_wave.h)
+#pragma clang fp contract(fast)
+
 // ---- reductions over an aligned group of GP = 8 or 16 lanes: two quad permutes, the half-row mirror, (16:) the row mirror
 template <int GP, class Op>
 __device__ __forceinline__ double oct_reduce(double v, Op op) {
@@ -40,9 +43,9 @@ __device__ __forceinline__ double oct_reduce(double v, Op op) {
     return v;
 }
 template <int GP>
-__device__ __forceinline__ double oct_max(double v) { return oct_reduce<GP>(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double oct_max(double v) { return oct_reduce<GP>(v, [](double a, double b) { return vmax(a, b); }); }
 template <int GP>
-__device__ __forceinline__ double oct_min(double v) { return oct_reduce<GP>(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double oct_min(double v) { return oct_reduce<GP>(v, [](double a, double b) { return vmin(a, b); }); }
 template <int GP>
 __device__ __forceinline__ double oct_sum(double v) { return oct_reduce<GP>(v, [](double a, double b) { return a + b; }); }
 template <int GP>
@@ -116,6 +119,10 @@ __device__ __forceinline__ bool band_chol_rows(double (&a)[R][4], double (&rinv)
             acc0 = __builtin_fma(-u3_3, u3_3, acc0);
             diag[r] = acc0;
             const double rs = fast_rsqrt(acc0 > 0.0 ? acc0 : 1.0);
+            // The selects below are what keeps the eight problems of a wavefront apart (round 6 tried without: A holds exact
+            // zeros past column N-1 and every product that meets them is zero by induction - in exact arithmetic.  But a lane
+            // that is not final yet iterates on garbage that squares itself every lane-step and overflows after seven of them,
+            // 0 x NaN is NaN, and the first lane of the NEXT group reads these entries at every step: tools/qp_rows_test.hip).
             a[r][0] = acc0 * rs;
             a[r][1] = inband[r][1] ? acc1 * rs : 0.0;
             a[r][2] = inband[r][2] ? acc2 * rs : 0.0;
@@ -358,8 +365,8 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                     if (ok) {
                         Q.tmp[(base + r) * F + f] = zu[r][f] - zl[r][f];
                         Q.wgt[(base + r) * F + f] = zu[r][f] * isu[r][f] + zl[r][f] * isl[r][f];
-                        rp_max = fmax(rp_max, fmax(fabs(rpu[r][f]), fabs(rpl[r][f])));
-                        zmax = fmax(zmax, fmax(zu[r][f], zl[r][f]));
+                        rp_max = vmax(rp_max, vmax_abs(rpu[r][f], rpl[r][f]));
+                        zmax = vmax(zmax, vmax(zu[r][f], zl[r][f]));
                         mu += su[r][f] * zu[r][f] + sl[r][f] * zl[r][f];
                     }
                 }
@@ -391,7 +398,7 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
 #pragma unroll
                 for (int d = 1; d < 4; ++d) acc += ld(Q.P, (m - d) * 4 + d, m - d >= 0) * ux[r + 3 - d];
                 rd_m[r] = ok ? acc + gz[r] : 0.0;
-                rd_max = fmax(rd_max, fabs(rd_m[r]));
+                rd_max = vmax_abs(rd_max, rd_m[r]);
                 double e0 = Q.P[m * 4 + 0], e1 = Q.P[m * 4 + 1], e2 = Q.P[m * 4 + 2];
                 const double e3 = Q.P[m * 4 + 3];
 #pragma unroll
@@ -475,8 +482,8 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                     dzua[r][f] = -zu[r][f] - (zu[r][f] * isu[r][f]) * dsua[r][f];
                     dzla[r][f] = -zl[r][f] - (zl[r][f] * isl[r][f]) * dsla[r][f];
                     if (ok)
-                        ratio = fmax(ratio, fmax(fmax(-dsua[r][f] * isu[r][f], -dsla[r][f] * isl[r][f]),
-                                                 fmax(-dzua[r][f] * izu[r][f], -dzla[r][f] * izl[r][f])));
+                        ratio = vmax(ratio, vmax(vmax(-dsua[r][f] * isu[r][f], -dsla[r][f] * isl[r][f]),
+                                                 vmax(-dzua[r][f] * izu[r][f], -dzla[r][f] * izl[r][f])));
                 }
             }
             ratio = oct_max<GP>(ratio);
@@ -534,8 +541,8 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
                     dzu[r][f] = -(rcu[r][f] + zu[r][f] * dsu[r][f]) * isu[r][f];
                     dzl[r][f] = -(rcl[r][f] + zl[r][f] * dsl[r][f]) * isl[r][f];
                     if (ok)
-                        ratio = fmax(ratio, fmax(fmax(-dsu[r][f] * isu[r][f], -dsl[r][f] * isl[r][f]),
-                                                 fmax(-dzu[r][f] * izu[r][f], -dzl[r][f] * izl[r][f])));
+                        ratio = vmax(ratio, vmax(vmax(-dsu[r][f] * isu[r][f], -dsl[r][f] * isl[r][f]),
+                                                 vmax(-dzu[r][f] * izu[r][f], -dzl[r][f] * izl[r][f])));
                 }
             }
             ratio = oct_max<GP>(ratio);
@@ -644,5 +651,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
     __syncthreads();
     return rc;
 }
+
+#pragma clang fp contract(off)
 
 }  // namespace emp

@@ -30,13 +30,40 @@
 
 namespace emp {
 
+// Floating-point contraction is ON from here to the end of this header (and in emp_qp_rows.h, emp_smooth_rows.h): the library is
+// compiled with -ffp-contract=off because the DP is specified operation by operation and compared bit for bit (emp_core.h), but an
+// interior-point iteration is not - its result is a fixed point that does not depend on how a step is rounded, QP outputs are
+// judged at 1e-6 and certified against the KKT system - and a fused multiply-add is one instruction instead of two and rounds once.
+// Round 6: the rows form's loop went from 423 mul + 394 add + 178 fma to 291 + 452 of 1794 -> 1477 vector instructions, its spills to
+// accumulation registers from 101 to 36; results moved by 1e-9 at most (tools/lib_equal.py --diff).
+#pragma clang fp contract(fast)
+
 // Hardware reciprocal / reciprocal square root seeds (v_rcp_f64, v_rsq_f64: ~2^-27 relative) plus Newton steps.
 // Not correctly rounded (a few ulp): used only inside the interior-point iteration, whose result is a fixed
 // point that does not depend on how the steps are rounded.
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);     // (round 6 measured ONE step: same results to 1e-9, same duration - kept at two)
+    return r;
+}
+// max / min of two doubles as ONE v_max_f64 / v_min_f64.  fmax() compiles to the same instruction behind a canonicalisation
+// (v_max_f64 x, x, x) of every operand that might be a signalling NaN - 71 of the path QP loop's 163 v_max_f64.  The IPM's norms
+// and ratio tests need no NaN semantics beyond the instruction's own (a NaN operand loses against a number, like fmax; the
+// callers test `mu == mu` for a poisoned iterate).
+__device__ __forceinline__ double vmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax_abs(double a, double b) {     // max(|a|, |b|)
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ double fast_rsqrt(double x) {
@@ -1634,5 +1661,7 @@ __device__ inline int smooth_pair_wave(double* lds, const double* xy, int stride
     *out_y = Q1.u;
     return __any(rc != 0) ? 2 : 0;
 }
+
+#pragma clang fp contract(off)
 
 }  // namespace emp

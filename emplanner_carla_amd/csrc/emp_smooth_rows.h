@@ -13,6 +13,8 @@
 
 namespace emp {
 
+#pragma clang fp contract(fast)      // see emp_qp_wave.h
+
 // Banded Cholesky, half bandwidth 2, R consecutive rows per lane (row j = gl * R + r); see band_chol_rows.
 // a[r][0..2] = A[j][j..j+2] on entry, the factor row on return; low[r][e] = U[j-e][e] (e = 1, 2).
 template <int GP, int R>
@@ -244,5 +246,7 @@ __device__ inline int box_qp_active_set_rows(const double (&ref)[R], int m, cons
     *iters_out = iters;
     return valid ? state : 2;
 }
+
+#pragma clang fp contract(off)
 
 }  // namespace emp

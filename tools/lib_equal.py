@@ -41,8 +41,9 @@ if __name__ == "__main__":
         child(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
         sys.exit(0)
     a, b = sys.argv[1], sys.argv[2]
-    cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
-    n = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+    pos = [x for x in sys.argv[3:] if not x.startswith("--")]
+    cfg = pos[0] if len(pos) > 0 else "cfg2"
+    n = int(pos[1]) if len(pos) > 1 else 4096
     outs = []
     for k, lib in enumerate((a, b)):
         out = f"/tmp/lib_equal_{k}.npz"
@@ -50,5 +51,14 @@ if __name__ == "__main__":
         outs.append(np.load(out))
     bad = [k for k in outs[0].files if not np.array_equal(outs[0][k], outs[1][k], equal_nan=True)]
     ok = ((outs[0]["bench_status"] & ~1) == 0).mean()
+    if "--diff" in sys.argv:            # builds that may differ by rounding (solver arithmetic): how far apart, scene statuses first
+        for tag in ("bench", "tight"):
+            sa, sb = outs[0][f"{tag}_status"], outs[1][f"{tag}_status"]
+            both = ((sa & ~1) == 0) & ((sb & ~1) == 0)
+            print(f"  {tag}: status differs on {(sa != sb).sum()} of {len(sa)} scenes; planned by both {both.sum()}")
+            for k in ("dp_rows", "dp_s", "dp_l", "path_s", "path_l", "traj"):
+                x, y = outs[0][f"{tag}_{k}"][both], outs[1][f"{tag}_{k}"][both]
+                d = np.abs(x - y)
+                print(f"    {k:8s} max |a-b| {d.max():.3e}   max |a-b| / max(|b|, 1) {(d / np.maximum(np.abs(y), 1.0)).max():.3e}")
     print(f"{cfg} {n} scenes x 2 geometries: {'BIT-IDENTICAL' if not bad else 'DIFFERENT: ' + ', '.join(bad)} ({a} vs {b}; planned {ok:.3f})")
     sys.exit(1 if bad else 0)
