@@ -389,7 +389,7 @@ def gather_path_leg(pl, torch, emp_dist, cfg, scenes, steps, device, scene_kw=No
 FP64_PIPE_CYCLES, SQ_CHARGED_CYCLES, ENGINE_CLOCK_HZ, SIMDS = 4.31, 4.0, 2.4e9, 1024
 
 
-def roofline_step(cfg, count, scene_dist, ms_per_step, speed=False):
+def roofline_step(cfg, count, scene_dist, ms_per_step, speed=False, measured_clock_mhz=None):
     """The whole step against the chip's vector-issue capacity (the path is FP64-issue bound everywhere but in the sweep): the
     VALU-busy quad-cycles of the step's six kernels, from the committed SQ counter pass of this workload (kernels run one at a
     time there: what they NEED, whatever overlaps what in the step), over what 1024 SIMDs offer in ms_per_step."""
@@ -409,8 +409,20 @@ def roofline_step(cfg, count, scene_dist, ms_per_step, speed=False):
     busy = sum(per_kernel.values())
     capacity = SIMDS * ENGINE_CLOCK_HZ / 4.0 * ms_per_step * 1e-3
     frac = busy / capacity
+    at_clock = {}
+    if measured_clock_mhz:
+        # the counters count SHADER-clock cycles; under this path's FP64 load the chip does not hold its 2.4 GHz peak (the edge-cost
+        # kernel's own clock probe, read inside the timed schedule by bench.py): the capacity the step really had is smaller
+        f_meas = frac * ENGINE_CLOCK_HZ / (measured_clock_mhz * 1e6)
+        at_clock = {"engine_clock_hz_measured": round(measured_clock_mhz * 1e6),
+                    "engine_clock_measured_by": "EMP_OPT_EDGE_CLOCK_PROBE: shader-clock over 100 MHz reference ticks of the edge-cost "
+                                                "kernel's wavefronts, a few steps of the headline's own schedule after the timed region",
+                    "frac_at_the_measured_clock": round(f_meas, 4),
+                    "frac_at_the_measured_clock_with_the_measured_fp64_pipe_cost": round(f_meas * FP64_PIPE_CYCLES / SQ_CHARGED_CYCLES, 4)}
     return {"bound": "fp64_valu_issue", "unit": "fraction of the step's VALU issue capacity (1024 SIMDs) its kernels keep busy",
-            "frac": round(frac, 4), "frac_with_the_measured_fp64_pipe_cost": round(frac * FP64_PIPE_CYCLES / SQ_CHARGED_CYCLES, 4),
+            "frac": round(frac, 4), "frac_is": "at the nominal 2.4 GHz peak clock; frac_at_the_measured_clock is what the chip offered",
+            **at_clock,
+            "frac_with_the_measured_fp64_pipe_cost": round(frac * FP64_PIPE_CYCLES / SQ_CHARGED_CYCLES, 4),
             "valu_busy_quad_cycles_per_step": int(busy), "capacity_quad_cycles_per_step": int(capacity),
             "per_kernel_valu_busy_quad_cycles": per_kernel, "per_kernel_active_lane_frac": lanes,
             "engine_clock_hz": ENGINE_CLOCK_HZ, "fp64_pipe_cycles_per_wave_instruction": FP64_PIPE_CYCLES,

@@ -37,15 +37,14 @@ def hw_queues() -> int:
 EMP_HOST, EMP_DEVICE, EMP_HOST_PINNED = 0, 1, 2
 EMP_EDGE_CANONICAL, EMP_EDGE_TILED = 0, 1
 EMP_DP_FUSED, EMP_DP_TWO_KERNEL = 0, 1
-EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = 1, 8
+EMP_PIPELINE_AUTO, EMP_PIPELINE_STAGED, EMP_PIPELINE_MAX = -1, 1, 8
 
-# emp_option (include/emplanner.h): per-context tuning / A-B / test-hook values - the library reads no environment variable
-OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "sweep_variant": 4,
-           "fused_columns": 5, "st_order": 6, "sweep_exclusive": 7, "back_stream_cus": 8, "sweep_clock_probe": 9,
-           "enrich_on_front": 10, "edge_after_enrich": 11, "sweep_marker": 12, "edge_form": 13, "edge_cols_per_wave": 14, "edge_clock_probe": 15,
-           "lane_edge_order": 16, "cycle_graph": 17}
+# emp_option (include/emplanner.h; ABI 11: twelve of them): per-context tuning / A-B / test-hook values
+OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "edge_block": 3, "edge_form": 4, "sweep_exclusive": 5,
+           "edge_after_enrich": 6, "lane_edge_order": 7, "cycle_graph": 8, "sweep_clock_probe": 9, "edge_clock_probe": 10,
+           "foreign_streams": 11}
 #: the values a fresh context holds (everything else is 0)
-OPTION_DEFAULTS = {"st_order": 1, "edge_after_enrich": 1, "sweep_marker": 1}
+OPTION_DEFAULTS = {"edge_after_enrich": 1, "foreign_streams": 1}
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2
@@ -130,12 +129,14 @@ PROTOTYPES = {
     "emp_set_pipeline": (C.c_int, [_vp, C.c_int]),
     "emp_result_stream": (_vp, [_vp]),
     "emp_pipeline_depth": (C.c_int, [_vp]),
+    "emp_pipeline_form": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "emp_set_fence": (C.c_int, [_vp, C.c_int]),
     "emp_set_option": (C.c_int, [_vp, _i32, _i32]),
     "emp_get_option": (C.c_int, [_vp, _i32, C.POINTER(_i32)]),
     "emp_sweep_clock_mhz": (_f64, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_cycle_graph_replays": (C.c_int64, [_vp]),
     "emp_edge_probe": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i32)]),
+    "emp_edge_clock_mhz": (_f64, [_vp]),
     "emp_sweep_probe_spans": (C.c_int, [_vp, C.POINTER(_f64), C.POINTER(_f64)]),
     "emp_pack_records": (C.c_int, [_vp, _i32, _i32, _i32, _i32] + [_vp] * 8 + [C.c_int, C.c_int]),
     "emp_pack_trajectory_records": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 4 + [C.c_int, C.c_int]),
@@ -214,7 +215,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.emp_abi_version() != 10:
+    if lib.emp_abi_version() != 11:
         raise RuntimeError("libemplanner.so ABI version mismatch")
     _lib = lib
     return lib

@@ -418,22 +418,34 @@ class Planner:
         """Several batches in flight for consecutive ``plan_cycle`` calls on device tensors (include/emplanner.h,
         emp_set_pipeline).  ``mode``: False / 0 = off; True / "staged" / 1 = two batches, the back stage (path QP,
         Cartesian tail) of one overlapping the front stage (projection, DP) of the next; an int n >= 2 = n batches on n
-        lanes (a stream and a pool of temporaries each), whole cycles overlapping freely - the highest throughput.  The
+        lanes (a stream and a pool of temporaries each), whole cycles overlapping freely - the highest throughput; "auto" =
+        the library picks three lanes when every stream of the process gets a hardware queue of its own (GPU_MAX_HW_QUEUES,
+        option "foreign_streams") and the staged form otherwise (``pipeline_form()`` tells).  The
         outputs of a cycle are then complete on ``torch_result_stream()`` (lane mode: the lane of the LATEST call) and
         ``synchronize()`` waits for everything."""
-        m = L.EMP_PIPELINE_STAGED if (mode is True or mode == "staged") else max(int(mode), 0)
+        auto = isinstance(mode, str) and mode == "auto"
+        m = L.EMP_PIPELINE_AUTO if auto else L.EMP_PIPELINE_STAGED if (mode is True or mode == "staged") else max(int(mode), 0)
         if m >= 2 and m + 1 > L.hw_queues():
             import warnings
             warnings.warn(f"{m} lanes + the main stream on GPU_MAX_HW_QUEUES={L.hw_queues()} hardware queues: lanes will share "
-                          "queues and serialise (emplanner_carla_amd._lib.configure_hw_queues() before HIP initialises)",
+                          "queues and serialise (set_pipeline('auto') picks the form the process can sustain; "
+                          "emplanner_carla_amd._lib.configure_hw_queues() before HIP initialises gives it the queues)",
                           RuntimeWarning, stacklevel=2)
         self._check(self._lib.emp_set_pipeline(self._h, m))
+        if auto:                                 # the library chose: three lanes if every stream gets a hardware queue, else staged
+            m = int(self._lib.emp_pipeline_form(self._h, None, None))
         self._torch_lane_streams = {}            # the library destroys the streams the new mode does not use
         self.pipe_mode = m
         self.in_flight = 2 if m == L.EMP_PIPELINE_STAGED else max(m, 1)       # batches that overlap on the GPU
         self._retain = max(int(self._lib.emp_pipeline_depth(self._h)), self.in_flight)     # calls whose outputs stay referenced
         self.pipelined = m != 0
         self._inflight = []                      # emp_set_pipeline has drained every stream
+
+    def pipeline_form(self):
+        """(form, hardware queues seen, other streams counted): form 0 = off, 1 = staged, n = lanes (emp_pipeline_form); the two
+        counts are what the latest ``set_pipeline("auto")`` based its choice on (0, 0 after an explicit mode)."""
+        q, o = C.c_int32(0), C.c_int32(0)
+        return int(self._lib.emp_pipeline_form(self._h, C.byref(q), C.byref(o))), int(q.value), int(o.value)
 
     def set_fence(self, enabled: bool):
         """emp_set_fence: whether calls other than a pipelined ``plan_cycle`` wait for the cycles in flight (default) or
@@ -442,8 +454,8 @@ class Planner:
 
     def set_option(self, name, value: int):
         """emp_set_option (include/emplanner.h, emp_option): ``name`` is a key of ``_lib.OPTIONS`` (the list is appended to this
-        docstring at import) or the option's number.  Takes effect at the next call ("back_stream_cus": at the next
-        ``set_pipeline``).  The library reads no environment variable."""
+        docstring at import) or the option's number.  Takes effect at the next call ("foreign_streams": at the next
+        ``set_pipeline("auto")``).  The library reads no environment variable."""
         key = L.OPTIONS[name] if isinstance(name, str) else int(name)
         self._check(self._lib.emp_set_option(self._h, key, int(value)))
 
@@ -471,6 +483,11 @@ class Planner:
         if self._lib.emp_edge_probe(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)) != 0:
             return None
         return float(a.value), float(b.value), float(c.value), int(n.value)
+
+    def edge_clock_mhz(self):
+        """With option "edge_clock_probe" on: the shader clock (MHz) of the latest edge-cost launch, or None (emp_edge_clock_mhz)."""
+        mhz = float(self._lib.emp_edge_clock_mhz(self._h))
+        return None if mhz < 0 else mhz
 
     def sweep_probe_spans(self):
         """With option "sweep_clock_probe" on: (us between the first and the last wavefront START of a sweep launch, us from

@@ -158,7 +158,6 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
         // (ring form: a wavefront drains its rings once, at the end of its columns - four columns per wavefront while that
         // still leaves several thousand blocks: 120 x 21 at 4096 scenes 2.18 -> 2.01 ms)
         if (ring && (long long)d.tiles * ((ncol + 4 * wpb - 1) / (4 * wpb)) >= 4096) cpw = 4;
-        if (ctx->opt[EMP_OPT_EDGE_COLS_PER_WAVE] > 0) cpw = ctx->opt[EMP_OPT_EDGE_COLS_PER_WAVE];
         chunks = (ncol + cpw * wpb - 1) / (cpw * wpb);
         if (chunks < 1) chunks = 1;
     }
@@ -198,7 +197,7 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     }
     if (ring && ctx->opt[EMP_OPT_EDGE_CLOCK_PROBE]) {          // measurement: two reference ticks per wavefront of this launch
         const size_t waves_total = (size_t)grid.x * grid.y * wpb;
-        const int grc = grow_buffer(ctx, ctx->edge_probe, waves_total * 2 * sizeof(unsigned long long));
+        const int grc = grow_buffer(ctx, ctx->edge_probe, waves_total * 4 * sizeof(unsigned long long));
         if (grc) return grc;
         if (!ctx->edge_probe_done) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->edge_probe_done, hipEventDisableTiming));
         ctx->edge_probe_waves = (long)waves_total;
@@ -248,7 +247,6 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
         EMP_LAUNCH_CHECK(ctx);
         return EMP_OK;
     }
-    const int variant = ctx->opt[EMP_OPT_SWEEP_VARIANT];
     // EMP_OPT_SWEEP_EXCLUSIVE (staged pipeline): the sweep starts once the previous call's back stage is done
     if (ctx->sweep_wait) {
         EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sweep_wait, 0));
@@ -298,7 +296,6 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
     } while (0)
     // Ring depth PD (columns in flight per wavefront), measured at 4096 scenes: 2 is best for rows 5..12 (row 9:
     // 20.4 us against 23.2 at PD = 8, 21.4 at PD = 1), 3 for the 21-row lattice; nontemporal loads change nothing.
-    // EMP_SWEEP_VARIANT selects alternatives for the 9-row lattice (development).
     // Load policy, measured on the 40x9 lattice (sweep alone, TB/s of algorithmic bytes; plain / nontemporal): 4096 scenes
     // (105 MB tensor) 5.45 / 4.74, 8192 (226 MB) 6.47 / 6.21, 12288 (331 MB) 5.04 / 6.45, 16384 4.47 / 6.40, 32768 (883 MB)
     // 4.52 / 6.03.  A tensor that fits the 256 MiB Infinity Cache is still there when the sweep follows the edge kernel
@@ -316,12 +313,8 @@ static int dev_dp_sweep(emp_ctx* ctx, const DpDev& d, const double* start_cost, 
             // (round 5: three columns in flight instead of two.  Alone the two are within noise of each other - 0.72-0.77 of the
             // peak either way; beside the previous batch's Cartesian tail, where the sweep runs since EMP_OPT_SWEEP_EXCLUSIVE
             // defaults to 0, the deeper ring holds 0.67-0.68 where the shallow one holds 0.65: six A/B pairs, tools/step_ab.sh)
-            if (variant == 1) EMP_SWEEP_AUTO(9, 2);
-            else if (variant == 2) EMP_SWEEP(9, 4, 1);
-            else if (variant == 3) EMP_SWEEP(9, 8, 1);
-            else if (variant == 4) EMP_SWEEP_NT(9, 3, 1, true);
-            else if (variant == 5) EMP_SWEEP_NT(9, 3, 1, false);
-            else if (nt) EMP_SWEEP_NT(9, 2, 1, true);         // from DRAM (32768 scenes) the shallow ring keeps 0.697 against 0.692
+            // (ring depths 4 and 8 and the other load policy were option values until round 6: HISTORY.md 3.2 has their numbers)
+            if (nt) EMP_SWEEP_NT(9, 2, 1, true);         // from DRAM (32768 scenes) the shallow ring keeps 0.697 against 0.692
             else EMP_SWEEP_NT(9, 3, 1, false);
             break;
         case 12: EMP_SWEEP_AUTO(12, 2); break;
@@ -390,9 +383,8 @@ static int dev_dp_fused(emp_ctx* ctx, const DpDev& d, const double* obs_s, const
     if (rc) return rc;
     // columns per chunk: 4 (one per wavefront) while two buffers of them leave room for three blocks per CU, fewer on wide
     // lattices whose pair table fills the LDS
-    const int nc_env = ctx->opt[EMP_OPT_FUSED_COLUMNS];                                   // emp_set_option
-    int nc = nc_env > 0 ? nc_env : 4;
-    while (nc > 1 && fused_lds(d.row, d.col, d.S, d.max_obs, nc).total > 53 * 1024 && nc_env <= 0) nc /= 2;
+    int nc = 4;
+    while (nc > 1 && fused_lds(d.row, d.col, d.S, d.max_obs, nc).total > 53 * 1024) nc /= 2;
     const size_t lds = (size_t)fused_lds(d.row, d.col, d.S, d.max_obs, nc).total;
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "lattice too wide for the fused DP kernel's LDS working set");
     KernelTimer t(ctx, "dp_fused");
@@ -680,10 +672,26 @@ int emp_pack_trajectory_records(emp_ctx* ctx, int32_t B, int32_t max_pts, int32_
 
 int emp_set_pipeline(emp_ctx* ctx, int mode) {
     EMP_REQUIRE(ctx, ctx != nullptr, "ctx is NULL");
-    EMP_REQUIRE(ctx, mode <= EMP_PIPELINE_MAX, "at most EMP_PIPELINE_MAX batches in flight");
+    EMP_REQUIRE(ctx, mode <= EMP_PIPELINE_MAX && mode >= EMP_PIPELINE_AUTO, "mode: EMP_PIPELINE_AUTO, 0, EMP_PIPELINE_STAGED or 2..EMP_PIPELINE_MAX lanes");
     EMP_HIP(ctx, hipSetDevice(ctx->device));
     EMP_HIP(ctx, (hipError_t)sync_all(ctx));
-    const int m = mode < 0 ? 0 : mode;
+    if (mode == EMP_PIPELINE_AUTO) {
+        // Three lanes are the fastest form - when every stream of the process has a hardware queue of its own.  The HIP runtime
+        // maps all streams onto GPU_MAX_HW_QUEUES queues (default 4), read once when it initialised: three lane streams, the main
+        // stream, the copy / d2h streams of the page-locked path if this context has them, and the streams the REST of the
+        // process brings (EMP_OPT_FOREIGN_STREAMS: the caller's own, a gather stream, RCCL's) must fit - otherwise lanes share
+        // queues, serialise and run slower than the staged form, which needs two.  (The one environment variable the library reads:
+        // it is the only place the queue count can be had from.)
+        const char* env = getenv("GPU_MAX_HW_QUEUES");
+        int queues = env ? atoi(env) : 4;
+        if (queues < 1) queues = 4;
+        const int owned = 1 + (ctx->copy_stream ? 1 : 0) + (ctx->d2h_stream ? 1 : 0);
+        const int foreign = ctx->opt[EMP_OPT_FOREIGN_STREAMS];
+        mode = (queues >= 3 + owned + foreign) ? 3 : EMP_PIPELINE_STAGED;
+        ctx->auto_queues = queues;
+        ctx->auto_streams = owned + foreign;
+    }
+    const int m = mode;
     const int need = m == EMP_PIPELINE_STAGED ? emp_ctx::kStagedPools : m;
     // Streams the new mode does not use go away (everything was drained above): a stream holds a share of one of the process's
     // few hardware queues, and a staged pipeline set up while three lane streams of an earlier mode were still alive found its
@@ -696,7 +704,6 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
     if (m != EMP_PIPELINE_STAGED && ctx->back_stream) {
         EMP_HIP(ctx, hipStreamDestroy(ctx->back_stream));
         ctx->back_stream = nullptr;
-        ctx->back_stream_cus = -1;
     }
     if ((int)ctx->lanes.size() < need) ctx->lanes.resize(need);
     for (int i = 0; i < need; ++i) {
@@ -709,35 +716,26 @@ int emp_set_pipeline(emp_ctx* ctx, int mode) {
         if (!ln.ev_qp) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_qp, hipEventDisableTiming));
         if (!ln.ev_enrich) EMP_HIP(ctx, hipEventCreateWithFlags(&ln.ev_enrich, hipEventDisableTiming));
     }
-    const int want_cus = ctx->opt[EMP_OPT_BACK_STREAM_CUS] > 0 && ctx->opt[EMP_OPT_BACK_STREAM_CUS] < ctx->cu_count
-                             ? ctx->opt[EMP_OPT_BACK_STREAM_CUS] : 0;
-    if (m == EMP_PIPELINE_STAGED && ctx->back_stream && ctx->back_stream_cus != want_cus) {   // the option changed: new stream
-        EMP_HIP(ctx, hipStreamDestroy(ctx->back_stream));
-        ctx->back_stream = nullptr;
-    }
     if (m == EMP_PIPELINE_STAGED && !ctx->back_stream) {
-        if (want_cus > 0) {
-            // EMP_OPT_BACK_STREAM_CUS: the back stage confined to `want_cus` compute units.  The driver deals the mask's
-            // bits out to the XCDs round robin and to the shader engines within an XCD, so the lowest n bits are n CUs
-            // spread evenly over the chip.  (A masked stream has the default queue priority.)
-            uint32_t mask[16] = {0};
-            for (int i = 0; i < want_cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
-            EMP_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->back_stream, (uint32_t)((ctx->cu_count + 31) / 32), mask));
-        } else {
-            // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
-            // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
-            // stage's bulk work they overlap with
-            int prio_low = 0, prio_high = 0;
-            EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-            EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->back_stream, hipStreamNonBlocking, prio_high));
-        }
-        ctx->back_stream_cus = want_cus;
+        // the back stage's kernels are short chains of dependent instructions on few wavefronts: their queue gets the
+        // higher priority, so that they are dispatched (and, with s_setprio in the kernels, issued) ahead of the front
+        // stage's bulk work they overlap with.  (Until round 6 an option confined this stream to a CU mask: never a gain.)
+        int prio_low = 0, prio_high = 0;
+        EMP_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        EMP_HIP(ctx, hipStreamCreateWithPriority(&ctx->back_stream, hipStreamNonBlocking, prio_high));
     }
     for (auto& ln : ctx->lanes) ln.done_valid = ln.qp_valid = ln.enrich_valid = false;       // everything was drained above
     ctx->lane_edge_done = nullptr;
     ctx->pipe_mode = m;
     ctx->lane = 0;
     return EMP_OK;
+}
+
+int emp_pipeline_form(emp_ctx* ctx, int32_t* hw_queues, int32_t* other_streams) {
+    if (!ctx) return EMP_ERR_INVALID;
+    if (hw_queues) *hw_queues = ctx->auto_queues;
+    if (other_streams) *other_streams = ctx->auto_streams;
+    return ctx->pipe_mode;
 }
 
 int emp_pipeline_depth(emp_ctx* ctx) {
@@ -759,10 +757,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_PATH_QP_FORM:
         case EMP_OPT_CARTESIAN_FORM:
         case EMP_OPT_SMOOTH_FORCE_FALLBACK:
-        case EMP_OPT_ST_ORDER:
-        case EMP_OPT_ENRICH_ON_FRONT:
         case EMP_OPT_EDGE_AFTER_ENRICH:
-        case EMP_OPT_SWEEP_MARKER:
         case EMP_OPT_EDGE_FORM:
         case EMP_OPT_EDGE_CLOCK_PROBE:
         case EMP_OPT_CYCLE_GRAPH:
@@ -770,10 +765,7 @@ int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value) {
         case EMP_OPT_LANE_EDGE_ORDER:
         case EMP_OPT_SWEEP_EXCLUSIVE: ok = value >= 0 && value <= 2; break;
         case EMP_OPT_EDGE_BLOCK: ok = value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0); break;
-        case EMP_OPT_SWEEP_VARIANT: ok = value >= 0 && value <= 5; break;
-        case EMP_OPT_FUSED_COLUMNS: ok = value >= 0 && value <= 64; break;
-        case EMP_OPT_EDGE_COLS_PER_WAVE: ok = value >= 0 && value <= 256; break;
-        case EMP_OPT_BACK_STREAM_CUS: ok = value >= 0 && value <= 512; break;
+        case EMP_OPT_FOREIGN_STREAMS: ok = value >= 0 && value <= 64; break;
     }
     EMP_REQUIRE(ctx, ok, "option value out of range (include/emplanner.h, emp_option)");
     ctx->opt[option] = value;
@@ -812,14 +804,14 @@ double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_
 int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* mean_resident_waves, int32_t* waves) {
     if (!ctx || !ctx->edge_probe.p || !ctx->edge_probe_done || ctx->edge_probe_waves <= 0) return EMP_ERR_INVALID;
     if (hipEventSynchronize(ctx->edge_probe_done) != hipSuccess) return EMP_ERR_HIP;
-    std::vector<unsigned long long> h((size_t)ctx->edge_probe_waves * 2);
+    std::vector<unsigned long long> h((size_t)ctx->edge_probe_waves * 4);
     if (hipMemcpy(h.data(), ctx->edge_probe.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return EMP_ERR_HIP;
     unsigned long long first = ~0ull, last = 0;
     double sum = 0.0;
     for (long w = 0; w < ctx->edge_probe_waves; ++w) {
-        first = std::min(first, h[2 * w]);
-        last = std::max(last, h[2 * w + 1]);
-        sum += (double)(h[2 * w + 1] - h[2 * w]);
+        first = std::min(first, h[4 * w]);
+        last = std::max(last, h[4 * w + 1]);
+        sum += (double)(h[4 * w + 1] - h[4 * w]);
     }
     const double span = (double)(last - first);
     if (mean_wave_us) *mean_wave_us = sum / (double)ctx->edge_probe_waves / 100.0;      // 100 MHz reference
@@ -827,6 +819,19 @@ int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* 
     if (mean_resident_waves) *mean_resident_waves = span > 0 ? sum / span : 0.0;
     if (waves) *waves = (int32_t)ctx->edge_probe_waves;
     return EMP_OK;
+}
+
+double emp_edge_clock_mhz(emp_ctx* ctx) {
+    if (!ctx || !ctx->edge_probe.p || !ctx->edge_probe_done || ctx->edge_probe_waves <= 0) return -1.0;
+    if (hipEventSynchronize(ctx->edge_probe_done) != hipSuccess) return -1.0;
+    std::vector<unsigned long long> h((size_t)ctx->edge_probe_waves * 4);
+    if (hipMemcpy(h.data(), ctx->edge_probe.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    double ticks_c = 0.0, ticks_r = 0.0;
+    for (long w = 0; w < ctx->edge_probe_waves; ++w) {
+        ticks_r += (double)(h[4 * w + 1] - h[4 * w]);
+        ticks_c += (double)(h[4 * w + 3] - h[4 * w + 2]);
+    }
+    return ticks_r > 0.0 ? ticks_c / ticks_r * 100.0 : -1.0;          // 100 MHz reference
 }
 
 int emp_sweep_probe_spans(emp_ctx* ctx, double* start_spread_us, double* first_start_to_last_end_us) {
@@ -1680,18 +1685,9 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     // 198 us, path QP 140, Cartesian 70, sweep 19) and the step takes 0.264 ms (mode 2) / 0.277 (mode 1); without it the
     // edge kernel runs at its stand-alone 147 us, starves the path QP beside it (250 us) and the step takes 0.32 - 0.35 ms
     // (profiles/r04_sweep/README.md).  The clock probe's event did the same by accident, which is how this was found.
-    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE] && ctx->opt[EMP_OPT_SWEEP_MARKER]) {
+    if (staged && ctx->opt[EMP_OPT_SWEEP_EXCLUSIVE]) {
         if (!ctx->sweep_marker) EMP_HIP(ctx, hipEventCreateWithFlags(&ctx->sweep_marker, hipEventDisableTiming));
         EMP_HIP(ctx, hipEventRecord(ctx->sweep_marker, ctx->stream));
-    }
-    // EMP_OPT_ENRICH_ON_FRONT: the densification kernel stays on the front stream, behind the sweep it depends on; the back
-    // stage then begins with the path QP
-    const bool enrich_front = staged && ctx->opt[EMP_OPT_ENRICH_ON_FRONT] != 0;
-    if (enrich_front) {
-        if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
-                                deferred ? d_term : nullptr, d_no, d_rows)))
-            return rc;
-        ctx->front_attached = nullptr;         // the event to wait for is the one recorded behind the densification
     }
     if (staged) {      // the back stage (short kernels that last as long as their slowest scene) goes to the back stream
         // behind the sweep's own completion event where the launch attached one (a marker packet behind the sweep costs the
@@ -1707,11 +1703,10 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     // The two events the NEXT call's front stage waits for (densification done, path QP done) are signalled by the dispatches
     // themselves where possible: a marker packet behind each idled the back queue ~6 us, and with the edge kernel's round-4 diet
     // the back queue is what bounds the step.
-    const bool want_enrich_ev = staged && !enrich_front && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH] != 0;
+    const bool want_enrich_ev = staged && ctx->opt[EMP_OPT_EDGE_AFTER_ENRICH] != 0;
     ctx->attach_stop = want_enrich_ev ? lane.ln->ev_enrich : nullptr;
     ctx->stop_attached = false;
-    if (!enrich_front &&
-        (rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
+    if ((rc = dev_dp_enrich(ctx, d, d_rows, d_start, max_pts, d_dps, d_dpl, d_dplen, d_st, 1, deferred ? d_pre : nullptr,
                             deferred ? d_term : nullptr, d_no, d_rows))) {
         ctx->attach_stop = nullptr;
         return rc;
@@ -2180,8 +2175,7 @@ int emp_speed_dp(emp_ctx* ctx, const emp_speed_dp_params* p, int32_t B, int32_t 
     if ((rc = stg.out(speed_t, (size_t)B * st::kCols, &d_tt, false))) return rc;
     // heaviest scenes first (emp_st_kernels.h: st_count_kernel); pointless when every block is resident at once
     int* d_order = nullptr;
-    const bool no_order = ctx->opt[EMP_OPT_ST_ORDER] == 0;               // emp_set_option (A/B)
-    if (B > 512 && !no_order) {
+    if (B > 512) {
         unsigned char* d_key;
         int* d_hist;
         if ((rc = stg.tmp<int>((size_t)B, &d_order))) return rc;

@@ -389,6 +389,7 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     // EMP_OPT_EDGE_CLOCK_PROBE (measurement; a scalar branch when off): the constant 100 MHz counter at the wavefront's first and
     // last instruction - how long a wavefront is resident and how many are resident at once, alone and inside the staged step
     const unsigned long long probe_r0 = clock_probe ? wall_clock64() : 0;
+    const unsigned long long probe_c0 = clock_probe ? clock64() : 0;       // the shader clock: what the chip holds under FP64 load
     constexpr int kMaskBits = (int)sizeof(MASK) * 8;
     const int row = ROW > 0 ? ROW : P.row, rr = row * row;
     double* tab = lds;                                  // [kTableFields][rr], pair index = k*row + i
@@ -568,9 +569,11 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     while (cnt[0] > 0) round(0);
     while (cnt[1] > 0) round(1);
     if (clock_probe && lane == 0) {
-        unsigned long long* o = clock_probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * waves + wave) * 2;
+        unsigned long long* o = clock_probe + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * waves + wave) * 4;
         o[0] = probe_r0;
         o[1] = wall_clock64();
+        o[2] = probe_c0;
+        o[3] = clock64();
     }
 }
 

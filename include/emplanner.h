@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EMP_ABI_VERSION 10
+#define EMP_ABI_VERSION 11
 
 typedef struct emp_ctx emp_ctx;
 
@@ -169,13 +169,25 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  *                          HOST PROGRAM exports e.g. GPU_MAX_HW_QUEUES=8 before it first touches HIP - the library does
  *                          not change the environment.  With fewer queues lanes share one and serialise (3 lanes on 4
  *                          queues beside torch's stream: slower than 2); beyond 7 lanes they share in any case.
+ *   EMP_PIPELINE_AUTO      (ABI version 11) the library picks what this PROCESS can sustain: three lanes when every stream has a
+ *                          hardware queue of its own - GPU_MAX_HW_QUEUES (the value the HIP runtime was started with; default
+ *                          4; the one environment variable the library reads) >= 3 lanes + emp_stream() + this context's copy /
+ *                          d2h streams (EMP_HOST_PINNED cycles) + EMP_OPT_FOREIGN_STREAMS (the streams the rest of the process
+ *                          uses: default 1, the caller's own; add a gather stream, RCCL's) - else EMP_PIPELINE_STAGED (two
+ *                          queues).  emp_pipeline_form reports the choice.  Measured on 4 queues (HIP's default): three lanes
+ *                          0.2x ms per 4096-scene step against the staged form's 0.22 (tests/test_gpu_fullsize.py).
  * Consequences for the caller: the outputs of a call are complete on emp_result_stream() - in lane mode the lane of the
  * LATEST emp_plan_cycle call, so ask after every call - and emp_synchronize waits for every stream; each call in flight
  * needs its OWN output buffers, and its inputs must stay unchanged until it is done.  Every other entry point first
  * lets emp_stream() wait for the cycles in flight.  Results are bit-identical to the unpipelined call. */
+#define EMP_PIPELINE_AUTO (-1)
 #define EMP_PIPELINE_STAGED 1
 #define EMP_PIPELINE_MAX 8
 int emp_set_pipeline(emp_ctx* ctx, int mode);
+/* The pipeline form in force: 0 off, EMP_PIPELINE_STAGED, or the number of lanes; negative: ctx is NULL.  After an
+ * emp_set_pipeline(EMP_PIPELINE_AUTO), optionally (pointers may be NULL) the hardware-queue count it saw and the streams it counted
+ * beside the lanes (0 / 0 when the latest mode was set explicitly). */
+int emp_pipeline_form(emp_ctx* ctx, int32_t* hw_queues, int32_t* other_streams);
 void* emp_result_stream(emp_ctx* ctx);
 /* How many consecutive emp_plan_cycle calls may have work in flight in the current mode (ABI version 8): the output buffers
  * of call k may be reused once call k + emp_pipeline_depth() has been ISSUED.  1 when the pipeline is off, n in lane mode,
@@ -190,10 +202,14 @@ int emp_pipeline_depth(emp_ctx* ctx);
  * temporaries are the main stream's own, so consecutive unfenced calls are still serial among themselves. */
 int emp_set_fence(emp_ctx* ctx, int enabled);
 
-/* ---- options (ABI version 9; EMP_OPT_EDGE_FORM, EMP_OPT_EDGE_COLS_PER_WAVE, EMP_OPT_LANE_EDGE_ORDER, EMP_OPT_CYCLE_GRAPH: version 10) ---------------------------------------------------------------------------------------
- * The library reads NO environment variable.  Everything that used to be an EMP_* environment switch of the development
+/* ---- options (ABI version 9; renumbered in version 11: twelve of them) -------------------------------------------------------
+ * The library reads no EMP_* environment variable.  Everything that used to be an environment switch of the development
  * builds is a per-context option here, set by the host program before the calls it should affect (a change takes effect
- * at the next call; EMP_OPT_BACK_STREAM_CUS at the next emp_set_pipeline).  Unknown options and values out of range are
+ * at the next call; EMP_OPT_FOREIGN_STREAMS at the next emp_set_pipeline(EMP_PIPELINE_AUTO)).  Retired in version 11, each with the
+ * number that retired it: EMP_OPT_SWEEP_MARKER (always on with EMP_OPT_SWEEP_EXCLUSIVE: 0.264 against 0.32-0.35 ms per step without),
+ * EMP_OPT_ENRICH_ON_FRONT (0.4 % slower, never a default), EMP_OPT_BACK_STREAM_CUS (a CU mask on the back stage never gained),
+ * EMP_OPT_FUSED_COLUMNS / EMP_OPT_EDGE_COLS_PER_WAVE / EMP_OPT_SWEEP_VARIANT (the auto rules are the measured optima: HISTORY.md 3.2,
+ * profiles/r05_edge/README.md), EMP_OPT_ST_ORDER (heaviest scenes first: 3 % on configs[4], never slower).  Unknown options and values out of range are
  * EMP_ERR_INVALID.  "result-affecting" options change WHICH kernel computes a stage: the two forms of a stage solve the
  * same problem with the same stopping rule but associate sums differently (path QP: ~2e-9 relative; Cartesian tail: bit
  * identical) - so they are never chosen from the batch size: a scene's result does not depend on how many scenes share
@@ -216,7 +232,6 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             scanned one edge per lane: 0.93 active lanes of a scan at 40 x 9
  *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
  *                                                             obstacle rows wider than 64 slots always take the lockstep form
- *   EMP_OPT_EDGE_COLS_PER_WAVE      0        tuning           lattice columns a wavefront of the edge-cost kernel takes; 0: auto
  *   EMP_OPT_LANE_EDGE_ORDER         0        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
  *                                                             when the previous call's - on another lane - is done, so that at most
  *                                                             one of them runs at a time and the sweep that follows one has a single
@@ -238,12 +253,8 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             the graph; emp_set_timing and the clock probes bypass it
  *   EMP_OPT_EDGE_CLOCK_PROBE        0        measurement      1: every launch of the work-ring edge kernel records, per wavefront,
  *                                                             the 100 MHz reference counter at its first and last instruction
- *                                                             (emp_edge_probe reads the latest launch)
- *   EMP_OPT_SWEEP_VARIANT           0        tuning           9-row sweep: 0 auto (register ring 3 columns deep since round 5);
- *                                                             1/2/3: ring 2/4/8 columns deep; 4/5: nontemporal / plain loads
- *                                                             whatever the tensor's size
- *   EMP_OPT_FUSED_COLUMNS           0        tuning           columns per LDS chunk of EMP_DP_FUSED; 0: auto
- *   EMP_OPT_ST_ORDER                1        tuning           speed DP: 1 heaviest scenes first, 0 input order (same results)
+ *                                                             and the shader clock there (emp_edge_probe, emp_edge_clock_mhz read
+ *                                                             the latest launch)
  *   EMP_OPT_SWEEP_EXCLUSIVE         0        tuning           staged pipeline, what the HBM-bound sweep of call k may run beside:
  *                                                             0 (default since round 5) = no wait: the fastest step.  With the
  *                                                             work-ring edge kernel the sweep of call k starts after call k-1's
@@ -262,13 +273,9 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             to 255 us behind it, a 0.32-0.34 ms step.  Without the wait the
  *                                                             order is a race that the N > 1 step (record packing on the back
  *                                                             queue) loses: 0.305 -> 0.270 ms there, +1 % on the plain step
- *   EMP_OPT_SWEEP_MARKER            1        tuning           staged pipeline with EMP_OPT_SWEEP_EXCLUSIVE != 0: an event record on
- *                                                             the front stream behind the sweep (0: none; profiles/r04_sweep)
- *   EMP_OPT_ENRICH_ON_FRONT         0        tuning           staged pipeline: 1 = the densification kernel runs on the front
- *                                                             stream behind the sweep, the back stage begins with the path QP
- *   EMP_OPT_BACK_STREAM_CUS         0        tuning           staged pipeline: n > 0 confines the back stage's stream to n
- *                                                             compute units (hipExtStreamCreateWithCUMask, the lowest n bits
- *                                                             of the mask: spread evenly over the XCDs); 0: no mask
+ *   EMP_OPT_FOREIGN_STREAMS         1        pipeline order   streams of the process OUTSIDE this context that carry GPU work while it
+ *                                                             plans (the caller's own stream, a gather stream, RCCL's): what
+ *                                                             emp_set_pipeline(EMP_PIPELINE_AUTO) counts beside its own
  *   EMP_OPT_SWEEP_CLOCK_PROBE       0        measurement      1: every sweep launch also records, per wavefront, the shader
  *                                                             clock ticks and the 100 MHz reference ticks it ran for
  *                                                             (emp_sweep_clock_mhz reads their ratio)                       */
@@ -277,21 +284,15 @@ typedef enum emp_option {
     EMP_OPT_CARTESIAN_FORM = 1,
     EMP_OPT_SMOOTH_FORCE_FALLBACK = 2,
     EMP_OPT_EDGE_BLOCK = 3,
-    EMP_OPT_SWEEP_VARIANT = 4,
-    EMP_OPT_FUSED_COLUMNS = 5,
-    EMP_OPT_ST_ORDER = 6,
-    EMP_OPT_SWEEP_EXCLUSIVE = 7,
-    EMP_OPT_BACK_STREAM_CUS = 8,
+    EMP_OPT_EDGE_FORM = 4,
+    EMP_OPT_SWEEP_EXCLUSIVE = 5,
+    EMP_OPT_EDGE_AFTER_ENRICH = 6,
+    EMP_OPT_LANE_EDGE_ORDER = 7,
+    EMP_OPT_CYCLE_GRAPH = 8,
     EMP_OPT_SWEEP_CLOCK_PROBE = 9,
-    EMP_OPT_ENRICH_ON_FRONT = 10,
-    EMP_OPT_EDGE_AFTER_ENRICH = 11,
-    EMP_OPT_SWEEP_MARKER = 12,
-    EMP_OPT_EDGE_FORM = 13,
-    EMP_OPT_EDGE_COLS_PER_WAVE = 14,
-    EMP_OPT_EDGE_CLOCK_PROBE = 15,
-    EMP_OPT_LANE_EDGE_ORDER = 16,
-    EMP_OPT_CYCLE_GRAPH = 17,
-    EMP_OPT_COUNT = 18
+    EMP_OPT_EDGE_CLOCK_PROBE = 10,
+    EMP_OPT_FOREIGN_STREAMS = 11,
+    EMP_OPT_COUNT = 12
 } emp_option;
 int emp_set_option(emp_ctx* ctx, int32_t option, int32_t value);
 int emp_get_option(emp_ctx* ctx, int32_t option, int32_t* value);
@@ -304,6 +305,10 @@ double emp_sweep_clock_mhz(emp_ctx* ctx, double* mean_wave_us, double* max_wave_
  * wavefront's start to the last one's end (us), mean number of wavefronts resident at once (their ratio x count), wavefronts.
  * Synchronises on that launch.  Any out pointer may be NULL. */
 int emp_edge_probe(emp_ctx* ctx, double* mean_wave_us, double* span_us, double* mean_resident_waves, int32_t* waves);
+/* The same probe: the shader clock the latest edge-cost launch ran at, in MHz (shader-clock ticks over 100 MHz reference ticks,
+ * summed over its wavefronts) - the clock the chip holds under the FP64-issue-bound kernel that is most of the step, which is what
+ * a vector-issue roofline of the step must be priced at (bench.py roofline_step).  Negative when nothing was recorded. */
+double emp_edge_clock_mhz(emp_ctx* ctx);
 /* EMP_OPT_CYCLE_GRAPH: how many emp_plan_cycle calls of this context were served by replaying a captured graph (-1: ctx is NULL). */
 int64_t emp_cycle_graph_replays(emp_ctx* ctx);
 /* The same probe, per launch and averaged over the recorded launches (100 MHz reference ticks, which all wavefronts share):

@@ -25,7 +25,7 @@ for form in (1, 0):
         for cpw in (0, 1, 2, 3, 4):
             pl.set_option("edge_form", form)
             pl.set_option("edge_block", block)
-            pl.set_option("edge_cols_per_wave", cpw)
+            # (edge_cols_per_wave was an option until ABI 11: the auto rule is the measured optimum)
             pl.set_timing(False)
             for _ in range(3):
                 c0, e = pl.dp_edge_costs(p, obs_s, obs_l, n_obs, start, layout=L.EMP_EDGE_TILED)

@@ -1,5 +1,5 @@
 """The edge-cost kernel alone, a few launches (for rocprofv3 counter passes: tools/pmc_sq_cmd.sh TAG tools/edge_only.py ...).
-Usage: python tools/edge_only.py [cfg2|cfg5] [scenes] [edge_form] [edge_block] [edge_cols_per_wave]"""
+Usage: python tools/edge_only.py [cfg2|cfg5] [scenes] [edge_form] [edge_block]"""
 import os
 import sys
 
@@ -18,7 +18,6 @@ batch = S.make_batch(range(B), cfg, start_ahead=S.BENCH_START_AHEAD)
 pl = Planner(0)
 pl.set_option("edge_form", int(a[2] or 0))
 pl.set_option("edge_block", int(a[3] or 0))
-pl.set_option("edge_cols_per_wave", int(a[4] or 0))
 p = dp_params_from_cfg(cfg)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
 obs_s, obs_l, n_obs, start = t(batch.sl_obs_s), t(batch.sl_obs_l), t(batch.n_obs), t(batch.sl_start)
