@@ -101,7 +101,9 @@ class CycleIO(C.Structure):
     _fields_ = [(n, _vp) for n in (
         "ref_line", "n_ref", "origin_xy", "start_xy", "start_v", "start_a", "obs_xy", "n_obs",
         "dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status",
-        "dyn_dis_speed")]
+        "dyn_dis_speed",
+        # the optional front end (ABI 11): the cycle starts from the global path
+        "global_path", "n_global", "pre_match_index", "match_index", "ref_status")] + [("max_global", C.c_int32), ("reserved_io", C.c_int32)]
 
 
 # name -> (restype, argtypes); data pointers are void* so numpy arrays and raw device addresses both fit

@@ -238,19 +238,22 @@ class HostRing:
             self.ring, self.index = ring, index
             pl, B, P, mo, M, col = ring.planner, ring.B, ring.max_ref, ring.max_obs, ring.max_pts, ring.col
             self.B, self.max_ref, self.max_obs, self.max_pts = B, P, mo, M
+            G = self.max_global = ring.max_global       # > 0: a slot for REQUESTS - the cycle starts from the global path
             self.use_dyn = False
             self._ticket = None
             f, i = np.float64, np.int32
             # ONE page-locked block for the inputs and one for the outputs (arrays at 256-byte offsets): the library then moves
             # each as a single PCIe copy (emp_context.h Stage::place)
-            self.inputs, self._in_block = self._carve(pl, (
-                ("ref_line", (B, P, 4), f), ("n_ref", (B,), i), ("origin_xy", (B, 2), f), ("start_xy", (B, 2), f),
+            line = ((("global_path", (B, G, 4), f), ("n_global", (B,), i), ("pre_match_index", (B,), i)) if G > 0 else
+                    (("ref_line", (B, P, 4), f), ("n_ref", (B,), i)))
+            self.inputs, self._in_block = self._carve(pl, line + (
+                ("origin_xy", (B, 2), f), ("start_xy", (B, 2), f),
                 ("start_v", (B, 2), f), ("start_a", (B, 2), f), ("obs_xy", (B, max(mo, 1), 2), f), ("n_obs", (B,), i),
                 ("dyn_dis_speed", (B, 2), f)))
             self.outputs, self._out_block = self._carve(pl, (
                 ("dp_rows", (B, col), f), ("dp_s", (B, M), f), ("dp_l", (B, M), f), ("dp_len", (B,), i), ("path_s", (B, M), f),
                 ("path_l", (B, M), f), ("path_len", (B,), i), ("traj", (B, M + 1, 4), f), ("traj_len", (B,), i),
-                ("status", (B,), i)))
+                ("status", (B,), i)) + ((("match_index", (B,), i), ("ref_status", (B,), i)) if G > 0 else ()))
 
         @staticmethod
         def _carve(pl, spec):
@@ -302,8 +305,11 @@ class HostRing:
             self._ticket = None
             return self
 
-    def __init__(self, planner, p, B, max_ref, max_obs, max_pts, depth):
+    def __init__(self, planner, p, B, max_ref, max_obs, max_pts, depth, max_global=0):
         self.planner, self.B, self.max_ref, self.max_obs, self.max_pts, self.col = planner, B, max_ref, max_obs, max_pts, int(p.col)
+        self.max_global = int(max_global)
+        if self.max_global > 0 and max_ref != REF_LINE_POINTS:
+            raise ValueError("a request ring plans on the front end's 51-point reference lines")
         self.slots = [HostRing.Slot(self, k) for k in range(depth)]
         self._next = 0
 
@@ -340,6 +346,8 @@ class CycleResult:
     traj: object         # (B, max_pts + 1, 4)
     traj_len: object
     status: object       # (B,) int32 bit mask
+    match_index: object = None   # (B,) int32 - only from a cycle that started at the global path (front end fused in)
+    ref_status: object = None    # (B,) int32 - the front end's own status (OR it into ``status``)
 
 
 class Planner:
@@ -987,11 +995,13 @@ class Planner:
         ptr = self._pinned.pop(key)
         self._check(self._lib.emp_host_free(self._h, C.c_void_p(ptr)))
 
-    def host_ring(self, p: DpParams, B: int, max_ref: int, max_obs: int, max_pts=None, depth=None) -> "HostRing":
+    def host_ring(self, p: DpParams, B: int, max_ref: int, max_obs: int, max_pts=None, depth=None, max_global: int = 0) -> "HostRing":
         """``depth`` (default: the pipeline depth) slots of page-locked input and output arrays for ``B`` scenes each: the
-        overlapped host path of the planning cycle (``HostRing``)."""
+        overlapped host path of the planning cycle (``HostRing``).  ``max_global`` > 0: slots for REQUESTS - their inputs hold
+        the global path (B, max_global, 4), n_global and pre_match_index instead of a reference line, the cycle runs the front
+        end itself and the outputs carry match_index and ref_status."""
         return HostRing(self, p, int(B), int(max_ref), int(max_obs), int(max_pts) if max_pts else max_path_points(p),
-                        int(depth) if depth else max(int(self._lib.emp_pipeline_depth(self._h)), 1))
+                        int(depth) if depth else max(int(self._lib.emp_pipeline_depth(self._h)), 1), int(max_global))
 
     def wait_cycle(self, calls_back: int = 0):
         """Block until the host outputs of the pinned cycle issued ``calls_back`` calls ago are in place (emp_wait_cycle)."""
@@ -999,24 +1009,36 @@ class Planner:
 
     def plan_cycle(self, p: DpParams, q: QpParams, sp: SmoothParams, ref_line, n_ref, origin_xy, start_xy, start_v,
                    start_a, obs_xy, n_obs, max_pts=None, mode=L.EMP_DP_TWO_KERNEL, dyn_dis_speed=None, slot=None,
-                   out: "CycleResult" = None) -> CycleResult:
+                   out: "CycleResult" = None, global_path=None, n_global=None, pre_match_index=None) -> CycleResult:
         """ref motion_planning body, test_9.py:113-218, for a batch of scenes.  dyn_dis_speed (B,2): distance and speed
         of each scene's first dynamic obstacle (NaN = none) for the virtual obstacles of test_9.py:137-169.
         ``slot``: a ``HostRing`` slot whose page-locked arrays ARE the inputs (the array arguments are then ignored) and
         receive the outputs - with a pipeline set the call returns before they are there (``slot.wait()``).
         ``out``: the ``CycleResult`` of an earlier call with the same sizes - its arrays are written again instead of new ones
         being allocated.  With the same inputs' memory too, consecutive calls have one signature, which is what option
-        "cycle_graph" (EMP_OPT_CYCLE_GRAPH: the call's launches replayed as one hipGraph) needs."""
+        "cycle_graph" (EMP_OPT_CYCLE_GRAPH: the call's launches replayed as one hipGraph) needs.
+        ``global_path`` (B,G,4), ``n_global`` (B,), ``pre_match_index`` (B,): the cycle starts from the GLOBAL path - the
+        reference's find_match_points / sampling / smooth_reference_line (test_9.py:99-110, ``reference_line``) run in front of it
+        in the same call, the 51-point line stays on the device, ``start_xy`` is the predicted location; ``ref_line`` and ``n_ref``
+        are then ignored (pass None) and the result carries ``match_index`` and ``ref_status``."""
         if slot is not None:
             return self._plan_cycle_pinned(p, q, sp, slot, mode)
-        a = self._args(ref_line, origin_xy)
+        front = global_path is not None
+        a = self._args(global_path if front else ref_line, origin_xy)
         a.cycle = True               # pipelined mode: the outputs become complete on the result stream (see _Args.done)
-        B, P = int(ref_line.shape[0]), int(ref_line.shape[1])
+        B, P = (int(global_path.shape[0]), REF_LINE_POINTS) if front else (int(ref_line.shape[0]), int(ref_line.shape[1]))
         mo = int(obs_xy.shape[1]) if obs_xy is not None else 0
         M = int(max_pts) if max_pts else max_path_points(p)
         io = L.CycleIO()
-        io.ref_line = a.inp(ref_line, np.float64, (B, P, 4))
-        io.n_ref = a.inp(n_ref, np.int32, (B,))
+        if front:
+            G = int(global_path.shape[1])
+            io.global_path = a.inp(global_path, np.float64, (B, G, 4))
+            io.n_global = a.inp(n_global, np.int32, (B,))
+            io.pre_match_index = a.inp(pre_match_index, np.int32, (B,))
+            io.max_global = G
+        else:
+            io.ref_line = a.inp(ref_line, np.float64, (B, P, 4))
+            io.n_ref = a.inp(n_ref, np.int32, (B,))
         io.origin_xy = a.inp(origin_xy, np.float64, (B, 2))
         io.start_xy = a.inp(start_xy, np.float64, (B, 2))
         io.start_v = a.inp(start_v, np.float64, (B, 2))
@@ -1029,7 +1051,8 @@ class Planner:
                                 ("dp_l", (B, M), np.float64), ("dp_len", (B,), np.int32),
                                 ("path_s", (B, M), np.float64), ("path_l", (B, M), np.float64),
                                 ("path_len", (B,), np.int32), ("traj", (B, M + 1, 4), np.float64),
-                                ("traj_len", (B,), np.int32), ("status", (B,), np.int32)):
+                                ("traj_len", (B,), np.int32), ("status", (B,), np.int32)) + \
+                ((("match_index", (B,), np.int32), ("ref_status", (B,), np.int32)) if front else ()):
             arr, ptr = a.out(shape, dt, getattr(out, name) if out is not None else None)
             res[name] = arr
             setattr(io, name, ptr)
@@ -1050,7 +1073,11 @@ class Planner:
 
     def _plan_cycle_pinned(self, p, q, sp, slot, mode):
         io = L.CycleIO()
-        for name in ("ref_line", "n_ref", "origin_xy", "start_xy", "start_v", "start_a"):
+        front = getattr(slot, "max_global", 0) > 0           # a slot made for requests: the cycle starts from the global path
+        names = ("global_path", "n_global", "pre_match_index") if front else ("ref_line", "n_ref")
+        if front:
+            io.max_global = slot.max_global
+        for name in names + ("origin_xy", "start_xy", "start_v", "start_a"):
             setattr(io, name, C.c_void_p(slot.inputs[name].ctypes.data))
         mo = slot.max_obs
         io.obs_xy = C.c_void_p(slot.inputs["obs_xy"].ctypes.data) if mo else None

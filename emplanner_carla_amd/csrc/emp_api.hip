@@ -1463,8 +1463,13 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     int rc = make_dp_dev(ctx, p, B, obs_cap, &d);
     if (rc) return rc;
     EMP_REQUIRE(ctx, max_ref >= 2 && max_pts >= 2 && max_pts <= 255, "max_ref >= 2 and 2 <= max_pts <= 255 required");
-    EMP_REQUIRE(ctx, io->ref_line && io->n_ref && io->origin_xy && io->start_xy && io->start_v && io->start_a,
+    // the optional front end (ABI 11): find_match_points on the global path, sampling, smooth_reference_line in front of the cycle
+    const bool front = io->global_path != nullptr;
+    EMP_REQUIRE(ctx, (front || (io->ref_line && io->n_ref)) && io->origin_xy && io->start_xy && io->start_v && io->start_a,
                 "cycle inputs missing");
+    EMP_REQUIRE(ctx, !front || (io->n_global && io->pre_match_index && io->match_index && io->ref_status && io->max_global >= 1 &&
+                                max_ref == kRefLinePoints),
+                "front end: n_global, pre_match_index, match_index, ref_status, max_global >= 1 and max_ref == EMP_REF_LINE_POINTS");
     EMP_REQUIRE(ctx, max_obs == 0 || (io->obs_xy && io->n_obs), "obstacle inputs missing");
     EMP_REQUIRE(ctx, io->traj && io->traj_len && io->status, "traj, traj_len and status are required outputs");
     EMP_REQUIRE(ctx, q->ds > 0, "ds must be > 0");
@@ -1589,10 +1594,16 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
         ctx->cycle_seen = 0;
     }
     Stage st(ctx, where, piped, pinned);
-    const double *d_ref, *d_o, *d_sxy, *d_v, *d_a, *d_oxy;
-    const int *d_nr, *d_no;
-    if ((rc = st.in(io->ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
-    if ((rc = st.in(io->n_ref, (size_t)B, &d_nr))) return rc;
+    const double *d_ref = nullptr, *d_o, *d_sxy, *d_v, *d_a, *d_oxy, *d_glob = nullptr;
+    const int *d_nr = nullptr, *d_no, *d_nglob = nullptr, *d_prem = nullptr;
+    if (front) {
+        if ((rc = st.in(io->global_path, (size_t)B * io->max_global * 4, &d_glob))) return rc;
+        if ((rc = st.in(io->n_global, (size_t)B, &d_nglob))) return rc;
+        if ((rc = st.in(io->pre_match_index, (size_t)B, &d_prem))) return rc;
+    } else {
+        if ((rc = st.in(io->ref_line, (size_t)B * max_ref * 4, &d_ref))) return rc;
+        if ((rc = st.in(io->n_ref, (size_t)B, &d_nr))) return rc;
+    }
     if ((rc = st.in(io->origin_xy, (size_t)B * 2, &d_o))) return rc;
     if ((rc = st.in(io->start_xy, (size_t)B * 2, &d_sxy))) return rc;
     if ((rc = st.in(io->start_v, (size_t)B * 2, &d_v))) return rc;
@@ -1623,6 +1634,11 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     if ((rc = st.out(io->traj, (size_t)B * (max_pts + 1) * 4, &d_traj, false))) return rc;
     if ((rc = st.out(io->traj_len, (size_t)B, &d_tlen, false))) return rc;
     if ((rc = st.out(io->status, (size_t)B, &d_st, false))) return rc;
+    int *d_match = nullptr, *d_rst = nullptr;
+    if (front) {
+        if ((rc = st.out(io->match_index, (size_t)B, &d_match, false))) return rc;
+        if ((rc = st.out(io->ref_status, (size_t)B, &d_rst, false))) return rc;
+    }
     if ((rc = st.outputs_ready())) return rc;
     // intermediates
     double *d_sm, *d_os, *d_ol, *d_bsl, *d_start;
@@ -1639,7 +1655,26 @@ int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q,
     }
     int* d_ntot = nullptr;
     if (has_dyn && (rc = st.tmp((size_t)B, &d_ntot, false))) return rc;
+    double* d_ref_w = nullptr;
+    int* d_nr_w = nullptr;
+    if (front) {
+        if ((rc = st.tmp((size_t)B * kRefLinePoints * 4, &d_ref_w))) return rc;
+        if ((rc = st.tmp((size_t)B, &d_nr_w))) return rc;
+    }
     if (B == 0) return st.finish();
+    if (front) {          // ref test_9.py:99-110, one wavefront per scene; the predicted location is the planning start
+        const SmoothQpParams sx{sp->w_smooth, sp->w_length, sp->w_ref, sp->x_thre};
+        const SmoothQpParams sy{sp->w_smooth, sp->w_length, sp->w_ref, sp->y_thre};
+        const size_t lds = (2 * (size_t)kRefLinePoints + 2 * (size_t)BoxRangeQp::words(kRefLinePoints, kRefLinePoints) +
+                            (size_t)kRefLinePoints) * sizeof(double);
+        if ((rc = set_lds(ctx, reference_line_wave_kernel, lds))) return rc;
+        KernelTimer t(ctx, "reference_line");
+        hipLaunchKernelGGL(reference_line_wave_kernel, dim3(B), dim3(64), lds, ctx->stream, B, (int)io->max_global, sx, sy, d_glob,
+                           d_nglob, d_sxy, (const int*)nullptr, d_prem, d_ref_w, d_nr_w, d_match, (int*)nullptr, d_rst, 2);
+        EMP_LAUNCH_CHECK(ctx);
+        d_ref = d_ref_w;
+        d_nr = d_nr_w;
+    }
     if ((rc = dev_project(ctx, B, max_ref, max_obs, d_ref, d_nr, d_o, d_sxy, d_v, d_a, d_oxy, d_no, d_sm, d_os, d_ol,
                           d_bsl, d_start, mo, d_dyn, d_ntot)))
         return rc;

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64) void reference_line_wave_kernel(int B, int max_
                                                                  const int* __restrict__ pre_match_index,
                                                                  double* __restrict__ ref_line, int* __restrict__ n_ref,
                                                                  int* __restrict__ match_index, int* __restrict__ iters,
-                                                                 int* __restrict__ status) {
+                                                                 int* __restrict__ status, int n_ref_on_fail = 0) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const double* line = global_path + (size_t)b * max_global * 4;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64) void reference_line_wave_kernel(int B, int max_
     if (fail)
         for (int i = lane; i < kRefLinePoints * 4; i += 64) out[i] = 0.0;
     if (lane == 0) {
-        n_ref[b] = fail ? 0 : kRefLinePoints;
+        n_ref[b] = fail ? n_ref_on_fail : kRefLinePoints;       // (the fused cycle hands a failed line on as two zero nodes)
         match_index[b] = m;
         if (iters) iters[b] = it;
         status[b] = fail;

@@ -21,13 +21,24 @@ def planner():
 
 
 def line_array(path):
-    """[(x, y, theta, kappa), ...] -> (1, P, 4) float64 + n_ref."""
-    a = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path], dtype=np.float64)
+    """[(x, y, theta, kappa), ...] -> (1, P, 4) float64 + n_ref.  One NumPy conversion where the nodes are plain 4-sequences of
+    numbers (the lists the reference's functions hand each other); element by element for anything else."""
+    try:
+        a = np.asarray(path, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 4:
+            raise ValueError
+    except (TypeError, ValueError):
+        a = np.asarray([[float(p[0]), float(p[1]), float(p[2]), float(p[3])] for p in path], dtype=np.float64)
     return a.reshape(1, -1, 4), np.array([a.shape[0]], np.int32)
 
 
 def xy_array(pts):
-    a = np.asarray([[float(p[0]), float(p[1])] for p in pts], dtype=np.float64)
+    try:
+        a = np.asarray(pts, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 2:
+            raise ValueError
+    except (TypeError, ValueError):
+        a = np.asarray([[float(p[0]), float(p[1])] for p in pts], dtype=np.float64)
     return a.reshape(1, -1, 2), np.array([a.shape[0]], np.int32)
 
 

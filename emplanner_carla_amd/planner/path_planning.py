@@ -67,7 +67,7 @@ def enrich_DP_s_l(DP_s_list, DP_l_list, plan_start_s, plan_start_l, plan_start_d
     cap = int(sum(int(np.ceil(max(int(v), 0) / resolution)) for v in spans)) + 1
     s, l, n, st = planner().enrich_nodes(node_s, node_l, np.array([col], np.int32), start, resolution, max(cap, 1))
     n = int(n[0])
-    return [f64(v) for v in s[0, :n]], [f64(v) for v in l[0, :n]]
+    return list(s[0, :n]), list(l[0, :n])
 
 
 def DP_algorithm(obs_s_list, obs_l_list, plan_start_s, plan_start_l, plan_start_dl, plan_start_ddl, sampling_res=2,
@@ -83,7 +83,7 @@ def DP_algorithm(obs_s_list, obs_l_list, plan_start_s, plan_start_l, plan_start_
         print(INFEASIBLE_BANNER)                                   # ref :351-352 prints and carries on
     s, l, n, st = pl.dp_enrich(p, rows, start, max_path_points(p))
     n = int(n[0])
-    return [f64(v) for v in s[0, :n]], [f64(v) for v in l[0, :n]]
+    return list(s[0, :n]), list(l[0, :n])
 
 
 def cal_lmin_lmax(dp_path_s, dp_path_l, obs_s_list, obs_l_list, obs_length, obs_width):

@@ -106,7 +106,8 @@ def smooth_reference_line(local_frenet_path_xy, w_cost_smooth=0.4, w_cost_length
     out, it, st = planner().smooth_line(smooth_params(w_cost_smooth, w_cost_length, w_cost_ref, x_thre, y_thre), xy, n)
     if st[0] & L.ST_SMOOTH_FAILED:
         raise ValueError("smooth_reference_line: the smoothing QP did not converge")
-    return [(float(p[0]), float(p[1]), f64(p[2]), f64(p[3])) for p in out[0]]
+    o = out[0]                                                      # x, y Python floats; theta, kappa np.float64 (ref :355-361)
+    return list(zip(o[:, 0].tolist(), o[:, 1].tolist(), list(o[:, 2]), list(o[:, 3])))
 
 
 def cal_projection_s_fun(local_path_opt, match_index_list, xy_list, s_map):
@@ -116,7 +117,7 @@ def cal_projection_s_fun(local_path_opt, match_index_list, xy_list, s_map):
     xy, n = xy_array(xy_list[:k])
     s, _ = planner().s_l(line, np.asarray(s_map, dtype=np.float64).reshape(1, -1), n_ref, xy, n,
                          match_index=np.asarray(match_index_list, dtype=np.int32).reshape(1, k), want_l=False)
-    return [f64(v) for v in s[0]]
+    return list(s[0])
 
 
 def cal_s_map_fun(local_path_opt, origin_xy):
@@ -131,7 +132,7 @@ def cal_s_l_fun(obs_xy_list, local_path_opt, s_map):
     line, n_ref = line_array(local_path_opt)
     xy, n = xy_array(obs_xy_list)
     s, l = planner().s_l(line, np.asarray(s_map, dtype=np.float64).reshape(1, -1), n_ref, xy, n)
-    return [f64(v) for v in s[0]], [f64(v) for v in l[0]]
+    return list(s[0]), list(l[0])
 
 
 def cal_s_l_deri_fun(xy_list, V_xy_list, a_xy_list, local_path_xy_opt, origin_xy):
@@ -141,7 +142,7 @@ def cal_s_l_deri_fun(xy_list, V_xy_list, a_xy_list, local_path_xy_opt, origin_xy
     v, _ = xy_array(V_xy_list)
     a, _ = xy_array(a_xy_list)
     o = planner().s_l_deri(line, n_ref, xy, v, a, n, np.array([[float(origin_xy[0]), float(origin_xy[1])]]))
-    return tuple([f64(x) for x in o[0, :, c]] for c in range(7))
+    return tuple(list(o[0, :, c]) for c in range(7))
 
 
 def cal_proj_point_1(s, pre_match_index, frenet_path_opt, s_map):
@@ -156,7 +157,7 @@ def cal_quintic_coefficient(start_l, start_dl, start_ddl, end_l, end_dl, end_ddl
     with the reference's on the segment to its own noise ("Reference noise floor")."""
     c = planner().quintic_coefficients(np.array([[start_l, start_dl, start_ddl, end_l, end_dl, end_ddl, start_s,
                                                   end_s]], dtype=np.float64))
-    return [f64(v) for v in c[0]]
+    return list(c[0])
 
 
 # ---- helpers beside the path (used by the reference's speed-planning drivers) ---------------------

@@ -505,6 +505,16 @@ typedef struct emp_cycle_io {
      * none.  ref test_9.py:137-169: it becomes three virtual static obstacles on the centre line (meet_s - 10, the
      * middle of the encounter, leave_s) unless the encounter ends beyond s = 80 m.  NULL: no dynamic obstacles. */
     const double* dyn_dis_speed;
+    /* optional front end (ABI 11): the cycle starts from the GLOBAL path, as the reference's planning loop does (test_9.py:99-110:
+     * find_match_points for the predicted location = start_xy, sampling, smooth_reference_line) - emp_reference_line and this
+     * call as ONE call, the 51-point reference line never leaving the device.  global_path [B][max_global][4], n_global [B],
+     * pre_match_index [B] in; match_index [B] (the next request's pre_match_index) and ref_status [B] (emp_reference_line's status:
+     * OR it into `status`) out.  Then ref_line / n_ref are ignored and max_ref must be EMP_REF_LINE_POINTS.  A scene whose
+     * reference line fails runs the cycle on an empty line, exactly as with n_ref = 2 handed to the two-call form.
+     * global_path NULL: no front end (the other five fields are ignored). */
+    const double* global_path; const int32_t* n_global; const int32_t* pre_match_index;
+    int32_t* match_index; int32_t* ref_status;
+    int32_t max_global; int32_t reserved_io;      /* reserved_io: 0 */
 } emp_cycle_io;
 
 int emp_plan_cycle(emp_ctx* ctx, const emp_dp_params* p, const emp_qp_params* q, const emp_smooth_params* sp,

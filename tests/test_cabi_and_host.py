@@ -504,12 +504,14 @@ def test_failing_submit_does_not_shrink_the_cycle_stream_ring():
     class Slot:
         def __init__(self):
             self.B, self.max_ref, self.max_pts = 8, 51, 32
-            self.inputs = {"obs_xy": np.zeros((8, 4, 2))}
-            self.outputs = {k: np.zeros(8, np.int32) for k in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l",
-                                                                "path_len", "traj", "traj_len", "status")}
+            self.inputs = {"obs_xy": np.zeros((8, 4, 2)), "global_path": np.zeros((8, 64, 4))}
+            self.outputs = {k: np.zeros(8, np.int32) for k in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len",
+                                                                "traj", "traj_len", "status", "match_index", "ref_status")}
             self._ticket, self.waits, self.use_dyn = None, 0, False
 
         def load(self, **arrays):
+            if FakePlanner.fail == "load":
+                raise ValueError("could not broadcast input array")
             return self
 
         def wait(self):
@@ -536,14 +538,8 @@ def test_failing_submit_does_not_shrink_the_cycle_stream_ring():
         def set_fence(self, on):
             pass
 
-        def host_ring(self, *a):
+        def host_ring(self, *a, **kw):
             return Ring()
-
-        def reference_line(self, sp, g, n, pred, pre):
-            if self.fail == "reference_line":
-                raise RuntimeError("front end refused")
-            B = len(n)
-            return np.zeros((B, 51, 4)), np.full(B, 51, np.int32), np.zeros(B, np.int32), None, np.zeros(B, np.int32)
 
         def plan_cycle(self, *a, slot=None, **kw):
             if self.fail == "plan_cycle":
@@ -557,20 +553,20 @@ def test_failing_submit_does_not_shrink_the_cycle_stream_ring():
              n_obs=np.zeros(2, np.int32), dyn=np.full((2, 2), np.nan))
     dp = dp_params()
     ring = None
-    for how in ("reference_line", "plan_cycle") * 5:              # ten failures on a ring of four slots
-        pl.fail = how
-        with pytest.raises(RuntimeError):
+    for how in ("load", "plan_cycle") * 5:                        # ten failures on a ring of four slots
+        FakePlanner.fail = how
+        with pytest.raises((RuntimeError, ValueError)):
             stream.submit(a, dp=dp)
         ring = next(iter(stream._rings.values()))
         assert len(ring.free) == 4, f"a failing submit ({how}) leaked a slot"
-    pl.fail = "wait"                                               # the call is issued, the wait in result() fails
+    FakePlanner.fail = "wait"                                      # the call is issued, the wait in result() fails
     for _ in range(6):
         h = stream.submit(a, dp=dp)
         assert len(ring.free) == 3
         with pytest.raises(RuntimeError):
             stream.result(h)
         assert len(ring.free) == 4 and h["slot"] is None
-    pl.fail = None
+    FakePlanner.fail = None
     for _ in range(6):                                             # and the ring still works
         st_ref, match, res, M = stream.plan_arrays(a, dp=dp)
         assert res.status.shape == (2,) and len(ring.free) == 4
