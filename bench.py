@@ -40,7 +40,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline_step   the whole step against the chip's vector-issue capacity: sum over the step's kernels of their VALU-busy
                 quad-cycles (committed SQ counter pass, source named) / (1024 SIMDs x clock / 4 x ms_per_step), with the measured
                 cost of a wave64 FP64 instruction (tools/fp64_pipe_bench.hip: 4.3 cycles, not the 4 the counter charges)
-  staged_leg, exclusive_sweep_leg, rccl_gather_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg
+  staged_leg, exclusive_sweep_leg, rccl_gather_leg, dram_leg, cfg5_leg, latency_leg, survey_leg, tight_corridor_leg, host_io_leg, gather_path_leg, dropin_leg
                 (default run only: N = 1, cfg2, 4096 scenes; --no-legs skips them) short secondary measurements after the
                 headline: the staged pipeline of rounds 2-5 (two batches, front stage beside back stage: ~9 % longer steps, the
                 sweep beside the Cartesian tail only) and the same with the sweep held back behind the previous batch's path QP
@@ -209,8 +209,8 @@ def scene_kwargs(args):
 DEFAULT_PIPELINE = "3"      # --pipeline auto: three lanes (see main)
 MAX_TIMED_BLOCKS = 64       # the timed block is repeated until --min-timed-ms are covered, this often at most
 
-from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, gather_path_leg, host_io_leg, latency_leg,  # noqa: E402
-                        rccl_gather_subprocess_leg, roofline_step, secondary_leg, staged_subprocess_leg)
+from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, dropin_subprocess_leg, gather_path_leg, host_io_leg,  # noqa: E402
+                        latency_leg, rccl_gather_subprocess_leg, roofline_step, secondary_leg, staged_subprocess_leg)
 
 
 def self_launch_argv(argv, n, port, python=None):
@@ -632,6 +632,9 @@ def main():
         legs["survey_leg"] = secondary_leg(pl, torch, S.CFG2, 4096, 10, 20, device, dict(tight, dist="survey"))
         legs["tight_corridor_leg"] = secondary_leg(pl, torch, S.CFG2, 4096, 10, 20, device, dict(tight, dist="corridor"))
         legs["host_io_leg"] = host_io_leg(pl, torch, S.CFG2, 4096, 60, scene_kw)
+        # the reference's OWN call shape - one request, Python lists in, tuples out - through a real Pipe and as the explicit function
+        # sequence of its planning loop (bench_dropin.py, a process of its own: the drop-in modules own a context per process)
+        legs["dropin_leg"] = dropin_subprocess_leg(200)
 
     # outcome statistics (sanity: the work was really done): the planned fraction of every input batch the steps rotate through
     # (one more pass each, untimed); every rank looks at its own shard and the fractions are averaged over the ranks

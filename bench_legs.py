@@ -461,6 +461,25 @@ def rccl_gather_subprocess_leg(steps):
         return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
 
 
+def dropin_subprocess_leg(requests=200):
+    """The reference's own call shape (one request, Python lists in, tuples out: test_9.py:92-96, 220, 390-395), timed by
+    bench_dropin.py in a process of its own: (i) a request down a real multiprocessing.Pipe to a planning process running the package's
+    motion_planning, (ii) the reference's planning-loop body as the explicit function sequence through the drop-in modules,
+    (iii) service.plan_requests in-process."""
+    import subprocess
+    t_leg = time.perf_counter()
+    cmd = [sys.executable, os.path.join(os.path.dirname(_BENCH), "bench_dropin.py"), "--requests", str(requests)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(_BENCH))
+        if out.returncode != 0:
+            return {"error": f"exit {out.returncode}: {out.stderr[-400:]}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+        d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        d["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
+        return d
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "leg_wall_s": round(time.perf_counter() - t_leg, 2)}
+
+
 def staged_subprocess_leg(steps, options):
     """`python bench.py --pipeline staged --no-legs --no-cpu-baseline [--opt ...]` in a fresh process (this one waits, its GPU
     work fenced): the staged form's step time and its sweep's launches, as that command prints them."""

@@ -44,7 +44,7 @@ OPTIONS = {"path_qp_form": 0, "cartesian_form": 1, "smooth_force_fallback": 2, "
            "edge_after_enrich": 6, "lane_edge_order": 7, "cycle_graph": 8, "sweep_clock_probe": 9, "edge_clock_probe": 10,
            "foreign_streams": 11}
 #: the values a fresh context holds (everything else is 0)
-OPTION_DEFAULTS = {"edge_after_enrich": 1, "foreign_streams": 1}
+OPTION_DEFAULTS = {"edge_after_enrich": 1, "lane_edge_order": 2, "foreign_streams": 1}
 
 ST_DP_INFEASIBLE = 1
 ST_S_OUT_OF_RANGE = 2

@@ -214,7 +214,7 @@ static int dev_dp_edge(emp_ctx* ctx, const DpDev& d, const double* obs_s, const 
     // lanes' FP64-bound kernels take turns instead of running two or three at a time, and the HBM-bound sweep behind each of them
     // has one of them beside it, not two (measured: include/emplanner.h).  Pure ordering: results do not depend on it.
     const int leo = ctx->opt[EMP_OPT_LANE_EDGE_ORDER];
-    const bool ordered = ctx->pipe_mode >= 2 && ctx->active_lane >= 0 && (leo == 1 || (leo == 2 && d.B >= 4096));
+    const bool ordered = ctx->pipe_mode >= 2 && ctx->active_lane >= 0 && (leo == 1 || (leo == 2 && d.B >= 8192));
     if (ordered && ctx->lane_edge_done) EMP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_edge_done, 0));
     KernelTimer t(ctx, "dp_edge");
     if (ring) {

@@ -114,7 +114,7 @@ struct emp_ctx {
     int active_lane = -1;               // LANES: the lane whose stream and pool stand in for `stream` / `pool` right now
     bool fence = true;                  // emp_set_fence: other entry points wait for the cycles in flight
     // emp_set_option (include/emplanner.h): per-context tuning / A-B / test-hook values; the library reads no environment
-    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, /* EDGE_AFTER_ENRICH */ 1, 0, 0, 0, 0, /* FOREIGN_STREAMS */ 1};
+    int32_t opt[EMP_OPT_COUNT] = {0, 0, 0, 0, 0, 0, /* EDGE_AFTER_ENRICH */ 1, /* LANE_EDGE_ORDER */ 2, 0, 0, 0, /* FOREIGN_STREAMS */ 1};
     int auto_queues = 0, auto_streams = 0;   // what the latest emp_set_pipeline(EMP_PIPELINE_AUTO) saw (emp_pipeline_form)
     // EMP_OPT_CYCLE_GRAPH: the launches of one emp_plan_cycle call as an executable graph, the call signature it belongs to, how
     // often that signature has been seen in a row, and the allocation count (grow_buffer) it was captured under

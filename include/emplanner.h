@@ -232,17 +232,17 @@ int emp_set_fence(emp_ctx* ctx, int enabled);
  *                                                             scanned one edge per lane: 0.93 active lanes of a scan at 40 x 9
  *                                                             with 8 obstacles), 1 = the lockstep form of rounds 1-4 (0.49);
  *                                                             obstacle rows wider than 64 slots always take the lockstep form
- *   EMP_OPT_LANE_EDGE_ORDER         0        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
+ *   EMP_OPT_LANE_EDGE_ORDER         2        pipeline order   lane mode (emp_set_pipeline(n >= 2)): 1 = the edge-cost kernel of a call starts
  *                                                             when the previous call's - on another lane - is done, so that at most
  *                                                             one of them runs at a time and the sweep that follows one has a single
  *                                                             edge kernel beside it instead of two (one stream-side wait per call);
- *                                                             2 = 1 for calls of 4096 scenes and more; 0 (default) = lanes are not
- *                                                             ordered among each other.  Worth setting for big batches of ordinary
- *                                                             scenes (32 768 scenes of the 40 x 9 lattice: 1.47 -> 1.36 ms per step,
- *                                                             the sweep at 0.53 of the HBM peak instead of 0.31; 4096: the same step,
- *                                                             0.42 instead of 0.36) - and NOT where the edge kernel is most of a
- *                                                             call (every obstacle beside the same columns: 0.18 -> 0.23 ms), which
- *                                                             is why it is not the default
+ *                                                             2 (default since ABI 11) = 1 for calls of 8192 scenes and more, where
+ *                                                             one edge kernel fills the chip by itself (32 768 scenes of the 40 x 9
+ *                                                             lattice: 1.47 -> 1.36 ms per step, the sweep at 0.53 of the HBM peak
+ *                                                             instead of 0.31; 8192: 2 %); 0 = lanes are never ordered among each
+ *                                                             other.  NOT for smaller calls: the order bounds the step from below by
+ *                                                             the edge kernel's own duration (4096 scenes with every obstacle beside
+ *                                                             the same columns: 0.18 -> 0.23 ms per step; 1024 scenes 0.116 -> 0.121)
  *   EMP_OPT_CYCLE_GRAPH             0        tuning           1: emp_plan_cycle on device pointers, one batch at a time (no pipeline): the
  *                                                             THIRD consecutive call with the same sizes, parameters, options and
  *                                                             pointers captures its six launches into a hipGraph, every further one

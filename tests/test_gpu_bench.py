@@ -129,6 +129,13 @@ def test_default_run_carries_the_secondary_legs():
     c = d["cfg5_leg"]
     assert "error" not in c, c
     assert c["speed_dp_us"] > 100 and 0.15 < c["sweep"]["frac"] < 1.0 and c["all_scenes_cycles_per_s"] > 1e5
+    # the reference's own call shape: a request down a real Pipe, the function sequence of its planning loop, plan_requests in-process
+    dr = d["dropin_leg"]
+    assert "error" not in dr, dr
+    assert dr["pipe_motion_planning"]["requests"] == 200 and 0.05 < dr["pipe_motion_planning"]["median_ms"] < 5.0
+    assert dr["function_sequence"]["planned"] > 150 and 0.2 < dr["function_sequence"]["median_ms"] < 10.0
+    assert dr["pipe_vs_function_sequence"]["trajectories_compared"] > 150 and dr["pipe_vs_function_sequence"]["max_abs_xy_difference_m"] < 1e-6
+    assert dr["pipe_motion_planning"]["median_ms"] < dr["function_sequence"]["median_ms"]
     lat = d["latency_leg"]
     assert "error" not in lat and 0.05 < lat["ms_per_cycle_median"] < 5.0 and lat["calls"] == 50
     g = lat["as_one_hipgraph"]

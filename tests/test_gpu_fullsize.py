@@ -754,7 +754,7 @@ def test_lane_edge_order_changes_no_result(planner, order):
     dev = torch.device("cuda:0")
     old = planner.get_option("lane_edge_order")
     try:
-        for n in (1024, 4096):
+        for n in (1024, 8192):
             batches = []
             for k in range(5):
                 b = S.make_batch(range(7000 + 5000 * k, 7000 + 5000 * k + n), cfg, **BENCH)
