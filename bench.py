@@ -576,7 +576,8 @@ def main():
     # The shader clock the chip holds in THIS schedule: a few more steps of it with the edge-cost kernel's clock probe on (two
     # counter reads per wavefront; untimed) - what roofline_step prices the step's vector-issue capacity at
     edge_clock_mhz = None
-    if args.dp_mode == "two_kernel" and not wide and pl.get_option("edge_form") == 0:
+    probe_steps = 0
+    if args.dp_mode == "two_kernel" and pl.get_option("edge_form") == 0:
         fence()
         pl.set_timing(False)
         pl.set_option("edge_clock_probe", 1)
@@ -584,6 +585,7 @@ def main():
         for _ in range(3):
             for _ in range(2 * max(in_flight, 1)):
                 out, res = step()
+                probe_steps += 1
             fence()
             c = pl.edge_clock_mhz()
             if c:
@@ -665,6 +667,7 @@ def main():
         if sweep_ms > 0:
             ach = bytes_dp / (sweep_ms * 1e-3) / 1e9
             prof = committed_profile("dp_sweep_traffic", config=cfg.name, scenes_per_gpu=count)
+            tprof = committed_profile("dp_sweep_trace", config=cfg.name, scenes_per_gpu=count, pipeline=("off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes"))
             roof = {"kernel": "dp_sweep_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": prof["hbm_bytes_per_launch"] if prof else None,
@@ -673,6 +676,10 @@ def main():
                     "mean_launch_us": round(sweep_ms * 1e3, 2),
                     "launch_us_min_median_max": [round(float(v), 2) for v in (sweep_samples.min(), np.median(sweep_samples), sweep_samples.max())]
                     if sweep_samples is not None and len(sweep_samples) else None,
+                    # the same three numbers from the COMMITTED rocprofv3 kernel trace of this command (another box, another day):
+                    # what the files under profiles/ say next to what this run's events say
+                    "committed_trace_launch_us_min_median_max": (tprof or {}).get("timed_launch_us_min_median_max"),
+                    "committed_trace_source": (tprof or {}).get("source"),
                     # the same kernel with nothing beside it: the diagnostic pass after the timed region, one batch in flight
                     "frac_alone": (round(bytes_dp / (kernels["dp_sweep"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if "dp_sweep" in kernels else None),
                     "alone_mean_launch_us": (round(kernels["dp_sweep"] * 1e3, 2) if "dp_sweep" in kernels else None)}
@@ -766,6 +773,9 @@ def main():
             "rccl_world_size": (dist.get_world_size() if world > 1 else None),     # what the process group itself reports
             "process_group_backend": (dist.get_backend() if world > 1 else None),
             "untimed_steps_before_the_timed_region": args.warmup + settle,
+            # (what a kernel trace of this command holds, in start order: the untimed steps, timed_blocks x steps timed steps, these -
+            # the clock probe's - then the diagnostic pass (2 + min(steps, 5) steps) and one pass per input batch)
+            "untimed_steps_between_the_timed_region_and_the_diagnostic_pass": probe_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "ms_per_step_is": f"the median of timed_blocks blocks of {args.steps} steps each (every block between two fences, max over ranks)",
             "ms_per_step_min_max": [round(min(block_s) / args.steps * 1e3, 4), round(max(block_s) / args.steps * 1e3, 4)],

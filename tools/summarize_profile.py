@@ -59,16 +59,32 @@ if os.path.exists(trace_csv):
         pass
     diag = 2 + min(steps, 5)
     extra = 0              # round 5: one more untimed pass per input batch behind the diagnostic pass (planned fractions)
+    blocks, between, pipeline = 1, 0, None   # round 6: the timed block is repeated (timed_blocks); the clock probe's steps follow it
     try:
-        extra = int(json.loads(line)["config"].get("input_batches", 0))
+        d = json.loads(line)
+        extra = int(d["config"].get("input_batches", 0))
+        blocks = int(d.get("timed_blocks", 1))
+        between = int(d.get("untimed_steps_between_the_timed_region_and_the_diagnostic_pass", 0))
+        pipeline = d["config"].get("pipeline")
     except Exception:
         pass
-    if untimed is not None and len(sw) == untimed + steps + diag + extra:
+    n_timed = steps * blocks
+    if untimed is not None and len(sw) == untimed + n_timed + between + diag + extra:
         dur = [(e - b) / 1e3 for b, e in sw]
-        timed, alone = dur[untimed:untimed + steps], dur[untimed + steps + 2:untimed + steps + diag]
-        region = {"launches_in_trace": len(sw), "untimed": untimed, "timed_mean_us": sum(timed) / len(timed),
+        timed = dur[untimed:untimed + n_timed]
+        alone = dur[untimed + n_timed + between + 2:untimed + n_timed + between + diag]
+        ts = sorted(timed)
+        region = {"launches_in_trace": len(sw), "untimed": untimed, "timed_blocks": blocks, "timed_launches": n_timed,
+                  "timed_mean_us": sum(timed) / len(timed), "timed_median_us": ts[len(ts) // 2],
                   "timed_min_us": min(timed), "timed_max_us": max(timed), "alone_mean_us": sum(alone) / len(alone),
                   "all_mean_us": sum(dur) / len(dur)}
+        _counters.upsert("dp_sweep_trace", {"config": config, "scenes_per_gpu": scenes, "pipeline": pipeline,
+                                            "timed_launch_us_min_median_max": [round(min(timed), 2), round(ts[len(ts) // 2], 2), round(max(timed), 2)],
+                                            "timed_launch_us_mean": round(sum(timed) / len(timed), 2), "timed_launches": n_timed,
+                                            "alone_launch_us_mean": round(sum(alone) / len(alone), 2),
+                                            "source": f"profiles/{tag}_sweep_regions.json (rocprofv3 --kernel-trace of python bench.py --steps {steps} "
+                                                      f"--warmup {warmup}: the sweep's launches inside the timed region)"},
+                         ("config", "scenes_per_gpu", "pipeline"))
     else:
         region = {"launches_in_trace": len(sw), "untimed": untimed, "note": "launch count does not match untimed + steps + diagnostic pass"}
 
@@ -80,8 +96,8 @@ for r in stats:
     lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
 if region and "timed_mean_us" in region:
     E_bytes = None
-    lines += ["", f"dp_sweep launches of the same trace by region (start order: {region['untimed']} untimed, {steps} timed, the diagnostic pass): "
-                  f"timed region mean {region['timed_mean_us']:.2f} us (min {region['timed_min_us']:.2f}, max {region['timed_max_us']:.2f}); "
+    lines += ["", f"dp_sweep launches of the same trace by region (start order: {region['untimed']} untimed, {region['timed_blocks']} x {steps} timed, the clock probe's, the diagnostic pass): "
+                  f"timed region mean {region['timed_mean_us']:.2f} us (min {region['timed_min_us']:.2f}, median {region['timed_median_us']:.2f}, max {region['timed_max_us']:.2f}); "
                   f"diagnostic pass, one batch in flight: {region['alone_mean_us']:.2f} us; all launches {region['all_mean_us']:.2f} us"]
     json.dump(region, open(os.path.join(dst, f"{tag}_sweep_regions.json"), "w"), indent=1)
 elif region:
