@@ -889,3 +889,59 @@ def test_cycle_graph_replays_the_same_bits():
     finally:
         pl.close()
         plain.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipe", [0, "staged", 3], ids=["no_pipeline", "staged", "lanes3"])
+def test_cycle_from_the_global_path_equals_the_two_call_form(planner, pipe):
+    """ABI 11: emp_plan_cycle with emp_cycle_io.global_path runs the reference's front end (test_9.py:99-110) in front of the cycle
+    in ONE call - what service.plan_requests / motion_planning / the wire server now use.  Same kernels: the outputs, the match index
+    and the front end's status must equal emp_reference_line followed by emp_plan_cycle bit for bit - for good requests, for a
+    previous match index outside the path (IndexError in the reference), for a global path shorter than 51 nodes, with and without
+    a dynamic obstacle, on host arrays and on device tensors, in every pipeline form."""
+    import torch
+    from emplanner_carla_amd import service
+    from emplanner_carla_amd.api import dp_params, qp_params, smooth_params, max_path_points
+    g = load_golden("driver_s147.npz")
+    from tests.test_wire import _driver_request
+    reqs = [_driver_request(g, c) for c in range(len(g["case"]))]
+    bad = list(reqs[0])
+    bad[7] = [10 ** 6]                                   # pre_match_index far outside the path
+    short = list(reqs[1])
+    short[6] = short[6][:40]                             # fewer nodes than the 51-point window
+    short[7] = [5]
+    reqs = reqs + [tuple(bad), tuple(short)]
+    a = service.pack_requests(reqs)
+    dp, qp, sp = dp_params(sample_s=14.7), qp_params(), smooth_params()
+    stages = {}
+    st_ref, match, res2, M = service.plan_arrays(planner, a, dp, qp, sp, stages=stages)            # the two-call form
+    assert (st_ref[-2:] != 0).all() and (st_ref[:-2] == 0).all()
+    planner.set_pipeline(pipe)
+    try:
+        for rep in range(3):
+            res = planner.plan_cycle(dp, qp, sp, None, None, max_pts=M, origin_xy=a["veh"], start_xy=a["pred"], start_v=a["v"],
+                                     start_a=a["a"], obs_xy=a["obs_xy"], n_obs=a["n_obs"], dyn_dis_speed=a["dyn"],
+                                     global_path=a["global_path"], n_global=a["n_global"], pre_match_index=a["pre_match"])
+            planner.synchronize()
+            assert np.array_equal(res.ref_status, st_ref) and np.array_equal(res.match_index, match)
+            for k in ("dp_rows", "dp_s", "dp_l", "dp_len", "path_s", "path_l", "path_len", "traj", "traj_len", "status"):
+                assert np.array_equal(getattr(res, k), getattr(res2, k), equal_nan=True), (k, rep)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in a.items()}
+        rd = planner.plan_cycle(dp, qp, sp, None, None, max_pts=M, origin_xy=dev["veh"], start_xy=dev["pred"], start_v=dev["v"],
+                                start_a=dev["a"], obs_xy=dev["obs_xy"], n_obs=dev["n_obs"], dyn_dis_speed=dev["dyn"],
+                                global_path=dev["global_path"], n_global=dev["n_global"], pre_match_index=dev["pre_match"])
+        planner.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(rd.ref_status.cpu().numpy(), st_ref) and np.array_equal(rd.match_index.cpu().numpy(), match)
+        for k in ("dp_rows", "path_l", "traj", "traj_len", "status"):
+            assert np.array_equal(getattr(rd, k).cpu().numpy(), getattr(res2, k), equal_nan=True), k
+    finally:
+        planner.set_pipeline(0)
+    # and the one-request fast path of the planning process: the same reply as plan_requests
+    one = service.RequestPlanner(planner, dp=dp)
+    want = service.plan_requests(planner, reqs, dp=dp)
+    for c, req in enumerate(reqs):
+        reply, status, m = one.plan(req)
+        assert status == want[c][1] and m == int(match[c]), c
+        assert reply == want[c][0], c
+    one.close()
