@@ -209,7 +209,7 @@ def scene_kwargs(args):
 DEFAULT_PIPELINE = "3"      # --pipeline auto: three lanes (see main)
 MAX_TIMED_BLOCKS = 64       # the timed block is repeated until --min-timed-ms are covered, this often at most
 
-from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_profile, dropin_subprocess_leg, gather_path_leg, host_io_leg,  # noqa: E402
+from bench_legs import (HBM_PEAK_GBS, _device_inputs, committed_parity_sweeps, committed_profile, dropin_subprocess_leg, gather_path_leg, host_io_leg,  # noqa: E402
                         latency_leg, rccl_gather_subprocess_leg, roofline_step, secondary_leg, staged_subprocess_leg)
 
 
@@ -801,6 +801,7 @@ def main():
             "kernels_ms": kernels,
             "alt_pipeline": alt,
             "scenes_fully_planned_frac": round(ok_frac, 4),
+            "parity_sweeps_committed": committed_parity_sweeps() if (world == 1 and not args.no_legs) else None,
             "options": {**{k: pl.get_option(k) for k in ("sweep_exclusive", "edge_after_enrich", "lane_edge_order", "path_qp_form", "edge_form")}, **options},
             **legs,
         }

@@ -37,6 +37,37 @@ def committed_profile(kind, **match):
     return None
 
 
+def committed_parity_sweeps(prefix="r06_parity_sweep_"):
+    """What the COMMITTED large-sample parity runs of this build say (tools/parity_sweep.py on a GPU box, GPU against the oracles on
+    its host cores; files profiles/<prefix>*.json): scenes compared and how many differ, next to the headline they vouch for -
+    including the batch whose planning starts sit ON reference-line nodes, where `s_map[idx + 1] < s` (reference path_planning.py:63)
+    is decided by the last bit.  Not re-run here: a sweep is minutes of host-core time."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", prefix + "*.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        e = {"source": os.path.relpath(path, ROOT)}
+        dp, cy = d.get("dp"), d.get("cycle")
+        if dp:
+            e["dp_scenes_bit_for_bit_against_the_exact_oracle"] = dp.get("scenes")
+            e["dp_scenes_mismatching"] = int(sum((dp.get("mismatching") or {}).values()))
+        if cy:
+            e.update(cycles=cy.get("scenes"), cycles_planned_and_compared=cy.get("fully_planned_and_compared"),
+                     outcome_mismatch=cy.get("outcome_mismatch"), start_ahead_m=cy.get("start_ahead"), geometry=cy.get("geometry"),
+                     worst_error_over_the_survey_rule=cy.get("worst_error_over_survey_rule"),
+                     scenes_with_the_start_on_a_node=cy.get("scenes_with_the_start_on_a_node"),
+                     tie_scenes_beyond_tolerance=len(cy.get("tie_scenes_beyond_tolerance") or []),
+                     tie_scenes_not_explained_by_the_flipped_branch=cy.get("tie_scenes_not_explained_by_the_flipped_branch"))
+        for part in ("st", "fe", "front"):
+            if isinstance(d.get(part), dict):
+                e[part] = {k: v for k, v in d[part].items() if isinstance(v, (int, float, str)) and k != "seconds"}
+        out[os.path.basename(path)[len(prefix):-5]] = e
+    return out or None
+
+
 def _device_inputs(torch, S, cfg, seeds, device, scene_kw=None):
     batch = S.make_batch(seeds, cfg, **(scene_kw or {}))
     P = batch.ref.shape[1]

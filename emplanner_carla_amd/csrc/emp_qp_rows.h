@@ -440,7 +440,17 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
         }
         const bool go = state == 1;
         // ---- 3: factorisation
+#ifdef EMP_QP_PROBE_SKIP_CHOL
+        bool okf = true;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            frinv[r] = 1.0 / (fa[r][0] + 1.0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) flow[r][d] = 0.0;
+        }
+#else
         const bool okf = band_chol_rows<GP, R>(fa, frinv, flow, N, gl, go, steps);
+#endif
         EMP_QP_DEBUG_ROWS("R    chol ok %d\n", (int)okf);
         if (go && !okf) {
             state = acceptable ? 0 : 2;
@@ -461,7 +471,9 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
         gather(Q.tmp, dua);
 #pragma unroll
         for (int r = 0; r < R; ++r) dua[r] = (go2 && ((mmask >> r) & 1u)) ? (-rd_m[r] + dua[r]) : 0.0;
+#ifndef EMP_QP_PROBE_SKIP_SOLVE
         band_solve_rows<R>(fa, frinv, flow, dua, steps);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (go2 && ((mmask >> r) & 1u)) Q.dua[base + r] = dua[r];
@@ -521,7 +533,9 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
         gather(Q.tmp, du);
 #pragma unroll
         for (int r = 0; r < R; ++r) du[r] = (go2 && ((mmask >> r) & 1u)) ? (-rd_m[r] + du[r]) : 0.0;
+#ifndef EMP_QP_PROBE_SKIP_SOLVE
         band_solve_rows<R>(fa, frinv, flow, du, steps);
+#endif
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (go2 && ((mmask >> r) & 1u)) Q.rhs[base + r] = du[r];
