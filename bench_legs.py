@@ -61,7 +61,7 @@ def committed_parity_sweeps(prefix="r06_parity_sweep_"):
                      scenes_with_the_start_on_a_node=cy.get("scenes_with_the_start_on_a_node"),
                      tie_scenes_beyond_tolerance=len(cy.get("tie_scenes_beyond_tolerance") or []),
                      tie_scenes_not_explained_by_the_flipped_branch=cy.get("tie_scenes_not_explained_by_the_flipped_branch"))
-        for part in ("st", "fe", "front"):
+        for part in ("speed_dp", "front_end"):
             if isinstance(d.get(part), dict):
                 e[part] = {k: v for k, v in d[part].items() if isinstance(v, (int, float, str)) and k != "seconds"}
         out[os.path.basename(path)[len(prefix):-5]] = e

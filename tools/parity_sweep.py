@@ -318,7 +318,7 @@ def main():
         ok = ok and not (m_bad or s_bad) and worst_fe <= 1e-6
     if "dp" in PARTS:
         ok = ok and not any(bad.values())
-    if "cycle" in PARTS:
+    if "cycle" in PARTS and N_CY > 0:
         ok = ok and not (outcome or feas_bad or length or tie_unresolved) and worst_rule <= 1.0
     print("PARITY-SWEEP", "OK" if ok else "MISMATCH")
     return 0 if ok else 1
