@@ -22,9 +22,11 @@ def child(lib):
     pl = Planner(0)
     p, sp = dp_params_from_cfg(cfg), smooth_params()
     out = []
-    for K in (0, 1, 2, 4, 8, 12, None):
+    for K in ("bounds only", 0, 1, 2, 4, 8, 12, None):
         q = qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width)
-        if K is not None:
+        if K == "bounds only":
+            q.reserved = 1               # debug stage 1: every group idles after cal_lmin_lmax (load + bounds + the kernel's skeleton)
+        elif K is not None:
             q.reserved = 10 + K
         for _ in range(3):
             pl.plan_cycle(p, q, sp, **dev)
@@ -35,7 +37,7 @@ def child(lib):
         pl.synchronize()
         out.append((K, pl.kernel_ms("path_qp") * 1e3))
         pl.set_timing(False)
-    ks = [(k, t) for k, t in out if k is not None]
+    ks = [(k, t) for k, t in out if isinstance(k, int)]
     slope = (ks[-1][1] - ks[2][1]) / (ks[-1][0] - ks[2][0])
     print(f"{os.path.basename(lib):28s}", "  ".join(f"K={k}: {t:6.1f} us" for k, t in out), f"  per iteration {slope:.2f} us", flush=True)
     pl.close()
