@@ -343,6 +343,32 @@ __device__ inline int argmin_abs(const double* s, int stride, int n, double targ
     return best;
 }
 
+// The three scans of one obstacle (ref path_planning.py:240, :241, :257) in ONE pass over the stations, four stations a step: the
+// same comparisons in the same order per target as three argmin_abs calls (strict '<': the first minimum), but the stations are
+// read once and four LDS reads are in flight at a time - the three separate loops were 3 n dependent LDS round trips of a wavefront
+// that has its SIMD to itself (round 6: 4 us of the path-QP kernel's 30 us set-up).  n >= 1.
+__device__ inline void argmin_abs3(const double* s, int n, double t0, double t1, double t2, int* i0, int* i1, int* i2) {
+    const double f = s[0];
+    double b0 = fabs(f - t0), b1 = fabs(f - t1), b2 = fabs(f - t2);
+    int k0 = 0, k1 = 0, k2 = 0;
+    for (int j0 = 1; j0 < n; j0 += 4) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = s[min(j0 + u, n - 1)];      // past the end: the last station again (never a strict improvement)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const double a0 = fabs(v[u] - t0), a1 = fabs(v[u] - t1), a2 = fabs(v[u] - t2);
+            if (a0 < b0) { b0 = a0; k0 = j; }
+            if (a1 < b1) { b1 = a1; k1 = j; }
+            if (a2 < b2) { b2 = a2; k2 = j; }
+        }
+    }
+    *i0 = min(k0, n - 1);      // (k never exceeds n - 1: a repeated last station is not strictly below itself; the clamp costs nothing)
+    *i1 = min(k1, n - 1);
+    *i2 = min(k2, n - 1);
+}
+
 __device__ inline bool lmin_lmax(const double* dp_s, const double* dp_l, int stride, int n, const double* obs_s,
                                  const double* obs_l, int n_obs, double obs_length, double obs_width, double* l_min,
                                  double* l_max) {
@@ -663,9 +689,10 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         bool bad = false;
         for (int k = gl; k < nob; k += G) {
             const double os = obs_s[(size_t)b * max_obs + k], ol = obs_l[(size_t)b * max_obs + k];
-            const int lo = argmin_abs(sd, 1, n, os - Q.obs_length / 2.0) + 2;     // ref :240
-            const int hi = argmin_abs(sd, 1, n, os + Q.obs_length / 2.0) + 2;     // ref :241
-            const int centre = argmin_abs(sd, 1, n, os);                           // ref :257
+            int lo, hi, centre;                                                    // ref :240, :241, :257
+            argmin_abs3(sd, n, os - Q.obs_length / 2.0, os + Q.obs_length / 2.0, os, &lo, &hi, &centre);
+            lo += 2;
+            hi += 2;
             const bool below = ld[centre] < ol;                                    // ref :263
             otab[4 * k + 0] = (double)lo;
             otab[4 * k + 1] = (double)hi;
@@ -678,16 +705,48 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
             live = false;
         }
         __syncthreads();
-        for (int j = gl; j < (live ? n : 0); j += G) {
-            double a = -10.0, c = 10.0;                                            // ref :233-234
+        {
+            // obstacle by obstacle (its four table entries read ONCE, the same for every lane), each lane folding it into its own
+            // stations gl, gl + G, ...: the same fmin / fmax in the same obstacle order per station as the station-outer loop this
+            // replaces, with nob LDS round trips instead of (stations per lane) x nob
+            constexpr int T = R > 0 ? R + 1 : (G == 64 ? 4 : 2);                  // stations a lane can own (cap <= G R + 2; 34 / 32; 255 / 64)
+            const int nn = live ? n : 0;
+            double a[T], c[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                a[t] = -10.0;                                                      // ref :233-234
+                c[t] = 10.0;
+            }
             for (int k = 0; k < nob; ++k) {
-                if ((double)j >= otab[4 * k] && (double)j <= otab[4 * k + 1]) {
-                    if (otab[4 * k + 2] != 0.0) c = fmin(c, otab[4 * k + 3]);
-                    else a = fmax(a, otab[4 * k + 3]);
+                const double klo = otab[4 * k], khi = otab[4 * k + 1], kbelow = otab[4 * k + 2], kb = otab[4 * k + 3];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const double j = (double)(gl + G * t);
+                    if (j >= klo && j <= khi) {
+                        if (kbelow != 0.0) c[t] = fmin(c[t], kb);
+                        else a[t] = fmax(a[t], kb);
+                    }
                 }
             }
-            lmin[j] = a;
-            lmax[j] = c;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int j = gl + G * t;
+                if (j < nn) {
+                    lmin[j] = a[t];
+                    lmax[j] = c[t];
+                }
+            }
+            for (int j = gl + G * T; j < nn; j += G) {                            // (no launch gives a lane more stations than T: kept for safety)
+                double aj = -10.0, cj = 10.0;
+                for (int k = 0; k < nob; ++k) {
+                    if ((double)j >= otab[4 * k] && (double)j <= otab[4 * k + 1]) {
+                        if (otab[4 * k + 2] != 0.0) cj = fmin(cj, otab[4 * k + 3]);
+                        else aj = fmax(aj, otab[4 * k + 3]);
+                    }
+                }
+                lmin[j] = aj;
+                lmax[j] = cj;
+            }
         }
         __syncthreads();
         if (Q.debug_stage == 1) live = false;
