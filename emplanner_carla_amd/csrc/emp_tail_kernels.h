@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64) void reference_line_wave_kernel(int B, int max_
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const double* line = global_path + (size_t)b * max_global * 4;
-    const int P = n_global[b];
+    const int P = min(n_global[b], max_global);          // a count beyond the row's capacity is clamped, never followed
     double* gxy = lds;                                   // [51][2]
     double* qmem = gxy + 2 * kRefLinePoints;
     double* out = ref_line + (size_t)b * kRefLinePoints * 4;

@@ -114,6 +114,32 @@ expect(cycle(ss=None), "emp_plan_cycle smooth params NULL")
 for kw in (dict(nB=-5), dict(max_ref=0), dict(max_ref=-1), dict(max_ref=1), dict(mo=-2), dict(mo=300), dict(max_pts=0), dict(max_pts=-4)):
     expect(cycle(**kw), f"emp_plan_cycle {kw}")
 expect(cycle(nB=0), "emp_plan_cycle B=0", allow_ok=True)
+# the optional front end (ABI 11): with a global path every one of its five fields is required, max_global >= 1, max_ref == 51
+gp = np.zeros((B, 80, 4))
+gp[:, :, 0] = np.arange(80) * 2.0
+front = dict(global_path=gp, n_global=np.full(B, 80, np.int32), pre_match_index=np.full(B, 12, np.int32),
+             match_index=np.zeros(B, np.int32), ref_status=np.zeros(B, np.int32))
+
+
+def cycle_front(drop=None, max_global=80, max_ref=51, **over):
+    io = L.CycleIO()
+    for k, v in {**inp, **out, **front, **over}.items():
+        setattr(io, k, None if k in (drop, "ref_line", "n_ref") else v.ctypes.data)
+    io.max_global = max_global
+    return lib.emp_plan_cycle(h, C.byref(p), C.byref(q), C.byref(sp), B, max_ref, MO, M, 1, C.byref(io), L.EMP_HOST)
+
+
+assert cycle_front() == 0 and (front["ref_status"] == 0).all() and (front["match_index"] >= 0).all()
+for name in ("n_global", "pre_match_index", "match_index", "ref_status"):
+    expect(cycle_front(drop=name), f"emp_plan_cycle front end: {name} NULL")
+expect(cycle_front(max_global=0), "emp_plan_cycle front end: max_global 0")
+expect(cycle_front(max_ref=P if P != 51 else 61), "emp_plan_cycle front end: max_ref != 51")
+wild = dict(n_global=np.full(B, 10 ** 6, np.int32))                      # a count beyond the row's capacity must never be followed
+wild["n_global"][::2] = -7
+expect(cycle_front(**wild), "front end: n_global beyond the capacity / negative (clamped or refused per scene)", allow_ok=True)
+expect(cycle_front(pre_match_index=np.full(B, -9, np.int32)), "front end: negative pre_match_index (status bits)", allow_ok=True)
+assert (front["ref_status"] != 0).all()
+assert cycle() == 0
 # a capacity too small for the path is a per-scene status bit (EMP_ST_TRUNCATED), never a write past the buffers
 small = 5
 guard = 64
@@ -149,7 +175,9 @@ expect(lib.emp_dp_plan(None, C.byref(p), B, MO, ptr(obs_s), ptr(obs_l), ptr(n_ob
 assert lib.emp_synchronize(None) < 0 and lib.emp_set_pipeline(None, 1) < 0
 assert lib.emp_set_pipeline(h, L.EMP_PIPELINE_MAX + 1) < 0 and b"EMP_PIPELINE_MAX" in lib.emp_last_error(h), "too many lanes is an error"
 assert lib.emp_set_fence(None, 1) < 0 and lib.emp_set_fence(h, 0) == 0 and lib.emp_set_fence(h, 1) == 0
-assert lib.emp_set_pipeline(h, -5) == 0 and lib.emp_set_pipeline(h, 3) == 0 and lib.emp_set_pipeline(h, 0) == 0    # negative = off
+assert lib.emp_set_pipeline(h, -5) < 0 and lib.emp_set_pipeline(h, 3) == 0 and lib.emp_set_pipeline(h, 0) == 0    # below EMP_PIPELINE_AUTO: an error (ABI 11)
+assert lib.emp_set_pipeline(h, L.EMP_PIPELINE_AUTO) == 0 and lib.emp_pipeline_form(h, None, None) in (1, 3) and lib.emp_set_pipeline(h, 0) == 0
+assert lib.emp_pipeline_form(None, None, None) < 0 and lib.emp_edge_clock_mhz(None) < 0 and lib.emp_edge_clock_mhz(h) < 0      # nothing recorded
 nul = C.c_void_p()
 assert lib.emp_device_alloc(h, C.c_uint64(1 << 62), C.byref(nul)) < 0 and not nul.value, "an impossible allocation is an error"
 assert lib.emp_create(9999, C.byref(nul)) < 0 and lib.emp_last_error(None), "no such device"
