@@ -438,6 +438,11 @@ __device__ int path_qp_solve_rows(PathRangeQp& Q, int gl, bool live, int iter_ca
             for (int r = 0; r < R; ++r)
                 if ((mmask >> r) & 1u) keep[base + r] = Q.u[base + r];
         }
+        // Nobody left to iterate (the pass in which the last group of the wavefront converges or gives up): leave here.  The rest of
+        // the body - factorisation, two solves, the step - would run fully masked: 4.5 us of a 6.6-us pass, once per wavefront
+        // (round 6, found by tools/qp_phase_probe.py: a solve capped at K iterations cost K + 1 passes).  Wave-uniform: one
+        // wavefront per block, so every lane of the block leaves together.
+        if (!__any(state == 1)) break;
         const bool go = state == 1;
         // ---- 3: factorisation
 #ifdef EMP_QP_PROBE_SKIP_CHOL
@@ -617,6 +622,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
     Q.bind_fast(lds + kCc, GP * R, GP * R, nn - 4 > 0 ? nn - 4 : 0, nn - 2 > 0 ? nn - 2 : 0);
     int rc = path_qp_setup_group<GP>(Q, cc, l_min, l_max, n, l0, dl0, ddl0, prm, gl, live);
     if (!live) rc = 2;
+    if (EMP_DEV_HOOKS && debug_stage == 2) rc = 2;          // development timing: stop behind the set-up (tools/qp_phase_probe.py)
     __syncthreads();
     bool ok = rc == 0;
     const int base = gl * R;
@@ -643,6 +649,7 @@ __device__ inline int path_qp_group_rows(double* lds, const double* l_min, const
             if (act && base + r < Q.N) Q.u[base + r] = b0[r];
         if (ok && !okc) rc = 2;
     }
+    if (EMP_DEV_HOOKS && debug_stage == 3) rc = 2;          // ... behind the start point
     __syncthreads();
     ok = rc == 0;
     const int cap_it = debug_stage >= 10 ? debug_stage - 10 : 1000;

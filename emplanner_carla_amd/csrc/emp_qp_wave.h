@@ -544,6 +544,7 @@ __device__ int range_qp_solve_wave(RangeQp<KD, F, W>& Q, int gl, bool live, int 
             if (state == 1 && acc_now && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;     // see range_qp_solve_wave_fast
         }
         __syncthreads();
+        if (!__any(state == 1)) break;          // nobody left to iterate: the rest of the pass would run fully masked (emp_qp_rows.h; one wavefront per block)
         const bool go = state == 1;
         // ---- C: factorisation.  N <= G: register-resident, one band row per lane; otherwise lane 0 out of LDS.
         int ok = 1;
@@ -896,6 +897,7 @@ __device__ int range_qp_solve_wave_fast(RangeQp<KD, F, W>& Q, int gl, bool live,
                 if (state == 1 && acc_now && rp_max <= Q.eps_p && mu <= Q.eps_mu) state = 0;
             }
         }
+        if (!__any(state == 1)) break;          // nobody left to iterate: the rest of the pass would run fully masked (emp_qp_rows.h; one wavefront per block)
         const bool go = state == 1;
         EMP_QP_PROF(3);
         // ---- 3: factorisation in registers
@@ -1338,6 +1340,7 @@ __device__ inline int box_qp_lanes(double r, int m, const SmoothQpParams& prm, d
             else if (iters >= kQpMaxIter) state = acceptable ? 0 : 2;
             if (rd_max <= 100.0 * eps_d_rel * dscale && rp_max <= 10.0 * eps_p && mu <= 1000.0 * eps_mu) acceptable = true;
         }
+        if (!__any(state == 1)) break;          // nobody left to iterate: the rest of the pass would run fully masked (emp_qp_rows.h; one wavefront per block)
         const bool go = state == 1;
         double fa[KD + 1], flow[KD + 1], frinv = 1.0;
         fa[0] = (go && has) ? Prow[0] + (wu + wl) : 0.0;

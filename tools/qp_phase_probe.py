@@ -22,10 +22,14 @@ def child(lib):
     pl = Planner(0)
     p, sp = dp_params_from_cfg(cfg), smooth_params()
     out = []
-    for K in ("bounds only", 0, 1, 2, 4, 8, 12, None):
+    for K in ("bounds only", "set-up", "start point", 0, 1, 2, 4, 8, 12, None):
         q = qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width)
         if K == "bounds only":
             q.reserved = 1               # debug stage 1: every group idles after cal_lmin_lmax (load + bounds + the kernel's skeleton)
+        elif K == "set-up":
+            q.reserved = 2               # ... after the B-spline problem is built
+        elif K == "start point":
+            q.reserved = 3               # ... after the unconstrained minimiser
         elif K is not None:
             q.reserved = 10 + K
         for _ in range(3):
