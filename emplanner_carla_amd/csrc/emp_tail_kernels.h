@@ -670,6 +670,9 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         otab = ql + cap;              // per obstacle: lo, hi, below, bound   [4*max_obs]
         qmem = otab + 4 * max_obs;
     }
+#ifdef EMP_QP_PROBE_EMPTY
+    if (Q.debug_stage == 4) return;                 // development timing: the launch alone (tools/qp_phase_probe.py)
+#endif
     const int ne = present ? dp_len[b] : 0;
     const int dec = Q.decimate > 0 ? Q.decimate : 1;
     const int n = (ne + dec - 1) / dec;                                            // len(x[::dec])
@@ -682,6 +685,9 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         ld[i] = dp_l[o + (size_t)i * dec];
     }
     __syncthreads();
+#ifdef EMP_QP_PROBE_EMPTY
+    if (Q.debug_stage == 5) return;                 // ... behind the loads of the DP path
+#endif
     if (Q.use_qp) {
         // ---- cal_lmin_lmax (ref path_planning.py:222-273): one obstacle per lane finds its index range,
         // then one station per lane folds the (commutative) min / max over the obstacles covering it

@@ -22,9 +22,13 @@ def child(lib):
     pl = Planner(0)
     p, sp = dp_params_from_cfg(cfg), smooth_params()
     out = []
-    for K in ("bounds only", "set-up", "start point", 0, 1, 2, 4, 8, 12, None):
+    for K in ("launch", "loads", "bounds only", "set-up", "start point", 0, 1, 2, 4, 8, 12, None):
         q = qp_params(obs_length=cfg.obs_length, obs_width=cfg.obs_width)
-        if K == "bounds only":
+        if K == "launch":
+            q.reserved = 4               # (builds with -DEMP_QP_PROBE_EMPTY) the kernel returns at once
+        elif K == "loads":
+            q.reserved = 5               # ... behind the loads of the DP path
+        elif K == "bounds only":
             q.reserved = 1               # debug stage 1: every group idles after cal_lmin_lmax (load + bounds + the kernel's skeleton)
         elif K == "set-up":
             q.reserved = 2               # ... after the B-spline problem is built
