@@ -276,7 +276,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", default="auto", help="emp_set_pipeline mode: 'staged' (two batches, back stage of one over "
                     "the front stage of the next; the sweep keeps its bandwidth), 'off', or n >= 2 = n batches on n lanes "
-                    "(more overlap: shorter steps, every kernel's own launches longer); 'auto' (default) = 3 lanes")
+                    "(more overlap: shorter steps, every kernel's own launches longer); 'auto' (default) = emp_set_pipeline(EMP_PIPELINE_AUTO): "
+                    "three lanes when every stream gets a hardware queue (bench.py asks for 12), else staged")
     ap.add_argument("--no-pipeline", action="store_true", help="the same as --pipeline off")
     ap.add_argument("--one-rank-rccl", action="store_true", help="with --force-gather-path on one GPU: a one-rank ProcessGroupNCCL, "
                     "so that every step's gather is a real RCCL call (rccl_gather_leg of the default run)")
@@ -423,15 +424,28 @@ def main():
     # nearly alone on the chip; lanes are the faster form on every workload measured (4096 scenes 0.220 -> 0.201 ms per step,
     # 1024 scenes 0.19 -> 0.12, 8192 0.416 -> 0.368, 32768 1.47 -> 1.45, configs[4] the same), so they are what the headline
     # runs - the staged form and its sweep are the `staged_leg` / `exclusive_sweep_leg` of the same line.
-    if args.pipeline == "auto":
-        args.pipeline = DEFAULT_PIPELINE
-    pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
     options = {}
     for kv in args.opt:
         name, val = kv.split("=")
         pl.set_option(name, int(val))
         options[name] = int(val)
-    pl.set_pipeline(pmode)
+    auto_choice = None
+    if args.pipeline == "auto" and not args.no_pipeline:
+        # emp_set_pipeline(EMP_PIPELINE_AUTO): three lanes if every stream of this process gets a hardware queue of its own - the
+        # queues configure_hw_queues(12) asked for above, unless the environment already said otherwise - else the staged form.
+        # Beside the lanes and the planner's own streams the process runs torch's stream and, with the exchange, the gather
+        # stream and RCCL's.
+        will_gather = (world > 1 or args.force_gather_path) and args.gather != "none"
+        if "foreign_streams" not in options:
+            pl.set_option("foreign_streams", 1 + (2 if will_gather else 0))
+        pl.set_pipeline("auto")
+        form, queues, others = pl.pipeline_form()
+        auto_choice = {"form": "staged" if form == 1 else f"{form} lanes", "hardware_queues": queues, "streams_beside_the_lanes": others}
+        args.pipeline = "staged" if form == 1 else str(form)
+        pmode = form
+    else:
+        pmode = 0 if (args.no_pipeline or args.pipeline == "off") else (1 if args.pipeline == "staged" else int(args.pipeline))
+        pl.set_pipeline(pmode)
     pipelined, in_flight = pl.pipelined, pl.in_flight
     ts = pl.torch_stream()
 
@@ -615,7 +629,7 @@ def main():
     # and its diagnostic pass; each is a short measurement of its own and never touches the headline's numbers
     legs = {}
     if (world == 1 and not gather_path and not wide and not args.no_legs and args.scenes_per_gpu in (0, 4096) and args.total_scenes in (0, 4096)
-            and args.dp_mode == "two_kernel" and args.pipeline == DEFAULT_PIPELINE and args.scene_dist == "corridor"):
+            and args.dp_mode == "two_kernel" and (auto_choice is not None or args.pipeline == DEFAULT_PIPELINE) and args.scene_dist == "corridor"):
         # (a) the staged pipeline of rounds 2-5 (two batches: the front stage of one beside the back stage of the other; the sweep
         # overlaps only the previous batch's Cartesian tail), with the library's default options and with the sweep held back
         # behind the previous batch's path QP (EMP_OPT_SWEEP_EXCLUSIVE = 2).  Each in a process of its own: which hardware queue
@@ -794,6 +808,7 @@ def main():
                        "scene_dist": args.scene_dist, "start_ahead_m": args.start_ahead, "arc_radii_m": list(scene_kw["radius_range"]),
                        "ref_line_points": int(P), "dp_mode": args.dp_mode,
                        "batches_in_flight": in_flight, "pipeline": "off" if pmode == 0 else "staged" if pmode == 1 else f"{pmode} lanes",
+                       "pipeline_chosen_by_the_library": auto_choice,
                        "parallelism": f"scenes sharded over {world} GPU(s), one process per GPU"},
             "roofline": roof,
             "roofline_step": (roofline_step(cfg, count, args.scene_dist, elapsed / args.steps * 1e3, speed=wide, measured_clock_mhz=edge_clock_mhz) if pmode != 0 else None),

@@ -42,6 +42,11 @@ def test_bench_line(extra):
     assert d["roofline"]["frac_alone"] > (0.15 if "--force-gather-path" in extra else 0.3) and len(d["roofline"]["launch_us_min_median_max"]) == 3
     assert d["config"]["batches_in_flight"] == (1 if "--no-pipeline" in extra else lanes or 2)
     assert d["config"]["pipeline"] == ("off" if "--no-pipeline" in extra else f"{lanes} lanes" if lanes else "staged")
+    if "--pipeline" not in extra and "--no-pipeline" not in extra:      # the default: the library chose, on the 12 queues bench.py asks for
+        c = d["config"]["pipeline_chosen_by_the_library"]
+        assert c["form"] == "3 lanes" and c["hardware_queues"] == 12 and c["streams_beside_the_lanes"] == (4 if "--force-gather-path" in extra else 2)
+    else:
+        assert d["config"]["pipeline_chosen_by_the_library"] is None
     if "--alt-pipeline" in extra:      # the second timed region, in the staged form
         alt = d["alt_pipeline"]
         assert alt["pipeline"] == "staged" and alt["all_scenes_cycles_per_s"] > 1e6 and 0.05 < alt["sweep_roofline_frac"] < 1.0
@@ -235,3 +240,16 @@ def test_bare_command_with_gpus_2_launches_two_ranks(size):
     else:
         assert d["scaling"] == "weak" and d["config"]["total_scenes"] == 2048 and d["config"]["scenes_per_rank"] == [1024, 1024]
     assert d["value"] > 1e4 and 0.8 < d["scenes_fully_planned_frac"] < 0.95
+
+
+def test_default_bench_takes_the_staged_form_when_the_process_has_four_hardware_queues():
+    """`python bench.py` asks the library for the pipeline form (EMP_PIPELINE_AUTO).  With GPU_MAX_HW_QUEUES=4 already in the
+    environment - bench.py does not override it - three lanes would share queues and run at 0.28 ms per step; the line must show
+    the staged form, chosen by the library, and a step near the staged form's."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-legs"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, GPU_MAX_HW_QUEUES="4"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["config"]["pipeline"] == "staged" and d["config"]["batches_in_flight"] == 2
+    assert d["config"]["pipeline_chosen_by_the_library"] == {"form": "staged", "hardware_queues": 4, "streams_beside_the_lanes": 2}
+    assert d["ms_per_step"] < 0.26 and d["roofline"]["frac"] > 0.45       # (three lanes on four queues: 0.28 ms, sweep 0.45 by accident of sharing)
