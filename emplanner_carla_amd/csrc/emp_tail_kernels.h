@@ -777,8 +777,14 @@ __device__ __forceinline__ void cycle_qp_body(int B, int max_pts, int max_obs, i
         double* ps = path_s + o;
         double* pl = path_l + o;
         int plen = 0;
-        // station abscissa i: from LDS, or - rows form, where the solver has overwritten it - from the DP path again
-        auto sd_at = [&](int i) { return (R > 0 && Q.use_qp) ? dp_s[o + (size_t)i * dec] : sd[i]; };
+        // station abscissa i: from LDS, or - rows form, where the solver has overwritten it - from the DP path again (the same
+        // number: sd[i] IS dp_s[i dec]).  The choice is made at COMPILE time (round 6): as a run-time select between a device and an
+        // LDS address it compiled to one flat load behind a select of two pointers, and builds of this kernel that differed only
+        // in where an unrelated value was loaded read that address wrong (an aperture violation, or midpoints of the wrong stations).
+        auto sd_at = [&](int i) {
+            if constexpr (R > 0) return dp_s[o + (size_t)i * dec];
+            else return sd[i];
+        };
         if (live) {
             if (Q.midpoint) {                                                      // ref test_9.py:204-210
                 for (int i = gl; i <= n; i += G) {
