@@ -349,7 +349,7 @@ static int dev_dp_enrich(emp_ctx* ctx, const DpDev& d, const double* rows, const
                          const unsigned char* pre = nullptr, const int* term = nullptr, const int* n_obs = nullptr,
                          double* rows_out = nullptr) {
     if (d.B == 0) return EMP_OK;
-    const size_t lds = pre ? (size_t)d.col * sizeof(double) + (size_t)d.col * d.row : 0;
+    const size_t lds = (size_t)d.col * sizeof(double) + (pre ? (size_t)d.col * d.row : 0);      // the rows [col], + the predecessor bytes
     EMP_REQUIRE(ctx, lds <= 160 * 1024, "too many columns for the densification kernel's predecessor table in LDS");
     if (lds > 48 * 1024)
         EMP_HIP(ctx, hipFuncSetAttribute((const void*)dp_enrich_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

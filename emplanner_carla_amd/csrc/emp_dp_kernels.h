@@ -1132,9 +1132,15 @@ __global__ __launch_bounds__(64) void dp_enrich_wave_kernel(DpDev P, const doubl
     const double ps = start[b * 4 + 0];
     double* os = path_s + (size_t)b * max_pts;
     double* ol = path_l + (size_t)b * max_pts;
-    const double* my_rows = rows + (size_t)b * P.col;
-    if (pre != nullptr) {
-        double* lrows = enrich_lds;                                                   // [col]
+    // The scene's rows are read from LDS in BOTH forms (round 6): as a run-time choice between the device array and the LDS copy
+    // the reads compiled to flat loads behind a select of two address spaces - the pattern that perturbed builds of the path-QP
+    // kernel read wrong (emp_tail_kernels.h, sd_at).
+    double* lrows = enrich_lds;                                                       // [col]
+    const double* my_rows = lrows;
+    if (pre == nullptr) {
+        for (int j = lane; j < P.col; j += 64) lrows[j] = rows[(size_t)b * P.col + j];
+        __syncthreads();
+    } else {
         unsigned char* bt = reinterpret_cast<unsigned char*>(lrows + P.col);          // [col][row]
         const int tile = b / P.S, base = (b - tile * P.S) * P.row;
         const unsigned char* tp = pre + (size_t)tile * P.col * 64 + base;
@@ -1156,7 +1162,6 @@ __global__ __launch_bounds__(64) void dp_enrich_wave_kernel(DpDev P, const doubl
         }
         __syncthreads();
         for (int j = lane; j < P.col; j += 64) rows_out[(size_t)b * P.col + j] = lrows[j];
-        my_rows = lrows;
     }
     int n_before = 0;
     bool trunc = false;
