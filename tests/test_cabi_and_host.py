@@ -572,3 +572,27 @@ def test_failing_submit_does_not_shrink_the_cycle_stream_ring():
         assert res.status.shape == (2,) and len(ring.free) == 4
     assert sorted(id(s) for s in ring.free) == sorted(id(s) for s in ring.slots)     # every slot exactly once
     stream.close()
+
+
+def test_no_kernel_addresses_memory_through_a_select_of_address_spaces(tmp_path):
+    """Round 6 found a kernel whose reads went through `cond ? device_pointer : lds_pointer`: the compiler turns that into ONE flat
+    load behind a select of two address spaces, it worked, and builds that differed only in where an unrelated value was loaded read
+    the address wrong (an aperture violation on the GPU box).  The device code is compiled to assembly here
+    (hipcc cross-compiles, ~30 s) and no kernel may contain a flat_* instruction - except heading_kappa_wave, a real out-of-line
+    function whose pointer arguments are generic by construction."""
+    from emplanner_carla_amd import build
+    out = tmp_path / "emp_api.s"
+    cmd = [build.hipcc()] + [f for f in build.FLAGS if f not in ("-shared", "-fPIC")] + \
+          ["--cuda-device-only", "-S", os.path.join(build.CSRC, "emp_api.hip"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    flat, cur = {}, None
+    for line in open(out):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            cur = m.group(1)
+        tok = line.split()
+        if cur and tok and tok[0].startswith("flat_"):
+            flat[cur] = flat.get(cur, 0) + 1
+    offenders = {k: v for k, v in flat.items() if "heading_kappa_wave" not in k}
+    assert not offenders, f"flat memory instructions in {offenders}"
