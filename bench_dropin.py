@@ -181,6 +181,16 @@ def main(argv=None):
         if k >= 10:
             ms.append((time.perf_counter() - t0) * 1e3)
     line["plan_requests_in_process"] = dict(_stats(ms), what="service.plan_requests(planner, [request]): emp_reference_line + emp_plan_cycle, host arrays")
+    # (iv) the planning process's own fast path, in-process: service.RequestPlanner (what motion_planning runs per request)
+    one = service.RequestPlanner(pl)
+    ms = []
+    for k, req in enumerate(reqs[:10] + reqs):
+        t0 = time.perf_counter()
+        one.plan(req)
+        if k >= 10:
+            ms.append((time.perf_counter() - t0) * 1e3)
+    one.close()
+    line["request_planner_in_process"] = dict(_stats(ms), what="service.RequestPlanner.plan(request): the request written into one page-locked block, one emp_plan_cycle call")
     # the three routes agree (same kernels underneath; the function sequence hands float64 lists from call to call)
     worst, compared = 0.0, 0
     if pipe_replies is not None:

@@ -533,6 +533,10 @@ void emp_destroy(emp_ctx* ctx) {
         if (kv.second.buf.p) (void)hipFree(kv.second.buf.p);
     for (auto& kv : ctx->named)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->arena_h_in) (void)hipHostFree(ctx->arena_h_in);
+    if (ctx->arena_h_out) (void)hipHostFree(ctx->arena_h_out);
+    if (ctx->arena_d_in) (void)hipFree(ctx->arena_d_in);
+    if (ctx->arena_d_out) (void)hipFree(ctx->arena_d_out);
     for (auto& kv : ctx->events)
         for (auto& pr : kv.second.pairs) {
             (void)hipEventDestroy(pr.first);

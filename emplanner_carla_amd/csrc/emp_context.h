@@ -99,6 +99,16 @@ struct emp_ctx {
         size_t bytes;
     };
     std::vector<Pinned> pinned;         // emp_host_alloc allocations still alive (freed by emp_destroy)
+    // Small EMP_HOST calls (round 6): ONE page-locked arena and one device arena per direction.  The arrays of a synchronous call
+    // with host pointers are packed into the input arena by the host and cross PCIe as one copy; the outputs come back as one
+    // copy and are unpacked by the host (Stage).  A copy command costs 4-14 us whatever its size and a call of the reference's
+    // function surface has three to twenty small arrays: emp_lmin_lmax went from 100 to ~60 us (profiles/r06_call_cost_probe.txt).
+    static constexpr size_t kArena = 256 * 1024, kArenaArray = 64 * 1024;
+    char* arena_h_in = nullptr;         // page-locked, kArena bytes each
+    char* arena_h_out = nullptr;
+    char* arena_d_in = nullptr;         // device, kArena bytes each
+    char* arena_d_out = nullptr;
+    bool arena_failed = false;          // an allocation failed once: the per-array path from then on
     // STAGED: the event the front stage's LAST kernel (the sweep) is asked to signal when it completes (hipExtLaunchKernelGGL's
     // stop event: no marker packet behind the kernel), and the event that launch did attach - its own timing event when the
     // kernel is being timed, else front_stop, else nullptr (launchers that attach nothing: the caller records an event).
@@ -238,6 +248,7 @@ class Stage {
     Stage(emp_ctx* c, emp_mem where, bool in_cycle = false, bool async_host = false)
         : ctx_(c), dev_(where == EMP_DEVICE), async_(async_host && where != EMP_DEVICE) {
         c->cursor = 0;
+        arena_ = !dev_ && !async_ && where == EMP_HOST && !c->capturing;
         if (!in_cycle && c->pipelined() && c->fence)
             for (auto& ln : c->lanes)
                 if (ln.done_valid) (void)hipStreamWaitEvent(c->stream, ln.ev_done, 0);
@@ -252,11 +263,28 @@ class Stage {
             *out = reinterpret_cast<const T*>(kPending);
             return EMP_OK;
         }
+        if (arena_ && arena_take(n * sizeof(T), &in_used_)) {      // packed: one copy for all small inputs (flush_inputs)
+            const size_t off = in_used_ - arena_round(n * sizeof(T));
+            if (n) memcpy(ctx_->arena_h_in + off, host, n * sizeof(T));
+            *out = (const T*)(ctx_->arena_d_in + off);
+            return EMP_OK;
+        }
         void* d = nullptr;
         int rc = pool_get(ctx_, n * sizeof(T), &d);
         if (rc) return rc;
         if (n) EMP_HIP(ctx_, hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, ctx_->stream));
         *out = (const T*)d;
+        return EMP_OK;
+    }
+    // The packed inputs gathered so far go to the device: ONE copy on the context's stream.  Called by every out() and tmp() -
+    // each entry point declares its outputs and temporaries behind its inputs and in front of its first launch - and by finish(),
+    // which refuses a call that launched with inputs still pending (a new entry point that breaks the order fails loudly).
+    int flush_inputs() {
+        if (in_used_ > in_sent_) {
+            EMP_HIP(ctx_, hipMemcpyAsync(ctx_->arena_d_in + in_sent_, ctx_->arena_h_in + in_sent_, in_used_ - in_sent_,
+                                         hipMemcpyHostToDevice, ctx_->stream));
+            in_sent_ = in_used_;
+        }
         return EMP_OK;
     }
     // async_host: every input of the call is known.  Arrays that lie side by side in host memory (a HostRing slot is ONE
@@ -301,6 +329,19 @@ class Stage {
             return EMP_OK;
         }
         if (!dev_) {
+            int rcf = flush_inputs();
+            if (rcf) return rcf;
+            if (arena_ && arena_take(n * sizeof(T), &out_used_)) {       // packed: one zero fill, one copy back (finish)
+                const size_t off = out_used_ - arena_round(n * sizeof(T));
+                if (!out_zeroed_) {      // the whole output arena once per call instead of a memset per array
+                    EMP_HIP(ctx_, hipMemsetAsync(ctx_->arena_d_out, 0, emp_ctx::kArena, ctx_->stream));
+                    out_zeroed_ = true;
+                }
+                arena_backs_.push_back({host, nullptr, n * sizeof(T), nullptr});
+                arena_offs_.push_back(off);
+                *outp = (T*)(ctx_->arena_d_out + off);
+                return EMP_OK;
+            }
             void* v = nullptr;
             int rc = pool_get(ctx_, n * sizeof(T), &v);
             if (rc) return rc;
@@ -314,6 +355,10 @@ class Stage {
     // device-only temporary
     template <typename T>
     int tmp(size_t n, T** outp, bool zero = false) {
+        if (!dev_ && !async_) {
+            int rcf = flush_inputs();
+            if (rcf) return rcf;
+        }
         void* v = nullptr;
         int rc = pool_get(ctx_, n * sizeof(T), &v);
         if (rc) return rc;
@@ -322,9 +367,14 @@ class Stage {
         return EMP_OK;
     }
     int finish() {
+        if (in_used_ > in_sent_)      // (cannot happen with the entry points as they are: see flush_inputs)
+            return emp::fail(ctx_, EMP_ERR_INVALID, "internal: packed inputs were never sent (an entry point launched before declaring its outputs)");
         for (auto& b : backs_)
             if (b.bytes) EMP_HIP(ctx_, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx_->stream));
+        if (out_used_) EMP_HIP(ctx_, hipMemcpyAsync(ctx_->arena_h_out, ctx_->arena_d_out, out_used_, hipMemcpyDeviceToHost, ctx_->stream));
         if (!dev_) EMP_HIP(ctx_, hipStreamSynchronize(ctx_->stream));
+        for (size_t i = 0; i < arena_backs_.size(); ++i)
+            if (arena_backs_[i].bytes) memcpy(arena_backs_[i].host, ctx_->arena_h_out + arena_offs_[i], arena_backs_[i].bytes);
         return EMP_OK;
     }
     bool on_device() const { return dev_; }
@@ -393,8 +443,37 @@ class Stage {
         }
         return EMP_OK;
     }
+    static size_t arena_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    // room for `bytes` in an arena whose fill mark is *used?  Creates the four arenas on first use; false = take the per-array path
+    // (an array of more than kArenaArray bytes - a host memcpy of that size costs more than the copy command it saves - or a full arena)
+    bool arena_take(size_t bytes, size_t* used) {
+        if (bytes > emp_ctx::kArenaArray || *used + arena_round(bytes) > emp_ctx::kArena || ctx_->arena_failed) return false;
+        if (!ctx_->arena_h_in) {
+            void *hi = nullptr, *ho = nullptr, *di = nullptr, *dout = nullptr;
+            if (hipHostMalloc(&hi, emp_ctx::kArena, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc(&ho, emp_ctx::kArena, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&di, emp_ctx::kArena) != hipSuccess || hipMalloc(&dout, emp_ctx::kArena) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hi) (void)hipHostFree(hi);
+                if (ho) (void)hipHostFree(ho);
+                if (di) (void)hipFree(di);
+                if (dout) (void)hipFree(dout);
+                ctx_->arena_failed = true;
+                return false;
+            }
+            ctx_->arena_h_in = (char*)hi;
+            ctx_->arena_h_out = (char*)ho;
+            ctx_->arena_d_in = (char*)di;
+            ctx_->arena_d_out = (char*)dout;
+        }
+        *used += arena_round(bytes);
+        return true;
+    }
     emp_ctx* ctx_;
-    bool dev_, async_;
+    bool dev_, async_, arena_ = false, out_zeroed_ = false;
+    size_t in_used_ = 0, in_sent_ = 0, out_used_ = 0;
+    std::vector<Back> arena_backs_;
+    std::vector<size_t> arena_offs_;
     std::vector<Back> backs_, ins_;
     Back block_out_ = {nullptr, nullptr, 0, nullptr};
 };
