@@ -596,3 +596,27 @@ def test_no_kernel_addresses_memory_through_a_select_of_address_spaces(tmp_path)
             flat[cur] = flat.get(cur, 0) + 1
     offenders = {k: v for k, v in flat.items() if "heading_kappa_wave" not in k}
     assert not offenders, f"flat memory instructions in {offenders}"
+
+
+def test_reference_line_conversion_cache_follows_node_identity():
+    """planner/_runtime.line_array converts the reference line once while the SAME immutable node tuples are handed in (the
+    reference's loop passes one list to six functions) and converts again the moment any node is another object - a replaced node,
+    another list of equal length, a list of lists (mutable nodes are never cached)."""
+    from emplanner_carla_amd.planner import _runtime as R
+    path = [(float(i), 2.0 * i, 0.1, 0.0) for i in range(51)]
+    a, n = R.line_array(path)
+    b, _ = R.line_array(path)
+    assert a is b and n[0] == 51 and a.shape == (1, 51, 4)
+    c, _ = R.line_array(list(path))                      # another list object, the same node objects: still the same line
+    assert c is a
+    path[3] = (9.0, 9.0, 9.0, 9.0)                       # a node replaced in place
+    d, _ = R.line_array(path)
+    assert d is not a and d[0, 3, 0] == 9.0 and a[0, 3, 0] == 3.0
+    other = [(float(i), 2.0 * i, 0.1, 0.0) for i in range(51)]     # equal values, other objects
+    e, _ = R.line_array(other)
+    assert e is not d and np.array_equal(e[0, :3], a[0, :3])
+    m1, _ = R.line_array([[1.0, 2.0, 3.0, 4.0]] * 3)
+    m2, _ = R.line_array([[1.0, 2.0, 3.0, 4.0]] * 3)
+    assert m1 is not m2                                   # mutable nodes: converted every time
+    short, n0 = R.line_array([])
+    assert short.shape == (1, 0, 4) and n0[0] == 0
