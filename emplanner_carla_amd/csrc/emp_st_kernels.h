@@ -50,6 +50,13 @@ constexpr int kStBlock = 320;
                               // scenes alone - but beside the cycle kernels of config 5 the 6-wave build takes 10.7 ms per step, the 5-wave build 5.8
 #endif
 constexpr int kStListCap = 256;   // list entries per wavefront (a longer list is processed in windows)
+// Development builds only (tools/st_phase_probe.py; results of a gutted kernel mean nothing, durations do): -DEMP_ST_PROBE=
+//   1  no obstacle reaches any column (interval tests, node sums, pair lists all empty: the kinematic DP alone)
+//   2  interval tests and node sums run, no pair is emitted or costed
+//   3  pairs are emitted and summed, the cost of a window is not computed
+#ifndef EMP_ST_PROBE
+#define EMP_ST_PROBE 0
+#endif
 constexpr int kStWaves = kStBlock / 64;
 constexpr int kStParts = kStBlock / st::kRows;   // 8 partial minima per destination row
 
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             const int k = kb + kStParts * i;          // interleaved: every wavefront sees source rows from the whole s range
             const bool active = c > 0 || tid < kRows;
             const bool from_origin = k == 0;          // ref :208-212 (and every edge of column 0, ref :125-131)
-            const unsigned long long colmask = (wave == 0 && i == 0) ? mask_all : mask_reg;
+            unsigned long long colmask = (wave == 0 && i == 0) ? mask_all : mask_reg;
+            if (EMP_ST_PROBE == 1) colmask &= (unsigned long long)(d.B < 0);   // opaque zero
             const double s0 = from_origin ? 0.0 : L.s_tab[k];
             const double t0 = from_origin ? 0.0 : t_of_col(c - 1);
             const double v0 = from_origin ? v_origin : L.p_sdot[prev * kRows + k];
@@ -284,7 +292,8 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
 #pragma unroll
             for (int m = 2; m < kStSamples; ++m) cnt += sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[m]) : __popc((unsigned)mask[m]);
             const int incl = st_wave_incl_sum(cnt);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int total = __builtin_amdgcn_readlane(incl, 63);
+            if (EMP_ST_PROBE == 2) total *= (d.B < 0);
             const int off = incl - cnt;
             double obs = 0.0;
             bool nodes_done = false;
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                 }
                 st_wave_handover();
                 // ---- cost them, 64 at a time -----------------------------------------------------------------
-                st_cost_window(d.w.w_obs, my_s, my_c, L.t_tab, L.o_s_in, MO, min(kStListCap, total - base), lane);
+                st_cost_window(d.w.w_obs, my_s, my_c, L.t_tab, L.o_s_in, MO, EMP_ST_PROBE == 3 ? (d.B < 0) : min(kStListCap, total - base), lane);
                 st_wave_handover();
                 // ---- ordered sum of the lane's own pairs (ref :249-269: sample outer, obstacle inner) -------
                 const int lo0 = off - base, mid = lo0 + cnt0, hi0 = lo0 + cnt;

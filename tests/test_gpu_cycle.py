@@ -60,6 +60,60 @@ def test_frenet_project_vs_reference(planner, key):
     assert_rel(start[:, 3], g["start"][:, 3], RTOL, "start d2l/ds2")
 
 
+def _near_tie_line(first):
+    """A 51-node line with two nodes 5 m from the point (0, 0) - A = (-4, 3) at exactly 25 m^2, B = (4, 3 + a few ulp) a last bit
+    above 25 m^2 whose ROOT rounds to 5.0 too - each the closest node of a straight stretch tangent to that circle, every other
+    node at 29 m^2 or more.  `first` = which of the two comes first along the line (node 10; the other is node 35)."""
+    ulp = np.spacing(3.0)
+    for k in range(1, 16):
+        yb = 3.0 + k * ulp
+        d2 = 4.0 * 4.0 + yb * yb
+        if d2 > 25.0 and np.sqrt(d2) == 5.0:
+            break
+    else:
+        raise AssertionError("no near tie found")
+    A, B = np.array([-4.0, 3.0]), np.array([4.0, yb])
+    tA, tB = np.array([0.6, 0.8]), np.array([-0.6, 0.8])          # unit tangents of the circle of radius 5 at A and at B
+    (p0, t0), (p1, t1) = ((A, tA), (B, tB)) if first == "A" else ((B, tB), (A, tA))
+    nodes = [p0 + 2.0 * (i - 10) * t0 for i in range(21)]
+    nodes[10] = p0.copy()
+    far = [np.array(v, dtype=np.float64) for v in ((40.0, 40.0), (60.0, 10.0), (60.0, -40.0), (0.0, -60.0))]
+    nodes += far
+    tail = [p1 + 2.0 * (i - 35) * t1 for i in range(25, 51)]
+    tail[10] = p1.copy()
+    nodes += tail
+    xy = np.array(nodes)
+    assert xy.shape == (51, 2)
+    d2_all = xy[:, 0] ** 2 + xy[:, 1] ** 2
+    assert np.sum(d2_all < 28.0) == 2 and d2_all[10] != d2_all[35] and np.sqrt(d2_all[10]) == np.sqrt(d2_all[35]) == 5.0
+    th = np.arctan2(np.gradient(xy[:, 1]), np.gradient(xy[:, 0]))
+    return np.concatenate([xy, th[:, None], np.zeros((51, 1))], axis=1)
+
+
+@pytest.mark.parametrize("first", ["A", "B"])
+def test_projection_scan_where_two_squared_distances_share_a_root(planner, first):
+    """The projection kernel's nearest-node scans compare SQUARED distances and are redone on the distances when two squares are
+    within their last bits of each other (emp_tail_kernels.h, match_scan_wave64): here two nodes of the line are 5.0 m from the
+    point after rounding while their squares differ by one unit in the last place - the reference's strict `<` on the distances
+    (planning_utils.py:390-396) keeps the FIRST of them, the squares alone would pick the smaller.  Origin, planning start and
+    obstacles all sit on such points; s differs by tens of metres between the two nodes."""
+    line = _near_tie_line(first)
+    pt = (0.0, 0.0)
+    obs = [pt, (0.5, 9.0), pt]
+    sm, os_, ol_, bsl, start = planner.frenet_project(ref_line=line[None], n_ref=np.array([51], np.int32), origin_xy=np.array([pt]),
+                                                      start_xy=np.array([pt]), start_v=np.array([[5.0, 1.0]]),
+                                                      start_a=np.array([[0.1, 0.0]]), obs_xy=np.array([obs]), n_obs=np.array([3], np.int32))
+    nodes = [tuple(r) for r in line]
+    want_map = op.cal_s_map_fun(nodes, pt)
+    assert abs(want_map[10]) < 1.0 and abs(want_map[35]) > 30.0          # node 10 is the first of the pair: the s axis starts there
+    assert_rel(sm[0], np.asarray(want_map), RTOL, "s_map")
+    want_s, want_l = op.cal_s_l_fun(obs, nodes, want_map)
+    assert_rel(os_[0, :3], np.asarray(want_s), RTOL, "obs_s")
+    assert_rel(ol_[0, :3], np.asarray(want_l), RTOL, "obs_l")
+    bs, bl = op.cal_s_l_fun([pt], nodes, want_map)
+    assert_rel(bsl[0], np.array([bs[0], bl[0]]), RTOL, "begin s, l")
+
+
 def test_match_and_heading_functions(planner):
     g = load_golden("functions.npz")
     path = g["mp_path"][None]
