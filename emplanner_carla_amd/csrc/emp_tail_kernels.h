@@ -80,16 +80,12 @@ __device__ __forceinline__ double prefix_fmin_step(double v) {
 // pm_i == pm_{i-limit} (no strict improvement among the last `limit` nodes), so the stopping node i* is the first lane where
 // that holds and the answer is the first lane j <= i* with d_j == pm_{i*} - or, if the scan never stops, the first lane that
 // attains the overall minimum.  Half the instructions of the indexed prefix (round 3).
-// SQRT selects what the lanes compare: the distances themselves (the reference's values, planning_utils.py:390) or their squares.
-template <bool SQRT>
-__device__ __forceinline__ int match_scan_wave64_body(const double* lx, const double* ly, int P, double x, double y, int limit,
-                                                      bool* ambiguous) {
+__device__ inline int match_scan_wave64(const double* lx, const double* ly, int P, double x, double y, int limit) {
     const int lane = threadIdx.x & 63;
     double d = __builtin_inf();
     if (lane < P) {
         const double dx = lx[lane] - x, dy = ly[lane] - y;
-        d = dx * dx + dy * dy;
-        if (SQRT) d = sqrt(d);
+        d = sqrt(dx * dx + dy * dy);
     }
     double pm = d;
     pm = prefix_fmin_step<0x111, 0xF>(pm);   // row_shr:1
@@ -99,35 +95,11 @@ __device__ __forceinline__ int match_scan_wave64_body(const double* lx, const do
     pm = prefix_fmin_step<0x142, 0xA>(pm);   // row_bcast:15 -> rows 1, 3
     pm = prefix_fmin_step<0x143, 0xC>(pm);   // row_bcast:31 -> rows 2, 3
     const double back = __shfl(pm, lane >= limit ? lane - limit : 0, 64);
-    const bool scanned = lane < P && lane >= limit;
-    const unsigned long long stop = __ballot(scanned && pm == back);
+    const unsigned long long stop = __ballot(lane < P && lane >= limit && pm == back);
     const int last = stop ? __builtin_ffsll((long long)stop) - 1 : P - 1;          // the node at which the scan ends
     const double target = __shfl(pm, last, 64);
     const unsigned long long hit = __ballot(lane <= last && d == target);
-    if (!SQRT) {
-        // Squares order like their roots (sqrt is monotone), but two DIFFERENT squares may share a root after rounding - only when
-        // they are within a few units in the last place of each other: a < b with b - a > b 2^-49 have roots a factor 1 + 2^-50
-        // apart, four spacings of the doubles there.  Either equality test above that saw such a pair (unequal, closer than that;
-        // an infinite difference counts) makes the answer the caller's to redo on the distances; no such pair, and every comparison
-        // above came out as it does on the distances.  pm <= back and target <= d wherever they are compared.
-        const double kClose = 0x1p-49;
-        const bool a1 = scanned && pm != back && !(back - pm > back * kClose);
-        const bool a2 = lane <= last && d != target && !(d - target > d * kClose);
-        *ambiguous = __any((a1 || a2) && pm == pm && d == d);
-    }
     return hit ? __builtin_ffsll((long long)hit) - 1 : 0;                           // (no finite distance at all: node 0)
-}
-__device__ inline int match_scan_wave64_distances(const double* lx, const double* ly, int P, double x, double y, int limit) {
-    return match_scan_wave64_body<true>(lx, ly, P, x, y, limit, nullptr);
-}
-// Round 6: the lanes compare SQUARED distances - the correctly rounded sqrt was 45 of a scan's 110 instructions and the kernel
-// is ten scans - and the scan is redone on the distances (one wave-uniform branch) when a comparison could have
-// come out differently there: two nodes whose squared distances from the point differ in their last bits only.
-__device__ inline int match_scan_wave64(const double* lx, const double* ly, int P, double x, double y, int limit) {
-    bool ambiguous = false;
-    const int m = match_scan_wave64_body<false>(lx, ly, P, x, y, limit, &ambiguous);
-    if (ambiguous) return match_scan_wave64_distances(lx, ly, P, x, y, limit);
-    return m;
 }
 
 __device__ inline int match_scan_wave(const double* lx, const double* ly, int P, double x, double y, int limit) {
