@@ -86,7 +86,9 @@ __device__ __forceinline__ unsigned long long st_uniform64(unsigned long long v)
 
 struct StLds {   // carve-up of the dynamic LDS of speed_dp_kernel
     double *o_s_in, *o_s_out, *o_t_in, *o_t_out, *o_ux, *o_uy, *o_len;   // [max_obs] each, squeezed
-    double* iv;       // [10][max_obs][2]  reach intervals (lo, hi): class 0 = regular edges, 1 = edges from the origin
+    double* iv;       // [2][max_obs][5][2]  reach intervals (lo, hi) per class (0 = regular edges, 1 = edges from the origin), obstacle
+                      //                     and sample: the eight bounds an edge tests against one obstacle are 80 contiguous bytes,
+                      //                     fetched by one burst of LDS reads (sample-major they were four dependent round trips)
     double* node_c;   // [40][max_obs]     cost of the source NODES of a column against every obstacle (sample m = 1)
     double* t_tab;    // [10]              sample times of the two classes
     double* s_tab;    // [40]              s of the grid rows
@@ -167,8 +169,8 @@ __device__ __forceinline__ void st_column_setup(const StDev& d, const StLds& L, 
             lo = INFINITY;
             hi = -INFINITY;
         }
-        L.iv[(slot * MO + j) * 2] = lo;
-        L.iv[(slot * MO + j) * 2 + 1] = hi;
+        L.iv[((cls * MO + j) * kStSamples + m) * 2] = lo;
+        L.iv[((cls * MO + j) * kStSamples + m) * 2 + 1] = hi;
         if (some) atomicOr(&L.colmask[(c & 1) * 2 + cls], (unsigned long long)1 << j);
     }
     if (x0 < 10) {
@@ -277,16 +279,18 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
 #pragma unroll
             for (int m = 0; m < kStSamples; ++m) mask[m] = 0;
             const double* ivl = L.iv + (size_t)slot0 * MO * 2;
+            const double sm0 = s_m(0), sm2 = s_m(2), sm3 = s_m(3), sm4 = s_m(4);
             for (unsigned long long rest = colmask; rest; rest &= rest - 1) {
                 const int jj = ctz64(rest);
-#pragma unroll
-                for (int m = 0; m < kStSamples; ++m) {
-                    if (m == 1) continue;
-                    const double lo = ivl[(m * MO + jj) * 2], hi = ivl[(m * MO + jj) * 2 + 1];
-                    const double sm = s_m(m);
-                    if (active && sm > lo && sm < hi) mask[m] |= (MaskT)1 << jj;
-                }
+                const double* q = ivl + jj * (2 * kStSamples);
+                const double lo0 = q[0], hi0 = q[1], lo2 = q[4], hi2 = q[5], lo3 = q[6], hi3 = q[7], lo4 = q[8], hi4 = q[9];
+                const MaskT bit = (MaskT)1 << jj;
+                mask[0] |= ((sm0 > lo0) & (sm0 < hi0)) ? bit : (MaskT)0;   // '&': no short-circuit branch
+                mask[2] |= ((sm2 > lo2) & (sm2 < hi2)) ? bit : (MaskT)0;   // '&': no short-circuit branch
+                mask[3] |= ((sm3 > lo3) & (sm3 < hi3)) ? bit : (MaskT)0;   // '&': no short-circuit branch
+                mask[4] |= ((sm4 > lo4) & (sm4 < hi4)) ? bit : (MaskT)0;   // '&': no short-circuit branch
             }
+            if (!active) mask[0] = mask[2] = mask[3] = mask[4] = 0;       // column 0: only the 40 edges from the origin exist
             const int cnt0 = sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[0]) : __popc((unsigned)mask[0]);
             int cnt = cnt0;
 #pragma unroll
