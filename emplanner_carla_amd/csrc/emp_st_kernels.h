@@ -97,15 +97,15 @@ struct StLds {   // carve-up of the dynamic LDS of speed_dp_kernel
     double* p_sdot;   // [2][40]
     double* row0;     // [16]              cost of row 0 in every column (terminal search)
     unsigned long long* colmask;   // [2][2] obstacles with a non-empty interval in the column: [column parity][class]
-    double* list_s;   // [waves][cap]      sample s of a pair, overwritten by the pair's cost
-    uint32_t* list_c; // [waves][cap]      obstacle | sample slot << 8
+    double* list_s;   // [waves][cap + 1]  sample s of a pair, overwritten by the pair's cost
+    uint32_t* list_c; // [waves][cap + 1]  obstacle | sample slot << 8
     unsigned char* part_k;  // [8][40]
     unsigned char* t_node;  // [40][16]
 };
 inline size_t speed_dp_lds_bytes(int max_obs) {
     return ((27 + st::kRows) * (size_t)max_obs + 10 + st::kRows + kStParts * st::kRows + 4 * st::kRows + st::kCols + 4 +
-            kStWaves * kStListCap) * sizeof(double) +
-           kStWaves * kStListCap * sizeof(uint32_t) + kStParts * st::kRows + st::kRows * st::kCols;
+            kStWaves * (kStListCap + 1)) * sizeof(double) +
+           kStWaves * (kStListCap + 1) * sizeof(uint32_t) + 4 + kStParts * st::kRows + st::kRows * st::kCols;
 }
 __device__ __forceinline__ StLds st_carve(double* lds, int max_obs) {
     StLds L;
@@ -126,8 +126,8 @@ __device__ __forceinline__ StLds st_carve(double* lds, int max_obs) {
     L.row0 = L.p_sdot + 2 * st::kRows;
     L.colmask = reinterpret_cast<unsigned long long*>(L.row0 + st::kCols);
     L.list_s = L.row0 + st::kCols + 4;
-    L.list_c = reinterpret_cast<uint32_t*>(L.list_s + kStWaves * kStListCap);
-    L.part_k = reinterpret_cast<unsigned char*>(L.list_c + kStWaves * kStListCap);
+    L.list_c = reinterpret_cast<uint32_t*>(L.list_s + kStWaves * (kStListCap + 1));
+    L.part_k = reinterpret_cast<unsigned char*>(L.list_c + kStWaves * (kStListCap + 1));
     L.t_node = L.part_k + kStParts * st::kRows;
     return L;
 }
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
 
     const int j = tid % kRows, kb = tid / kRows;
     const double s1 = L.s_tab[j];
-    double* my_s = L.list_s + wave * kStListCap;
-    uint32_t* my_c = L.list_c + wave * kStListCap;
+    double* my_s = L.list_s + wave * (kStListCap + 1);      // [cap] + one spare entry that takes the writes outside a window
+    uint32_t* my_c = L.list_c + wave * (kStListCap + 1);
     const size_t tb = (size_t)b * kRows * kCols;
 
 #pragma unroll 1
@@ -280,15 +280,19 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             for (int m = 0; m < kStSamples; ++m) mask[m] = 0;
             const double* ivl = L.iv + (size_t)slot0 * MO * 2;
             const double sm0 = s_m(0), sm2 = s_m(2), sm3 = s_m(3), sm4 = s_m(4);
+            const double* my_nodes = L.node_c + k * MO;
+            MaskT node_nz = 0;                          // obstacles the source node has a non-zero cost against (sample 1)
             for (unsigned long long rest = colmask; rest; rest &= rest - 1) {
                 const int jj = ctz64(rest);
                 const double* q = ivl + jj * (2 * kStSamples);
                 const double lo0 = q[0], hi0 = q[1], lo2 = q[4], hi2 = q[5], lo3 = q[6], hi3 = q[7], lo4 = q[8], hi4 = q[9];
+                const double nc = my_nodes[jj];
                 const MaskT bit = (MaskT)1 << jj;
                 mask[0] |= ((sm0 > lo0) & (sm0 < hi0)) ? bit : (MaskT)0;   // '&': no short-circuit branch
-                mask[2] |= ((sm2 > lo2) & (sm2 < hi2)) ? bit : (MaskT)0;   // '&': no short-circuit branch
-                mask[3] |= ((sm3 > lo3) & (sm3 < hi3)) ? bit : (MaskT)0;   // '&': no short-circuit branch
-                mask[4] |= ((sm4 > lo4) & (sm4 < hi4)) ? bit : (MaskT)0;   // '&': no short-circuit branch
+                mask[2] |= ((sm2 > lo2) & (sm2 < hi2)) ? bit : (MaskT)0;
+                mask[3] |= ((sm3 > lo3) & (sm3 < hi3)) ? bit : (MaskT)0;
+                mask[4] |= ((sm4 > lo4) & (sm4 < hi4)) ? bit : (MaskT)0;
+                node_nz |= (nc != 0.0) ? bit : (MaskT)0;                    // NaN counts; x + 0.0 == x for the sums of costs here
             }
             if (!active) mask[0] = mask[2] = mask[3] = mask[4] = 0;       // column 0: only the 40 edges from the origin exist
             const int cnt0 = sizeof(MaskT) == 8 ? __popcll((unsigned long long)mask[0]) : __popc((unsigned)mask[0]);
@@ -301,9 +305,9 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             const int off = incl - cnt;
             double obs = 0.0;
             bool nodes_done = false;
-            const double* my_nodes = L.node_c + k * MO;
-            auto add_nodes = [&]() {                  // sample 1: the source node against the column's obstacles, in order
-                for (unsigned long long rest = colmask; rest; rest &= rest - 1) obs = obs + my_nodes[ctz64(rest)];
+            auto add_nodes = [&]() {                  // sample 1: the source node against the column's obstacles, in order -
+                for (MaskT rest = node_nz; rest; rest &= rest - 1)          // the exact zeros (nearly all of them) left out
+                    obs = obs + my_nodes[sizeof(MaskT) == 8 ? ctz64((uint64_t)rest) : __ffs((unsigned)rest) - 1];
                 nodes_done = true;
             };
 #pragma unroll 1
@@ -314,10 +318,9 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                 for (int m = 0; m < kStSamples; ++m) {
                     for (MaskT rest = mask[m]; rest; rest &= rest - 1) {
                         const int jj = sizeof(MaskT) == 8 ? ctz64((uint64_t)rest) : __ffs((unsigned)rest) - 1;
-                        if (idx >= 0 && idx < kStListCap) {
-                            my_s[idx] = s_m(m);
-                            my_c[idx] = (uint32_t)jj | (uint32_t)(slot0 + m) << 8;
-                        }
+                        const int at = (unsigned)idx < (unsigned)kStListCap ? idx : kStListCap;   // outside the window: the spare entry
+                        my_s[at] = s_m(m);
+                        my_c[at] = (uint32_t)jj | (uint32_t)(slot0 + m) << 8;
                         ++idx;
                     }
                 }
