@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "emp_st_core.h"
 
 namespace emp {
@@ -63,10 +65,10 @@ constexpr int kStParts = kStBlock / st::kRows;   // 8 partial minima per destina
 __device__ __forceinline__ int st_wave_incl_sum(int v) {
     // inclusive prefix sum over the 64 lanes: Hillis-Steele inside the 16-lane rows, then the row totals travel
     // with row_bcast:15 / row_bcast:31 (lanes without a source add 0)
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1 (bound_ctrl: a lane without a source reads 0 - the
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2  move folds into the add)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
     return v;
@@ -256,24 +258,26 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
         if (tid == 0) L.colmask[prev * 2] = L.colmask[prev * 2 + 1] = 0;   // the next column's setup ORs into them after [C]
         double best = INFINITY;
         int best_k = 0;
-        const int n_src = c == 0 ? 1 : kStSamples;   // five source rows per lane; only the origin in column 0
-#pragma unroll 1
-        for (int i = 0; i < n_src; ++i) {
+        // One pass = one source row per lane (five per lane and column; only the origin in column 0).  GENERAL passes hold edges
+        // from the DP origin (k == 0: the first pass of wavefront 0, where lanes 0-39 start at the origin and lanes 40-63 at row
+        // 1; all of column 0) and select per lane; every other pass is REGULAR - every lane an edge between two grid columns, whose
+        // t1 - t0 is 0.5 exactly: dt = 0.125, (s1 - s0) / 0.5 = (s1 - s0) * 2 (st::div_dt), one class of intervals, no selects.
+        // Same operations on the same operands either way (round 6: the regular form is 30 instructions a pass shorter).
+        auto edge_pass = [&](auto general_tag, const int i) {
+            constexpr bool GENERAL = decltype(general_tag)::value;
             const int k = kb + kStParts * i;          // interleaved: every wavefront sees source rows from the whole s range
-            const bool active = c > 0 || tid < kRows;
-            const bool from_origin = k == 0;          // ref :208-212 (and every edge of column 0, ref :125-131)
-            unsigned long long colmask = (wave == 0 && i == 0) ? mask_all : mask_reg;
+            const bool active = !GENERAL || c > 0 || tid < kRows;
+            const bool from_origin = GENERAL && k == 0;   // ref :208-212 (and every edge of column 0, ref :125-131)
+            unsigned long long colmask = GENERAL ? mask_all : mask_reg;
             if (EMP_ST_PROBE == 1) colmask &= (unsigned long long)(d.B < 0);   // opaque zero
             const double s0 = from_origin ? 0.0 : L.s_tab[k];
             const double t0 = from_origin ? 0.0 : t_of_col(c - 1);
             const double v0 = from_origin ? v_origin : L.p_sdot[prev * kRows + k];
-            const double dt = (t1 - t0) * 0.25;
-            // (s1 - s0) / (t1 - t0): edges between grid columns have t1 - t0 == 0.5 exactly, a multiplication by 2; only
-            // edges from the origin divide, and only wavefront 0 has any (one wave-level branch, not a select)
-            double ks = (s1 - s0) * 2.0;
-            if (wave == 0 && i == 0) ks = div_dt(s1 - s0, t1 - t0);
+            const double dt = GENERAL ? (t1 - t0) * 0.25 : 0.125;
+            // (s1 - s0) / (t1 - t0): only edges from the origin divide
+            const double ks = GENERAL ? div_dt(s1 - s0, t1 - t0) : (s1 - s0) * 2.0;
             const int slot0 = from_origin ? kStSamples : 0;
-            auto s_m = [&](int m) { return s0 + (ks * (double)(m - 1)) * dt; };   // ref :252 (rebuilt where used: registers)
+            auto s_m = [&](int m) { return s0 + (ks * (double)(m - 1)) * dt; };   // ref :252
             // ---- candidate pairs of samples 0, 2, 3, 4: lo < s_m < hi --------------------------------------
             MaskT mask[kStSamples];
 #pragma unroll
@@ -337,14 +341,28 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             }
             if (!nodes_done) add_nodes();
             double acc, ref;
-            kinematic_cost(d.w, s0, t0, v0, s1, t1, &acc, &ref);
+            if (GENERAL) {
+                kinematic_cost(d.w, s0, t0, v0, s1, t1, &acc, &ref);
+            } else {                                  // st::kinematic_cost with t1 - t0 == 0.5: v = ks, a = (v - v0) * 2
+                const double a = (ks - v0) * 2.0, e = ks - d.w.v_ref, a2 = a * a;
+                ref = d.w.w_ref * (e * e);
+                acc = (4.0 > a && a > -6.0) ? d.w.w_acc * a2 : (100000.0 * d.w.w_acc) * a2;
+            }
             const double cand = ((obs + acc) + ref) + L.p_cost[prev * kRows + k];
             if (c == 0) best = cand;                  // column 0 stores the edge cost as it is
             else if (cand < best) {
                 best = cand;
                 best_k = k;
             }
+        };
+        int i_first = 0;
+        if (c == 0 || wave == 0) {                    // (column 0: wavefronts 1-4 have no edge at all)
+            if (wave == 0) edge_pass(std::true_type{}, 0);
+            i_first = 1;
         }
+        const int i_end = c == 0 ? 0 : kStSamples;
+#pragma unroll 1
+        for (int i = i_first; i < i_end; ++i) edge_pass(std::false_type{}, i);
         L.part_c[tid] = best;
         L.part_k[tid] = (unsigned char)best_k;
         __syncthreads();   // [C] partial minima complete; nobody reads this column's intervals any more
