@@ -56,6 +56,7 @@ constexpr int kStListCap = 256;   // list entries per wavefront (a longer list i
 //   1  no obstacle reaches any column (interval tests, node sums, pair lists all empty: the kinematic DP alone)
 //   2  interval tests and node sums run, no pair is emitted or costed
 //   3  pairs are emitted and summed, the cost of a window is not computed
+//   5  the whole kernel, and speed_t [b][0..2] = passes of a wavefront with pairs, pairs, 64-pair cost rounds of the scene
 #ifndef EMP_ST_PROBE
 #define EMP_ST_PROBE 0
 #endif
@@ -215,6 +216,8 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ob = (size_t)b * MO;
     __shared__ int n_live_s;
+    __shared__ int probe_cnt[3];
+    if (EMP_ST_PROBE == 5 && threadIdx.x < 3) probe_cnt[threadIdx.x] = 0;
     if (tid < 64) {  // max_obs <= 64: one wavefront squeezes the present obstacles to the front, in order (ref :255)
         const bool has = tid < MO && !isnan(g_s_in[ob + (tid < MO ? tid : 0)]);
         const unsigned long long m = __ballot(has);
@@ -306,6 +309,11 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
             const int incl = st_wave_incl_sum(cnt);
             int total = __builtin_amdgcn_readlane(incl, 63);
             if (EMP_ST_PROBE == 2) total *= (d.B < 0);
+            if (EMP_ST_PROBE == 5 && lane == 0 && total > 0) {
+                atomicAdd(&probe_cnt[0], 1);
+                atomicAdd(&probe_cnt[1], total);
+                atomicAdd(&probe_cnt[2], (total + 63) / 64);
+            }
             const int off = incl - cnt;
             double obs = 0.0;
             bool nodes_done = false;
@@ -421,6 +429,8 @@ __global__ __launch_bounds__(kStBlock, EMP_ST_WAVES) void speed_dp_kernel(StDev 
                 --col;
             }
         }
+        if (EMP_ST_PROBE == 5)
+            for (int x = 0; x < 3; ++x) speed_t[(size_t)b * kCols + x] = (double)probe_cnt[x];
     }
 }
 
