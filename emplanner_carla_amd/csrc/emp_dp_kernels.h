@@ -444,8 +444,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     const int nob = live ? min(min(max(n_obs[b], 0), P.max_obs), kMaskBits) : 0;
     const double* my_obs_s = t_obs_s + sl * P.max_obs;
     const double* my_obs_l = t_obs_l + sl * P.max_obs;
-    double* my_lo = box_all + ((size_t)(2 * wave) * P.S + sl) * P.max_obs;
-    double* my_hi = my_lo + (size_t)P.S * P.max_obs;
+    double* my_band = box_all + ((size_t)wave * P.S + sl) * 2 * P.max_obs;   // [max_obs][2]: (lo, hi) of an obstacle side by side - one LDS
+                                                                            // read for both (two arrays: two dependent round trips a test)
     unsigned* r_code = reinterpret_cast<unsigned*>(rings + (size_t)wave * edge_ring_bytes(P.max_obs));   // [2][kRingSlots]
     unsigned char* r_mask = reinterpret_cast<unsigned char*>(r_code + 2 * kRingSlots);                     // [kRingSlots] of mask_bytes
     auto put_mask = [&](int slot, MASK v) {
@@ -524,8 +524,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
                 const double dx = fmax(fmax(s0 - os, os - s9), 0.0);
                 const double thr = 36.5 - dx * dx;
                 const double r = sqrt(fmax(thr, 0.0));
-                my_lo[m] = thr > 0.0 ? ol - r : __builtin_inf();
-                my_hi[m] = thr > 0.0 ? ol + r : -__builtin_inf();
+                my_band[2 * m] = thr > 0.0 ? ol - r : __builtin_inf();
+                my_band[2 * m + 1] = thr > 0.0 ? ol + r : -__builtin_inf();
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -540,7 +540,8 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
                 const double l_lo = tab[kF_LLO * rr + p], l_hi = tab[kF_LHI * rr + p];
                 for (MASK rest = near_s; rest; rest &= rest - 1) {
                     const int m = (kMaskBits == 32 ? __ffs((int)rest) : __ffsll((long long)rest)) - 1;
-                    if (l_hi > my_lo[m] && l_lo < my_hi[m]) pass |= (MASK)1 << m;
+                    const double b_lo = my_band[2 * m], b_hi = my_band[2 * m + 1];
+                    pass |= ((l_hi > b_lo) & (l_lo < b_hi)) ? (MASK)1 << m : (MASK)0;       // '&': no short-circuit branches
                 }
                 if (pass == 0) store_edge(j, k, lane, (smooth + 0.0) + tab[kF_REF * rr + p]);
             }
