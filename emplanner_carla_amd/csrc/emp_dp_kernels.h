@@ -506,28 +506,35 @@ __global__ EMP_EDGE_RING_BOUNDS void dp_edge_ring_kernel(DpDev P, const double* 
     for (int j = j_begin + wave; j < j_end; j += waves) {
         const double s0 = ps + (double)j * P.sample_s;                  // ref :330 pre_node_s
         const double s9 = s0 + t_smp[kSamples - 1];
-        // longitudinal half of the reach test, once per (scene, column): as dp_edge_column
-        MASK near_s = 0;
-        for (int m = 0; m < nob; ++m) {
-            const double os = my_obs_s[m];
-            if (os > s0 - 6.5 && os < s9 + 6.5) near_s |= (MASK)1 << m;
-        }
         // The box test (obstacle_box_in_reach: dx^2 + dy^2 < 36.5 with dy = max(l_lo - ol, ol - l_hi, 0)) solved for the lateral
         // band once per (scene, column, obstacle): with r = sqrt(36.5 - dx^2) an edge's box [l_lo, l_hi] is in reach iff
         // l_hi > ol - r and l_lo < ol + r - two compares per (edge, obstacle) instead of seven operations.  Like the box test
         // itself this only PRUNES pairs that contribute exactly 0 (every sample 6.04 m or more away, against the 6 m where a
         // cost begins): the half metre of margin dwarfs the rounding of the square root, and a pair pruned by one form and not
         // the other contributes 0 either way, so the tensor does not depend on which form a kernel uses.
-        if (live) {
-            for (int m = i; m < nob; m += row) {
+        // The scene's `row` lanes share the work - lane i the obstacles i, i + row, ... - and the longitudinal half of the reach
+        // test falls out of it: an obstacle is in reach of the column iff its band exists (thr > 0: dx < 6.04).  Every lane of
+        // the scene reads those verdicts out of ONE ballot per `row` obstacles (the scene's lanes are neighbours), where each
+        // lane used to walk all the scene's obstacles itself (round 6: nob LDS reads and 4 nob instructions a column and lane;
+        // its 6.5 m margin let through a few obstacles more, whose bands were empty all the same).
+        MASK near_s = 0;
+        const int my_first_lane = sl * row;
+        for (int m0 = 0; m0 < P.max_obs && m0 < kMaskBits; m0 += row) {      // wave-uniform trip count
+            const int m = m0 + i;
+            bool in_reach = false;
+            if (live && m < nob) {
                 const double os = my_obs_s[m], ol = my_obs_l[m];
                 const double dx = fmax(fmax(s0 - os, os - s9), 0.0);
                 const double thr = 36.5 - dx * dx;
                 const double r = sqrt(fmax(thr, 0.0));
-                my_band[2 * m] = thr > 0.0 ? ol - r : __builtin_inf();
-                my_band[2 * m + 1] = thr > 0.0 ? ol + r : -__builtin_inf();
+                in_reach = thr > 0.0;
+                my_band[2 * m] = in_reach ? ol - r : __builtin_inf();
+                my_band[2 * m + 1] = in_reach ? ol + r : -__builtin_inf();
             }
+            const unsigned long long verdicts = (__ballot(in_reach) >> my_first_lane) & ((1ull << row) - 1);   // obstacles m0 .. m0 + row - 1 of MY scene
+            near_s |= (MASK)((MASK)verdicts << m0);
         }
+        if (!live) near_s = 0;
         __builtin_amdgcn_wave_barrier();
         const double F = jerk_unit_sum(t_smp, s0);                      // the column's jerk factor
         if (live && i == 0) f_tab[((j - j_begin - wave) / waves) * P.S + s] = F;
