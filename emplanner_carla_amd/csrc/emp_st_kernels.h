@@ -48,8 +48,8 @@ constexpr int kStBlock = 320;
 // the first minimum of its five candidates; lanes 0-39 then take the minimum over the eight partial results, the
 // lowest k winning ties (= the reference's ordered strict-< scan, ref :138-152).
 #ifndef EMP_ST_WAVES
-#define EMP_ST_WAVES 5          // wavefronts per SIMD the register allocation aims for: 4 (127 VGPRs) 3.2 ms, 5 (96) 2.4 ms, 6 (80) 2.3 ms per 4096
-                              // scenes alone - but beside the cycle kernels of config 5 the 6-wave build takes 10.7 ms per step, the 5-wave build 5.8
+#define EMP_ST_WAVES 5          // wavefronts per SIMD the register allocation aims for.  Round 6, per 4096 scenes alone: 4 (128 VGPRs) 2.6 ms,
+                              // 5 (96) 2.02 ms, 6 (80) 2.02 ms and the same configs[4] step (round 3's kernel: 3.2 / 2.4 / 2.3 ms)
 #endif
 constexpr int kStListCap = 256;   // list entries per wavefront (a longer list is processed in windows)
 // Development builds only (tools/st_phase_probe.py; results of a gutted kernel mean nothing, durations do): -DEMP_ST_PROBE=

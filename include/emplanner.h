@@ -177,7 +177,7 @@ int emp_set_timing_filter(emp_ctx* ctx, const char* kernel);
  *                          d2h streams (EMP_HOST_PINNED cycles) + EMP_OPT_FOREIGN_STREAMS (the streams the rest of the process
  *                          uses: default 1, the caller's own; add a gather stream, RCCL's) - else EMP_PIPELINE_STAGED (two
  *                          queues).  emp_pipeline_form reports the choice.  Measured on 4 queues (HIP's default): three lanes
- *                          0.274 ms per 4096-scene step against the staged form's 0.207; on 12: 0.191 against 0.207
+ *                          0.272-0.274 ms per 4096-scene step against the staged form's 0.202-0.207; on 12: 0.187-0.191 against the same
  *                          (profiles/r06_bench_queues*.json; tests/test_gpu_fullsize.py).
  * Consequences for the caller: the outputs of a call are complete on emp_result_stream() - in lane mode the lane of the
  * LATEST emp_plan_cycle call, so ask after every call - and emp_synchronize waits for every stream; each call in flight
