@@ -618,7 +618,11 @@ __global__ void path_to_xy_kernel(int B, int max_ref, int max_pts, const double*
 // doubles of LDS per group (scene)
 template <int G, int R = 0>
 __host__ __device__ constexpr int cycle_qp_group_words(int cap, int max_obs) {
-    if (R > 0) return path_qp_words_rows<(R > 0 ? G : 8), (R > 0 ? R : 3)>() + (4 * max_obs <= 4 * G * R ? 0 : 4 * max_obs);
+    // Rows form: an ODD number of doubles.  The eight (four) groups of a wavefront read the same offsets of their own slices in
+    // every LDS instruction; with a stride that is a multiple of 32 doubles they would all sit on the same banks (468 doubles at
+    // R = 3: the station and Hessian arrays at 2-4 times their conflict-free cost, 14.5 % of the kernel's wavefront cycles in
+    // SQ_LDS_BANK_CONFLICT, profiles/r06a_sq.csv) - an odd stride walks the groups across the banks.
+    if (R > 0) return (path_qp_words_rows<(R > 0 ? G : 8), (R > 0 ? R : 3)>() + (4 * max_obs <= 4 * G * R ? 0 : 4 * max_obs)) | 1;
     return 5 * cap + 4 * max_obs + (G == 32 ? path_qp_words_pair() : path_qp_words(cap));
 }
 template <int G, int R = 0>
